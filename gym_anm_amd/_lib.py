@@ -1,0 +1,173 @@
+"""ctypes binding of the C ABI (include/anm_mi355x.h) and the loader of the per-topology library.
+
+The only library this module ever loads on its own is the hipcc-built
+``gym_anm_amd/_build/libanm_<topology>.so``.  If it is missing and cannot be built, or if no
+MI355X is visible when a model is created, a :class:`~gym_anm_amd.errors.HipExtensionError` is
+raised: there is no CPU code path in the product.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import codegen
+from . import errors as E
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class NetworkDesc(C.Structure):
+    _fields_ = [
+        ("n_bus", C.c_int32), ("n_dev", C.c_int32), ("n_branch", C.c_int32),
+        ("base_mva", C.c_double), ("delta_t", C.c_double), ("lamb", C.c_double),
+        ("bus_vmin", c_double_p), ("bus_vmax", c_double_p),
+        ("br_from", c_int32_p), ("br_to", c_int32_p),
+        ("br_series", c_double_p), ("br_shunt", c_double_p), ("br_tap", c_double_p), ("br_rate", c_double_p),
+        ("dev_type", c_int32_p), ("dev_bus", c_int32_p),
+        ("dev_pmin", c_double_p), ("dev_pmax", c_double_p), ("dev_qmin", c_double_p), ("dev_qmax", c_double_p),
+        ("dev_qp", c_double_p), ("dev_tau", c_double_p), ("dev_rho", c_double_p),
+        ("dev_soc_min", c_double_p), ("dev_soc_max", c_double_p), ("dev_eff", c_double_p),
+    ]  # fmt: skip
+
+
+class Dims(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ["n_bus", "n_dev", "n_branch", "n_load", "n_gen", "n_des", "action_dim", "state_base_dim",
+                 "full_dim", "const_doubles"]]  # fmt: skip
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [
+        ("K", C.c_int32), ("gamma", C.c_double), ("clip_e_loss", C.c_double), ("clip_penalty", C.c_double),
+        ("obs_low", c_double_p), ("obs_high", c_double_p), ("series", c_double_p), ("period", C.c_int32),
+    ]  # fmt: skip
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32)]
+
+
+FULL_FIELDS = ["bus_p", "bus_q", "bus_v_magn", "bus_v_ang", "bus_i_magn", "bus_i_ang", "dev_p", "dev_q", "des_soc",
+               "gen_p_max", "branch_p", "branch_q", "branch_s", "branch_i_magn", "branch_i_ang"]  # fmt: skip
+
+
+class FullLayout(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in FULL_FIELDS + ["size"]]
+
+
+SOLVE_F64, SOLVE_F32 = 0, 1
+
+_P = C.c_void_p  # raw device (or, for the test double, host) pointers are passed as integers
+
+# name -> (restype, argtypes): every symbol include/anm_mi355x.h declares
+ABI = {
+    "anm_last_error": (C.c_char_p, []),
+    "anm_topology_name": (C.c_char_p, []),
+    "anm_topology_signature": (C.c_char_p, []),
+    "anm_device_count": (C.c_int, []),
+    "anm_model_create": (C.c_int, [C.POINTER(NetworkDesc), C.POINTER(C.c_void_p)]),
+    "anm_model_destroy": (None, [C.c_void_p]),
+    "anm_model_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
+    "anm_model_set_env": (C.c_int, [C.c_void_p, C.POINTER(EnvConfig)]),
+    "anm_model_get_ybus": (C.c_int, [C.c_void_p, c_double_p]),
+    "anm_model_full_layout": (C.c_int, [C.c_void_p, C.POINTER(FullLayout)]),
+    "anm_transition_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 11 + [C.POINTER(SolverOpts), _P]),
+    "anm_reset_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 10 + [C.POINTER(SolverOpts), _P]),
+    "anm_step_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 13 + [C.c_int32, C.c_uint64, _P,
+                                                                      C.POINTER(SolverOpts), _P]),
+    "anm_gather_obs_f64": (C.c_int, [C.c_int64, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "anm_time_step_launches": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 9 + [C.c_int32, C.c_uint64, _P,
+                                                                              C.POINTER(SolverOpts), _P, C.c_int32,
+                                                                              C.POINTER(C.c_float)]),
+}  # fmt: skip
+
+
+def bind(cdll):
+    """Attach argtypes / restypes; raises AttributeError if the library lacks a declared symbol."""
+    for name, (res, args) in ABI.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+class Backend:
+    """A bound per-topology library plus what the host layer needs to know about it."""
+
+    def __init__(self, cdll, device_type, path):
+        self.lib = bind(cdll)
+        self.device_type = device_type  # "cuda" for the product; the test double says "cpu"
+        self.path = path
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.anm_last_error()
+            raise E.HipExtensionError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def signature(self) -> str:
+        return self.lib.anm_topology_signature().decode()
+
+
+_CACHE = {}
+
+
+def load_for_topology(topo) -> Backend:
+    """Build (if needed) and load the gfx950 library specialised for ``topo``."""
+    name = codegen.topology_name(topo)
+    if name in _CACHE:
+        return _CACHE[name]
+    path = codegen.lib_path(name)
+    if not os.path.exists(path):
+        path = codegen.build_library(topo)  # raises HipExtensionError when hipcc is unavailable
+    try:
+        cdll = C.CDLL(path)
+    except OSError as ex:
+        raise E.HipExtensionError("cannot load the gfx950 library %s: %s" % (path, ex)) from ex
+    be = Backend(cdll, "cuda", path)
+    if be.signature() != codegen.topology_signature(topo):
+        raise E.HipExtensionError("library %s was built for another topology (%s)" % (path, be.signature()))
+    _CACHE[name] = be
+    return be
+
+
+def as_c(arr, dtype):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    ptr_t = c_double_p if dtype == np.float64 else c_int32_p
+    return a, a.ctypes.data_as(ptr_t)
+
+
+def network_desc(model):
+    """anm_network_desc for a :class:`gym_anm_amd.model.NetworkModel` (keeps the arrays alive)."""
+    keep = []
+
+    def d(a):
+        arr, p = as_c(a, np.float64)
+        keep.append(arr)
+        return p
+
+    def i(a):
+        arr, p = as_c(a, np.int32)
+        keep.append(arr)
+        return p
+
+    def cplx(a):
+        a = np.asarray(a, dtype=np.complex128)
+        return d(np.stack([a.real, a.imag], axis=-1))
+
+    desc = NetworkDesc(
+        n_bus=model.N_bus, n_dev=model.N_device, n_branch=model.N_branch,
+        base_mva=float(model.baseMVA), delta_t=float(model.delta_t), lamb=float(model.lamb),
+        bus_vmin=d(model.bus_vmin), bus_vmax=d(model.bus_vmax),
+        br_from=i(model.br_f), br_to=i(model.br_t),
+        br_series=cplx(model.br_series), br_shunt=cplx(model.br_shunt), br_tap=cplx(model.br_tap),
+        br_rate=d(model.br_rate),
+        dev_type=i(model.dev_type), dev_bus=i(model.dev_bus),
+        dev_pmin=d(model.dev_p_min), dev_pmax=d(model.dev_p_max), dev_qmin=d(model.dev_q_min),
+        dev_qmax=d(model.dev_q_max), dev_qp=d(model.dev_qp), dev_tau=d(model.dev_tau), dev_rho=d(model.dev_rho),
+        dev_soc_min=d(model.dev_soc_min), dev_soc_max=d(model.dev_soc_max), dev_eff=d(model.dev_eff),
+    )  # fmt: skip
+    return desc, keep

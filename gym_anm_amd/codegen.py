@@ -1,0 +1,260 @@
+"""Topology compiler: network structure -> constexpr descriptor -> one gfx950 library per topology.
+
+The per-environment kernels (csrc/anm_device.hpp) are templates over a ``Topo`` descriptor so that
+every loop over buses / branches / devices / admittance non-zeros / Jacobian blocks is unrolled
+with constant indices and the whole per-environment working set stays in VGPRs.  This module
+
+1. does the *symbolic* part of the sparse block-LU used inside Newton-Raphson once per topology
+   (minimum-degree elimination order over the non-slack buses, fill-in, the flat op lists the
+   kernel replays every iteration),
+2. writes the descriptor header, and
+3. drives ``hipcc --offload-arch=gfx950`` to build ``libanm_<name>.so`` in-tree
+   (``gym_anm_amd/_build/``), ahead of time for the stock topologies (``build_stock``) or on
+   first use for a new one.
+
+Nothing here has a counterpart in the reference (which rebuilds a SciPy sparse Jacobian and calls
+SuperLU on every Newton iteration, ``solve_load_flow.py:123-164,220``); numerically the kernel
+solves the same linear system.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+
+from . import errors as E
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+BUILD_DIR = os.path.join(PKG_DIR, "_build")
+
+LOAD, SLACK, CLASSICAL, RENEWABLE, STORAGE = -1, 0, 1, 2, 3
+
+
+def topology_signature(topo) -> str:
+    n_bus, branches, devices = topo
+    return "N%d|B%s|D%s" % (
+        n_bus,
+        ",".join("%d-%d" % ft for ft in branches),
+        ",".join("%d@%d" % tb for tb in devices),
+    )
+
+
+def topology_name(topo) -> str:
+    h = hashlib.sha1(topology_signature(topo).encode()).hexdigest()[:10]
+    return "n%db%dd%d_%s" % (topo[0], len(topo[1]), len(topo[2]), h)
+
+
+def symbolic_block_lu(n_bus, branches):
+    """Symbolic factorisation of the bus-block Jacobian over buses 1..n_bus-1.
+
+    Returns a dict of flat lists (see emit_header).  Bus indices are the real ones (1-based among
+    unknowns because bus 0 is the slack); block ids index the compact list of structurally
+    non-zero 2x2 blocks after fill-in.
+    """
+    unknown = list(range(1, n_bus))
+    adj = {u: set() for u in unknown}
+    for f, t in branches:
+        if f != 0 and t != 0 and f != t:
+            adj[f].add(t)
+            adj[t].add(f)
+    # Y-pattern blocks first (row-major), fill appended later
+    blocks = {}
+    for i in unknown:
+        for k in sorted(adj[i] | {i}):
+            blocks[(i, k)] = len(blocks)
+    fill = []
+    work = {u: set(v) for u, v in adj.items()}
+    remaining = set(unknown)
+    piv, l_i, l_blk, lseg = [], [], [], [0]
+    u_dst, u_src, useg = [], [], [0]
+    upper = {}
+    while remaining:
+        # minimum degree, ties -> larger bus index first (leaves of a feeder before its trunk)
+        k = min(remaining, key=lambda u: (len(work[u] & remaining), -u))
+        remaining.discard(k)
+        nb = sorted(work[k] & remaining)
+        piv.append(k)
+        upper[k] = nb
+        for i in nb:
+            for j in nb:
+                if (i, j) not in blocks:
+                    blocks[(i, j)] = len(blocks)
+                    fill.append(blocks[(i, j)])
+                if i != j:
+                    work[i].add(j)
+        for i in nb:
+            l_i.append(i)
+            l_blk.append(blocks[(i, k)])
+            for j in nb:
+                u_dst.append(blocks[(i, j)])
+                u_src.append(blocks[(k, j)])
+            useg.append(len(u_dst))
+        lseg.append(len(l_i))
+    b_j, b_blk, bseg = [], [], [0]
+    for k in piv:
+        for j in upper[k]:
+            b_j.append(j)
+            b_blk.append(blocks[(k, j)])
+        bseg.append(len(b_j))
+    return dict(blocks=blocks, fill=fill, piv=piv, l_i=l_i, l_blk=l_blk, lseg=lseg, u_dst=u_dst, u_src=u_src,
+                useg=useg, b_j=b_j, b_blk=b_blk, bseg=bseg)  # fmt: skip
+
+
+def _arr(name, values, typ="int"):
+    vals = list(values)
+    body = ", ".join(str(int(v)) for v in vals) if vals else "0"
+    return "  static constexpr %s %s[%d] = {%s};" % (typ, name, max(len(vals), 1), body)
+
+
+def emit_header(topo, name=None) -> str:
+    n_bus, branches, devices = topo
+    name = name or topology_name(topo)
+    nd = len(devices)
+    loads = [k for k, (t, _) in enumerate(devices) if t == LOAD]
+    gens = [k for k, (t, _) in enumerate(devices) if t in (CLASSICAL, RENEWABLE)]
+    des = [k for k, (t, _) in enumerate(devices) if t == STORAGE]
+    setp = sorted(gens + des)
+    slot, sset = [-1] * nd, [-1] * nd
+    for lst in (loads, gens, des):
+        for s, k in enumerate(lst):
+            slot[k] = s
+    for s, k in enumerate(setp):
+        sset[k] = s
+    # Y pattern (row-major): diagonal of every bus that has a branch + both directions of each branch
+    pat = set()
+    for f, t in branches:
+        pat.update({(f, t), (t, f), (f, f), (t, t)})
+    for i in range(n_bus):
+        pat.add((i, i))
+    ypat = sorted(pat)
+    sym = symbolic_block_lu(n_bus, branches)
+    yblk = [sym["blocks"].get((i, j), -1) if (i != 0 and j != 0) else -1 for (i, j) in ypat]
+    diag = [-1] + [sym["blocks"][(u, u)] for u in range(1, n_bus)]
+    lines = [
+        "// Generated by gym_anm_amd/codegen.py -- topology descriptor '%s'." % name,
+        "// signature: %s" % topology_signature(topo),
+        "#pragma once",
+        "// internal linkage: several per-topology libraries can live in one process without their",
+        "// template instantiations (same mangled names) being merged by the dynamic linker",
+        "namespace {",
+        "struct Topo {",
+        '  static constexpr const char* NAME = "%s";' % name,
+        '  static constexpr const char* SIGNATURE = "%s";' % topology_signature(topo),
+        "  static constexpr int NB = %d, NU = %d, NBR = %d, ND = %d;" % (n_bus, n_bus - 1, len(branches), nd),
+        "  static constexpr int NLOAD = %d, NGEN = %d, NDES = %d, NSET = %d;" % (len(loads), len(gens), len(des), len(setp)),
+        "  static constexpr int SDIM = %d;  // 2 ND + NDES + NGEN" % (2 * nd + len(des) + len(gens)),
+        _arr("BR_F", [f for f, _ in branches]),
+        _arr("BR_T", [t for _, t in branches]),
+        _arr("DEV_TYPE", [t for t, _ in devices]),
+        _arr("DEV_BUS", [b for _, b in devices]),
+        _arr("DEV_SLOT", slot),
+        _arr("DEV_SET", sset),
+        "  static constexpr int NNZ = %d;" % len(ypat),
+        _arr("Y_I", [i for i, _ in ypat]),
+        _arr("Y_J", [j for _, j in ypat]),
+        _arr("YBLK", yblk),
+        "  static constexpr int NBLK = %d, NFILL = %d;" % (len(sym["blocks"]), len(sym["fill"])),
+        _arr("FILL_BLK", sym["fill"]),
+        _arr("DIAG", diag),
+        _arr("PIV", sym["piv"]),
+        "  static constexpr int NL = %d, NUOP = %d, NBS = %d;" % (len(sym["l_i"]), len(sym["u_dst"]), len(sym["b_j"])),
+        _arr("L_I", sym["l_i"]),
+        _arr("L_BLK", sym["l_blk"]),
+        _arr("LSEG", sym["lseg"]),
+        _arr("U_DST", sym["u_dst"]),
+        _arr("U_SRC", sym["u_src"]),
+        _arr("USEG", sym["useg"]),
+        _arr("B_J", sym["b_j"]),
+        _arr("B_BLK", sym["b_blk"]),
+        _arr("BSEG", sym["bseg"]),
+        "};",
+        "}  // namespace",
+        "",
+    ]
+    return "\n".join(lines)
+
+
+# --------------------------------------------------------------------------------------------
+# building
+# --------------------------------------------------------------------------------------------
+def lib_path(name: str) -> str:
+    return os.path.join(BUILD_DIR, "libanm_%s.so" % name)
+
+
+def header_path(name: str) -> str:
+    return os.path.join(BUILD_DIR, "topo_%s.h" % name)
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ftemplate-depth=4096",
+               "-fno-gpu-rdc", "-Wno-unused-value"]  # fmt: skip
+
+
+def _sources_mtime():
+    return max(
+        os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip", ".h"))
+    )
+
+
+def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):
+    """Write the descriptor and compile ``libanm_<name>.so`` for gfx950 (no GPU needed to build)."""
+    name = name or topology_name(topo)
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    hdr, lib = header_path(name), lib_path(name)
+    text = emit_header(topo, name)
+    if not os.path.exists(hdr) or open(hdr).read() != text:
+        with open(hdr, "w") as f:
+            f.write(text)
+    fresh = os.path.exists(lib) and os.path.getmtime(lib) >= max(os.path.getmtime(hdr), _sources_mtime())
+    if fresh and not force:
+        return lib
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise E.HipExtensionError(
+            "no prebuilt gfx950 library for topology '%s' (%s) and hipcc was not found to build it"
+            % (name, topology_signature(topo))
+        )
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + [
+        '-DANM_TOPO_HEADER="%s"' % hdr,
+        "-I", os.path.join(os.path.dirname(PKG_DIR), "include"),
+        os.path.join(CSRC, "anm_capi.hip"),
+        "-o", lib + ".tmp",
+    ]  # fmt: skip
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise E.HipExtensionError("hipcc failed for topology '%s':\n%s\n%s" % (name, res.stdout[-4000:], res.stderr[-8000:]))
+    os.replace(lib + ".tmp", lib)
+    return lib
+
+
+def stock_topologies():
+    """Topologies built ahead of time by ``__graft_entry__.build()``: the ANM6 case, the 30-bus
+    synthetic feeder of BASELINE.json config 4 and the small nets of the reference's own tests."""
+    from . import networks
+    from .model import NetworkModel
+
+    nets = {
+        "anm6": networks.anm6_network(),
+        "case30": networks.synthetic_radial_network(30, 0),
+        "2bus": networks.two_bus_network(),
+        "3bus": networks.three_bus_loop_network(),
+    }
+    return {k: NetworkModel(v, 0.25, 100).topology() for k, v in nets.items()}
+
+
+def build_stock(force=False, verbose=False):
+    out = {}
+    for nm, topo in stock_topologies().items():
+        out[nm] = build_library(topo, force=force, verbose=verbose)
+    return out

@@ -1,0 +1,366 @@
+// anm_capi.hip -- gfx950 kernels + the C ABI of include/anm_mi355x.h for ONE network topology
+// (the descriptor header is injected with -DANM_TOPO_HEADER=...; see gym_anm_amd/codegen.py).
+//
+// Launch shape: one thread per environment, 64-thread workgroups (one wavefront each) so that a
+// divergent Newton-Raphson straggler only ever holds back the 63 other environments of its own
+// wave and workgroups spread round-robin over the 8 XCDs; no LDS, no inter-workgroup traffic.
+// HBM traffic per environment step is the action row in and the obs/reward rows out (~250 B for
+// ANM6Easy); the network constants are wave-uniform scalar loads that stay in the scalar cache.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include ANM_TOPO_HEADER
+#include "anm_env_ops.hpp"
+#include "anm_pack.hpp"
+
+using namespace anm;
+
+namespace {
+
+constexpr int BLOCK = 64;
+
+thread_local std::string g_err;
+
+int fail(const char* what) {
+  g_err = what;
+  return -1;
+}
+int fail_hip(hipError_t e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+  return -2;
+}
+
+template <class JT>
+__global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C, TransitionIO io, SolverOpts so, int64_t n) {
+  const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
+  if (e >= n) return;
+  op_transition<Topo, JT>(C, io, so, e);
+}
+
+template <class JT>
+__global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+  const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
+  if (e >= n) return;
+  op_reset<Topo, JT>(C, io, so, e);
+}
+
+template <class JT>
+__global__ __launch_bounds__(BLOCK) void k_step(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+  const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
+  if (e >= n) return;
+  op_step<Topo, JT>(C, io, so, e);
+}
+
+__global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__ full, int n_obs,
+                             const int32_t* __restrict__ index, const double* __restrict__ scale,
+                             const double* __restrict__ low, const double* __restrict__ high,
+                             double* __restrict__ obs) {
+  const int64_t total = n * n_obs;
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t e = t / n_obs;
+    const int k = int(t - e * n_obs);
+    const double v = full[e * full_dim + index[k]] * scale[k];
+    obs[t] = fmin(fmax(v, low[k]), high[k]);
+  }
+}
+
+}  // namespace
+
+struct anm_model {
+  double* d_const = nullptr;    // device constant buffer (Layout<Topo>)
+  double* d_series = nullptr;   // device exogenous series [NEXO][period]
+  int period = 0;
+  int K = 0;
+  bool env_set = false;
+  std::vector<double> h_const;
+  std::vector<cplx> ybus;
+};
+
+namespace {
+
+int upload_const(anm_model* m) {
+  hipError_t e = hipMemcpy(m->d_const, m->h_const.data(), m->h_const.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail_hip(e, "hipMemcpy(constants)");
+  return 0;
+}
+
+SolverOpts solver(const anm_solver_opts* o, int& precision) {
+  SolverOpts s{1e-5, 100};
+  precision = ANM_SOLVE_F64;
+  if (o) {
+    s.tol = o->tol;
+    s.max_iter = o->max_iter;
+    precision = o->precision;
+  }
+  return s;
+}
+
+inline unsigned grid_for(int64_t n) { return unsigned((n + BLOCK - 1) / BLOCK); }
+
+}  // namespace
+
+extern "C" {
+
+const char* anm_last_error(void) { return g_err.c_str(); }
+const char* anm_topology_name(void) { return Topo::NAME; }
+const char* anm_topology_signature(void) { return Topo::SIGNATURE; }
+
+int anm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int anm_model_create(const anm_network_desc* desc, anm_model** out) {
+  if (!desc || !out) return fail("anm_model_create: null argument");
+  anm_model* m = new (std::nothrow) anm_model();
+  if (!m) return fail("out of host memory");
+  std::string err;
+  if (!pack_constants<Topo>(*desc, m->h_const, m->ybus, err)) {
+    delete m;
+    g_err = err;
+    return -3;
+  }
+  hipError_t e = hipMalloc(&m->d_const, m->h_const.size() * sizeof(double));
+  if (e != hipSuccess) {
+    delete m;
+    return fail_hip(e, "hipMalloc(constants)");
+  }
+  int rc = upload_const(m);
+  if (rc) {
+    hipFree(m->d_const);
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+void anm_model_destroy(anm_model* m) {
+  if (!m) return;
+  if (m->d_const) hipFree(m->d_const);
+  if (m->d_series) hipFree(m->d_series);
+  delete m;
+}
+
+int anm_model_dims(const anm_model* m, anm_dims* out) {
+  if (!m || !out) return fail("anm_model_dims: null argument");
+  out->n_bus = Topo::NB;
+  out->n_dev = Topo::ND;
+  out->n_branch = Topo::NBR;
+  out->n_load = Topo::NLOAD;
+  out->n_gen = Topo::NGEN;
+  out->n_des = Topo::NDES;
+  out->action_dim = Dims<Topo>::ADIM;
+  out->state_base_dim = Topo::SDIM;
+  out->full_dim = FullState<Topo>::SIZE;
+  out->const_doubles = Layout<Topo>::TOTAL;
+  return 0;
+}
+
+int anm_model_full_layout(const anm_model* m, anm_full_layout* o) {
+  if (!m || !o) return fail("anm_model_full_layout: null argument");
+  typedef FullState<Topo> F;
+  o->bus_p = F::BUS_P; o->bus_q = F::BUS_Q; o->bus_v_magn = F::BUS_VM; o->bus_v_ang = F::BUS_VA;
+  o->bus_i_magn = F::BUS_IM; o->bus_i_ang = F::BUS_IA; o->dev_p = F::DEV_P; o->dev_q = F::DEV_Q;
+  o->des_soc = F::DES_SOC; o->gen_p_max = F::GEN_PMAX; o->branch_p = F::BR_P; o->branch_q = F::BR_Q;
+  o->branch_s = F::BR_S; o->branch_i_magn = F::BR_IM; o->branch_i_ang = F::BR_IA; o->size = F::SIZE;
+  return 0;
+}
+
+int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
+  if (!m || !cfg) return fail("anm_model_set_env: null argument");
+  std::string err;
+  if (!pack_env<Topo>(*cfg, m->h_const, err)) {
+    g_err = err;
+    return -3;
+  }
+  m->K = cfg->K;
+  if (m->d_series) {
+    hipFree(m->d_series);
+    m->d_series = nullptr;
+  }
+  m->period = 0;
+  if (cfg->series && cfg->period > 0) {
+    if (cfg->K != 1) return fail("series mode needs exactly K = 1 auxiliary variable (the time index)");
+    const size_t bytes = sizeof(double) * size_t(Dims<Topo>::NEXO) * size_t(cfg->period);
+    hipError_t e = hipMalloc(&m->d_series, bytes ? bytes : 8);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(series)");
+    e = hipMemcpy(m->d_series, cfg->series, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpy(series)");
+    m->period = cfg->period;
+  }
+  m->env_set = true;
+  return upload_const(m);
+}
+
+int anm_model_get_ybus(const anm_model* m, double* y) {
+  if (!m || !y) return fail("anm_model_get_ybus: null argument");
+  for (size_t k = 0; k < m->ybus.size(); ++k) {
+    y[2 * k] = m->ybus[k].real();
+    y[2 * k + 1] = m->ybus[k].imag();
+  }
+  return 0;
+}
+
+int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const double* p_pot, const double* p_set,
+                       const double* q_set, double* soc, double* full, double* reward, double* e_loss,
+                       double* penalty, uint8_t* converged, int32_t* nr_iters, const anm_solver_opts* opts,
+                       void* stream) {
+  if (!m) return fail("anm_transition_f64: null model");
+  if (n <= 0) return 0;
+  if (!reward || !e_loss || !penalty || !converged) return fail("anm_transition_f64: null output");
+  TransitionIO io{p_load, p_pot, p_set, q_set, soc, full, reward, e_loss, penalty, converged, nr_iters};
+  int prec;
+  SolverOpts so = solver(opts, prec);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  cptr_t C = (cptr_t)m->d_const;
+  if (prec == ANM_SOLVE_F32)
+    hipLaunchKernelGGL(k_transition<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+  else
+    hipLaunchKernelGGL(k_transition<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_transition");
+  return 0;
+}
+
+int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, double* soc, double* state,
+                  double* obs, uint8_t* converged, uint8_t* terminated, int32_t* timestep, int32_t* nr_iters,
+                  double* full, const anm_solver_opts* opts, void* stream) {
+  if (!m) return fail("anm_reset_f64: null model");
+  if (!m->env_set) return fail("anm_reset_f64: call anm_model_set_env first");
+  if (n <= 0) return 0;
+  if (!init_state || !state || !obs || !converged || !terminated) return fail("anm_reset_f64: null argument");
+  EnvIO io{};
+  io.K = m->K;
+  io.init_state = init_state;
+  io.mask = mask;
+  io.soc = soc;
+  io.state = state;
+  io.obs = obs;
+  io.converged = converged;
+  io.terminated = terminated;
+  io.timestep = timestep;
+  io.nr_iters = nr_iters;
+  io.full = full;
+  int prec;
+  SolverOpts so = solver(opts, prec);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  cptr_t C = (cptr_t)m->d_const;
+  if (prec == ANM_SOLVE_F32)
+    hipLaunchKernelGGL(k_reset<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+  else
+    hipLaunchKernelGGL(k_reset<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_reset");
+  return 0;
+}
+
+static int make_step_io(anm_model* m, const double* action, const double* exo, const double* aux_next, double* soc,
+                        double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
+                        double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
+                        uint64_t rng_seed, int32_t* reset_count, EnvIO& io) {
+  if (!m) return fail("anm_step_f64: null model");
+  if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
+  if (!action || !state || !terminated || !obs || !reward || !e_loss || !penalty)
+    return fail("anm_step_f64: null argument");
+  if (Topo::NDES > 0 && !soc) return fail("anm_step_f64: null soc");
+  const bool series = exo == nullptr;
+  if (series && m->period <= 0) return fail("anm_step_f64: no exo given and the model has no series (set_env)");
+  if (!series && m->K > 0 && !aux_next) return fail("anm_step_f64: exo given without aux_next");
+  if (autoreset && (!series || !reset_count)) return fail("anm_step_f64: autoreset needs series mode and reset_count");
+  io = EnvIO{};
+  io.K = m->K;
+  io.action = action;
+  io.exo = exo;
+  io.aux_next = aux_next;
+  io.series = m->d_series;
+  io.period = m->period;
+  io.soc = soc;
+  io.state = state;
+  io.terminated = terminated;
+  io.timestep = timestep;
+  io.obs = obs;
+  io.reward = reward;
+  io.e_loss = e_loss;
+  io.penalty = penalty;
+  io.nr_iters = nr_iters;
+  io.full = full;
+  io.autoreset = autoreset;
+  io.rng_seed = rng_seed;
+  io.reset_count = reset_count;
+  return 0;
+}
+
+static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solver_opts* opts, hipStream_t s) {
+  int prec;
+  SolverOpts so = solver(opts, prec);
+  cptr_t C = (cptr_t)m->d_const;
+  if (prec == ANM_SOLVE_F32)
+    hipLaunchKernelGGL(k_step<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+  else
+    hipLaunchKernelGGL(k_step<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_step");
+  return 0;
+}
+
+int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
+                 double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
+                 double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
+                 uint64_t rng_seed, int32_t* reset_count, const anm_solver_opts* opts, void* stream) {
+  EnvIO io;
+  int rc = make_step_io(m, action, exo, aux_next, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
+                        nr_iters, full, autoreset, rng_seed, reset_count, io);
+  if (rc) return rc;
+  if (n <= 0) return 0;
+  return launch_step(m, io, n, opts, static_cast<hipStream_t>(stream));
+}
+
+int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double* soc, double* state,
+                           uint8_t* terminated, int32_t* timestep, double* obs, double* reward, double* e_loss,
+                           double* penalty, int32_t autoreset, uint64_t rng_seed, int32_t* reset_count,
+                           const anm_solver_opts* opts, void* stream, int32_t n_launch, float* ms_per_launch) {
+  EnvIO io;
+  int rc = make_step_io(m, action, nullptr, nullptr, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
+                        nullptr, nullptr, autoreset, rng_seed, reset_count, io);
+  if (rc) return rc;
+  if (n <= 0 || n_launch <= 0 || !ms_per_launch) return fail("anm_time_step_launches: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t t0, t1;
+  hipError_t e;
+  if ((e = hipEventCreate(&t0)) != hipSuccess) return fail_hip(e, "hipEventCreate");
+  if ((e = hipEventCreate(&t1)) != hipSuccess) return fail_hip(e, "hipEventCreate");
+  hipEventRecord(t0, s);
+  for (int k = 0; k < n_launch && rc == 0; ++k) rc = launch_step(m, io, n, opts, s);
+  hipEventRecord(t1, s);
+  e = hipEventSynchronize(t1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, t0, t1);
+  hipEventDestroy(t0);
+  hipEventDestroy(t1);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail_hip(e, "event timing");
+  *ms_per_launch = ms / float(n_launch);
+  return 0;
+}
+
+int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t n_obs, const int32_t* index,
+                       const double* scale, const double* low, const double* high, double* obs, void* stream) {
+  if (n <= 0 || n_obs <= 0) return 0;
+  if (!full || !index || !scale || !low || !high || !obs) return fail("anm_gather_obs_f64: null argument");
+  const int64_t total = n * n_obs;
+  unsigned grid = unsigned(std::min<int64_t>((total + 255) / 256, 2048));
+  hipLaunchKernelGGL(k_gather_obs, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), n, full_dim, full,
+                     n_obs, index, scale, low, high, obs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_gather_obs");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,6 @@
+"""Batched (and single-environment) drop-ins for ``gym_anm.envs``."""
+
+from .anm_env import BatchedANMEnv
+from .anm6 import ANM6Vec, ANM6EasyVec, ANM6Easy
+
+ANMEnv = BatchedANMEnv

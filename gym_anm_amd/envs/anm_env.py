@@ -1,0 +1,424 @@
+"""Batched ``ANMEnv``: the Gymnasium surface of the reference over ``num_envs`` environments.
+
+Mirrors ``gym_anm/envs/anm_env.py``: same constructor arguments (plus ``num_envs`` / ``device`` /
+solver options), same hooks for task designers (``init_state``, ``next_vars``,
+``observation_bounds``, ``observation``), same attributes (``K``, ``gamma``, ``lamb``,
+``delta_t``, ``simulator``, ``state_values``, ``state_N``, ``action_space``, ``obs_values``,
+``observation_space``, ``observation_N``, ``terminated``, ``timestep``, ``state``, ``e_loss``,
+``penalty``, ``costs_clipping``, ``pfe_converged``) and the same ``reset`` / ``step`` contracts,
+with a leading ``num_envs`` dimension on every per-environment quantity:
+
+* ``reset(seed=, options=) -> (obs[num_envs, O], {})``
+* ``step(action[num_envs, A]) -> (obs, reward[num_envs], terminated[num_envs], truncated[num_envs], {})``
+
+``step`` is ONE launch of the fused HIP kernel (next_vars lookup in series mode, set-point
+projection, Newton-Raphson power flow, branch flows, reward + clipping, state and observation);
+nothing is copied to the host and nothing synchronises.  Non-convergence of the power flow is not
+an error: it sets ``terminated`` (anm_env.py:421), the environment then stays in the absorbing
+zero state with reward 0 (anm_env.py:365-367) until it is reset -- explicitly through
+``reset(options={"mask": ...})``, or by itself at the next ``step`` when ``autoreset=True``
+(series-mode tasks; Gymnasium's "next step" vector autoreset).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import errors as E
+from ..model import CLASSICAL, RENEWABLE, STORAGE, STATE_VARIABLES
+from ..simulator import BatchedSimulator, _stream_ptr
+from ..spaces import Box, GymEnv
+
+
+def check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, state_bounds):
+    """Argument validation of ``gym_anm/envs/utils.py:7-122`` (same exceptions)."""
+    if K < 0:
+        raise E.ArgsError("The argument K is %d but should be >= 0." % (K))
+    if delta_t <= 0:
+        raise E.ArgsError("The argument delta_t is %.2f but should be > 0." % (delta_t))
+    if lamb < 0:
+        raise E.ArgsError("The argument lamb is %d but should be >= 0." % (lamb))
+    if gamma < 0 or gamma > 1:
+        raise E.ArgsError("The argument gamma is %.4f but should be in [0, 1]." % (gamma))
+    if isinstance(observation, str) and observation == "state":
+        pass
+    elif isinstance(observation, list):
+        for obs in observation:
+            if len(obs) not in (2, 3):
+                raise E.ObsSpaceError("The observation tuple {} should be a list with 2 or 3 elements.".format(obs))
+            key, nodes = obs[0], obs[1]
+            if key not in STATE_VARIABLES:
+                raise E.ObsNotSupportedError(key, STATE_VARIABLES)
+            if isinstance(nodes, str) and nodes == "all":
+                pass
+            elif key == "aux":
+                for n in nodes:
+                    if n >= K:
+                        raise E.ObsSpaceError("Aux variable index {} is out of bound for {} aux variables.".format(n, K))
+            elif isinstance(nodes, list):
+                for n in nodes:
+                    if n not in state_bounds[key]:
+                        raise E.ObsSpaceError(
+                            "Observation {} is not supported for device/branch/bus with ID {}.".format(key, n)
+                        )
+            else:
+                raise E.ObsSpaceError()
+            if len(obs) == 3 and obs[2] not in STATE_VARIABLES[key]:
+                raise E.UnitsNotSupportedError(obs[2], STATE_VARIABLES[key], key)
+    elif callable(observation):
+        pass
+    else:
+        raise E.ArgsError(
+            'The argument observation is of type {} but should be either a list, a callable, or the string "state".'.format(
+                type(observation)
+            )
+        )
+    if aux_bounds is not None and len(aux_bounds) != K:
+        raise E.ArgsError(
+            "The argument aux_bounds has length {} but the environment has K={} auxiliary variables.".format(
+                len(aux_bounds), K
+            )
+        )
+
+
+class BatchedANMEnv(GymEnv):
+    def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
+                 num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
+                 _backend=None):  # fmt: skip
+        GymEnv.reset(self, seed=seed)
+        self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
+        self.aux_bounds = aux_bounds
+        if costs_clipping is None:
+            c1, c2 = np.inf, np.inf
+        else:
+            c1 = np.inf if costs_clipping[0] is None else costs_clipping[0]
+            c2 = np.inf if costs_clipping[1] is None else costs_clipping[1]
+        self.costs_clipping = (c1, c2)
+        self.num_envs = int(num_envs)
+        self.autoreset = bool(autoreset)
+
+        self.simulator = BatchedSimulator(network, delta_t, lamb, num_envs=num_envs, device=device, tol=tol,
+                                          max_iter=max_iter, precision=precision, _backend=_backend)  # fmt: skip
+        sim = self.simulator
+        self.device = sim.device
+        check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, sim.state_bounds)
+
+        self.state_values = self._expand_all_ids(
+            [("dev_p", "all", "MW"), ("dev_q", "all", "MVAr"), ("des_soc", "all", "MWh"), ("gen_p_max", "all", "MW"),
+             ("aux", "all", None)]
+        )  # fmt: skip
+        self.state_N = sum(len(s[1]) for s in self.state_values)
+        lo, hi = sim.model.action_bounds()
+        self.action_space = Box(low=lo, high=hi, dtype=np.float64)
+        self.single_action_space = self.action_space
+
+        self.obs_values = self._build_observation_space(observation)
+        self.observation_space = self.observation_bounds()
+        if self.observation_space is not None:
+            self.observation_N = self.observation_space.shape[0]
+        self.single_observation_space = self.observation_space
+
+        # ---- device-resident per-environment state ------------------------------------------------
+        E_, S = self.num_envs, self.state_N
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.state = torch.zeros((E_, S), **f64)
+        self._state_obs = torch.zeros((E_, S), **f64)  # clip(state, state-space bounds), written by the kernel
+        self.reward = torch.zeros(E_, **f64)
+        self.e_loss = torch.zeros(E_, **f64)
+        self.penalty = torch.zeros(E_, **f64)
+        self._term_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
+        self._term_bool = self._term_u8.view(torch.bool)  # zero-copy: the kernel only writes 0 / 1
+        self.timestep = torch.zeros(E_, dtype=torch.int32, device=self.device)
+        self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
+        self._reset_count = torch.zeros(E_, dtype=torch.int32, device=self.device)
+        self._truncated = torch.zeros(E_, dtype=torch.bool, device=self.device)
+        self.rng_seed = 0 if seed is None else int(seed)
+        self._act_low = torch.as_tensor(lo, **f64)
+        self._act_high = torch.as_tensor(hi, **f64)
+        self.check_actions = True
+
+        # ---- environment constants for the kernels ---------------------------------------------------
+        self._series = None if series is None else np.ascontiguousarray(series, dtype=np.float64)
+        slo, shi = self._state_bounds_vectors()
+        self._obs_is_state = self.obs_values is not None and self.obs_values == self.state_values
+        if self._obs_is_state and self.observation_space is not None:
+            slo, shi = np.asarray(self.observation_space.low, float), np.asarray(self.observation_space.high, float)
+        cfg = _lib.EnvConfig(
+            K=K, gamma=float(gamma), clip_e_loss=float(c1), clip_penalty=float(c2),
+            obs_low=_lib.as_c(slo, np.float64)[1], obs_high=_lib.as_c(shi, np.float64)[1],
+            series=None if self._series is None else self._series.ctypes.data_as(_lib.c_double_p),
+            period=0 if self._series is None else int(self._series.shape[1]),
+        )  # fmt: skip
+        self._cfg_keep = (slo, shi)
+        with sim._device_ctx():
+            sim.backend.check(sim.backend.lib.anm_model_set_env(sim._handle, C.byref(cfg)), "anm_model_set_env")
+        self._gather = None  # (index, scale, low, high) device tensors for list-form observations
+        if self.obs_values is not None and not self._obs_is_state:
+            self._gather = self._build_gather(self.obs_values)
+        self._need_full = self._gather is not None or self.obs_values is None
+        self._obs_buf = None
+
+    # ---- hooks for task designers (anm_env.py:158-191) -----------------------------------------------
+    def init_state(self):
+        """Sample initial states: return a ``[num_envs, state_N]`` array/tensor (reference layout)."""
+        raise NotImplementedError
+
+    def next_vars(self, s_t):
+        """Return ``[num_envs, N_load + N_gen + K]``: load injections (MW), generator potentials (MW)
+        and the next auxiliary variables, given the state batch ``s_t``.  Not used in series mode."""
+        raise NotImplementedError
+
+    def observation_bounds(self):  # anm_env.py:193-233
+        if self.obs_values is None:
+            return None
+        lower, upper = [], []
+        bounds = self.simulator.state_bounds
+        for key, nodes, unit in self.obs_values:
+            for n in nodes:
+                if key == "aux":
+                    if self.aux_bounds is not None:
+                        lower.append(self.aux_bounds[n][0])
+                        upper.append(self.aux_bounds[n][1])
+                    else:
+                        lower.append(-np.inf)
+                        upper.append(np.inf)
+                else:
+                    lower.append(bounds[key][n][unit][0])
+                    upper.append(bounds[key][n][unit][1])
+        return Box(low=np.array(lower), high=np.array(upper), dtype=np.float64)
+
+    # ---- spaces helpers (anm_env.py:497-549) ------------------------------------------------------------
+    def _build_observation_space(self, observation):
+        if isinstance(observation, str) and observation == "state":
+            obs_values = deepcopy(self.state_values)
+        elif isinstance(observation, list):
+            obs_values = deepcopy(observation)
+            for idx, o in enumerate(obs_values):
+                if len(o) == 2:
+                    obs_values[idx] = tuple(list(o) + [STATE_VARIABLES[o[0]][0]])
+        elif callable(observation):
+            obs_values = None
+            self.observation = observation
+        else:
+            raise E.ObsSpaceError()
+        return self._expand_all_ids(obs_values)
+
+    def _expand_all_ids(self, values):
+        m = self.simulator.model
+        if values is None:
+            return None
+        for idx, o in enumerate(values):
+            if isinstance(o[1], str) and o[1] == "all":
+                if "bus" in o[0]:
+                    ids = list(m.bus_ids)
+                elif "dev" in o[0]:
+                    ids = list(m.dev_ids)
+                elif "des" in o[0]:
+                    ids = [m.dev_ids[k] for k in m.des_idx]
+                elif "gen" in o[0]:
+                    ids = [m.dev_ids[k] for k in m.gen_idx]
+                elif "branch" in o[0]:
+                    ids = list(m.branch_ids)
+                elif o[0] == "aux":
+                    ids = list(range(0, self.K))
+                else:
+                    raise E.ObsNotSupportedError(o[0], STATE_VARIABLES.keys())
+                values[idx] = (o[0], ids, o[2])
+        return values
+
+    def _state_bounds_vectors(self):
+        """Box bounds of the *state* vector, used when the observation is the state."""
+        lo, hi = [], []
+        bounds = self.simulator.state_bounds
+        for key, nodes, unit in self.state_values:
+            for n in nodes:
+                if key == "aux":
+                    if self.aux_bounds is not None:
+                        lo.append(self.aux_bounds[n][0])
+                        hi.append(self.aux_bounds[n][1])
+                    else:
+                        lo.append(-np.inf)
+                        hi.append(np.inf)
+                else:
+                    lo.append(bounds[key][n][unit][0])
+                    hi.append(bounds[key][n][unit][1])
+        return np.array(lo, dtype=np.float64), np.array(hi, dtype=np.float64)
+
+    def _build_gather(self, values):
+        """Index/scale/clip vectors that turn the kernel's full-state dump (+ aux) into the
+        list-form observation (anm_env.py:562-592 with the units of simulator.py:559-616)."""
+        sim, m = self.simulator, self.simulator.model
+        index, scale = [], []
+        for key, nodes, unit in values:
+            for n in nodes:
+                if key == "aux":
+                    index.append(sim.full_dim + n)  # aux columns are appended to the dump
+                    scale.append(1.0)
+                    continue
+                if key.startswith("bus"):
+                    j = m.bus_ids.index(n)
+                elif key.startswith("dev"):
+                    j = m.dev_ids.index(n)
+                elif key == "des_soc":
+                    j = [m.dev_ids[k] for k in m.des_idx].index(n)
+                elif key == "gen_p_max":
+                    j = [m.dev_ids[k] for k in m.gen_idx].index(n)
+                else:
+                    j = m.branch_ids.index(tuple(n))
+                index.append(sim.full_offsets[key] + j)
+                kv_j = j
+                if key.startswith("branch"):  # kA for branches is not defined by the reference (pu only)
+                    kv_j = 0
+                scale.append(sim.unit_scale(key, unit, kv_j))
+        space = self.observation_space
+        dev = self.device
+        return (
+            torch.as_tensor(index, dtype=torch.int32, device=dev),
+            torch.as_tensor(scale, dtype=torch.float64, device=dev),
+            torch.as_tensor(np.asarray(space.low, float), dtype=torch.float64, device=dev),
+            torch.as_tensor(np.asarray(space.high, float), dtype=torch.float64, device=dev),
+        )
+
+    # ---- observation ---------------------------------------------------------------------------------------
+    def observation(self, s_t):
+        """``o_t = observation(s_t)``: clip(state variables, Box) (anm_env.py:313-331), batched."""
+        if self._obs_is_state:
+            return self._state_obs
+        sim = self.simulator
+        index, scale, low, high = self._gather
+        n_obs = index.numel()
+        if self._obs_buf is None:
+            self._obs_buf = torch.zeros((self.num_envs, n_obs), dtype=torch.float64, device=self.device)
+        full = sim.full
+        if self.K > 0:
+            full = torch.cat([sim.full, self.state[:, self.state_N - self.K :]], dim=1).contiguous()
+        with sim._device_ctx():
+            rc = sim.backend.lib.anm_gather_obs_f64(
+                self.num_envs, full.shape[1], full.data_ptr(), n_obs, index.data_ptr(), scale.data_ptr(),
+                low.data_ptr(), high.data_ptr(), self._obs_buf.data_ptr(), _stream_ptr(self.device),
+            )  # fmt: skip
+        sim.backend.check(rc, "anm_gather_obs_f64")
+        return self._obs_buf
+
+    @property
+    def terminated(self):
+        return self._term_bool
+
+    @property
+    def pfe_converged(self):
+        return self._conv_u8.bool()
+
+    # ---- reset (anm_env.py:235-311) --------------------------------------------------------------------------
+    def _launch_reset(self, init_state, mask_u8):
+        sim = self.simulator
+        with sim._device_ctx():
+            rc = sim.backend.lib.anm_reset_f64(
+                sim._handle, self.num_envs, init_state.data_ptr(), None if mask_u8 is None else mask_u8.data_ptr(),
+                sim.soc.data_ptr(), self.state.data_ptr(), self._state_obs.data_ptr(), self._conv_u8.data_ptr(),
+                self._term_u8.data_ptr(), self.timestep.data_ptr(), sim.nr_iters.data_ptr(),
+                sim.full.data_ptr() if self._need_full else None, C.byref(sim.opts), _stream_ptr(self.device),
+            )  # fmt: skip
+        sim.backend.check(rc, "anm_reset_f64")
+
+    def reset(self, *, seed=None, options=None):
+        """Reset every environment (or those selected by ``options["mask"]``).
+
+        ``options["init_state"]`` (``[num_envs, state_N]``) bypasses ``init_state()``; otherwise
+        initial states are drawn with ``init_state()`` and redrawn (up to 100 times, like the
+        reference) for the environments whose first power flow does not converge.
+        """
+        GymEnv.reset(self, seed=seed)
+        if seed is not None:
+            self.rng_seed = int(seed)
+        options = options or {}
+        mask = options.get("mask")
+        mask_u8 = None
+        if mask is not None:
+            mask_u8 = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        given = options.get("init_state")
+        todo = mask_u8.clone() if mask_u8 is not None else torch.ones(self.num_envs, dtype=torch.uint8,
+                                                                     device=self.device)  # fmt: skip
+        n_max = 100
+        for attempt in range(1, n_max + 1):
+            s0 = given if given is not None else self.init_state()
+            s0 = torch.as_tensor(s0, dtype=torch.float64, device=self.device)
+            if s0.dim() == 1:
+                s0 = s0.unsqueeze(0).expand(self.num_envs, -1)
+            if s0.shape[1] != self.state_N:
+                raise E.EnvInitializationError(
+                    "Expected size of initial state s0 is %d but actual is %d" % (self.state_N, s0.shape[1])
+                )
+            self._launch_reset(s0.contiguous(), todo)
+            todo = todo * (1 - self._conv_u8)
+            if given is not None or not bool(todo.any()):
+                break
+            if attempt == n_max:
+                raise E.EnvInitializationError(
+                    "No non-terminal state found out of %d initial states for environment %s"
+                    % (n_max, type(self).__name__)
+                )
+        if given is not None:
+            # an explicit initial state that does not converge leaves that environment terminated
+            sel = todo.bool()
+            self._term_u8[sel] = 1
+        touched = mask_u8.bool() if mask_u8 is not None else slice(None)
+        self.e_loss[touched] = 0.0
+        self.penalty[touched] = 0.0
+        obs = self.observation(self.state)
+        if self.observation_space is None:
+            n = obs.shape[1]
+            self.observation_space = Box(low=-np.ones(n) * np.inf, high=np.ones(n) * np.inf)
+            self.observation_N = n
+        return obs, {}
+
+    # ---- step (anm_env.py:333-453) -----------------------------------------------------------------------------
+    def step(self, action):
+        sim = self.simulator
+        action = torch.as_tensor(action, dtype=torch.float64, device=self.device)
+        if action.dim() == 1:
+            action = action.unsqueeze(0)
+        if action.shape != (self.num_envs, sim.dims.action_dim):
+            raise AssertionError("Action %r (%s) invalid." % (tuple(action.shape), type(action)))
+        if self.check_actions:  # anm_env.py:356-357 (one device reduction + sync; disable for throughput runs)
+            ok = bool(((action >= self._act_low) & (action <= self._act_high)).all())
+            assert ok, "Action %r (%s) invalid." % (action, type(action))
+        action = action.contiguous()
+        exo_ptr = aux_ptr = None
+        if self._series is None:
+            v = torch.as_tensor(self.next_vars(self.state), dtype=torch.float64, device=self.device)
+            expected = sim.N_load + sim.N_non_slack_gen + self.K
+            if v.dim() != 2 or v.shape[1] != expected:
+                raise E.EnvNextVarsError(
+                    "Next vars vector has size %d but expected is %d" % (v.shape[-1] if v.dim() else 0, expected)
+                )
+            n_exo = sim.N_load + sim.N_non_slack_gen
+            exo = v[:, :n_exo].contiguous()
+            aux = v[:, n_exo:].contiguous()
+            exo_ptr, aux_ptr = exo.data_ptr(), (aux.data_ptr() if self.K > 0 else None)
+        with sim._device_ctx():
+            rc = sim.backend.lib.anm_step_f64(
+                sim._handle, self.num_envs, action.data_ptr(), exo_ptr, aux_ptr, sim.soc.data_ptr(),
+                self.state.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(), self._state_obs.data_ptr(),
+                self.reward.data_ptr(), self.e_loss.data_ptr(), self.penalty.data_ptr(), sim.nr_iters.data_ptr(),
+                sim.full.data_ptr() if self._need_full else None, 1 if self.autoreset else 0, self.rng_seed,
+                self._reset_count.data_ptr(), C.byref(sim.opts), _stream_ptr(self.device),
+            )  # fmt: skip
+        sim.backend.check(rc, "anm_step_f64")
+        if self._obs_is_state:
+            obs = self._state_obs
+        else:
+            obs = self.observation(self.state)
+            if self._gather is not None:
+                obs = torch.where(self._term_bool.unsqueeze(1), torch.zeros_like(obs), obs)
+        return obs, self.reward, self._term_bool, self._truncated, {}
+
+    def render(self, mode="human"):
+        raise NotImplementedError()
+
+    def close(self):
+        pass

@@ -1,0 +1,153 @@
+// hostsim.cpp -- TEST DOUBLE, not a product path.
+//
+// Compiles the very same per-environment templates the gfx950 kernels instantiate
+// (gym_anm_amd/csrc/anm_env_ops.hpp) with g++ and exposes them behind the same C ABI
+// (include/anm_mi355x.h) on HOST pointers, one environment after the other.  The CPU-only test
+// tier (-m "not gpu") uses it to check the kernel logic, the constant packing and the Python host
+// layer against the oracle without a GPU.  The product package never loads this library: its
+// loader (gym_anm_amd/_lib.py) only accepts the hipcc-built libanm_<topology>.so and raises when
+// that is missing.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include ANM_TOPO_HEADER
+#include "../../gym_anm_amd/csrc/anm_env_ops.hpp"
+#include "../../gym_anm_amd/csrc/anm_pack.hpp"
+
+using namespace anm;
+
+static thread_local std::string g_err;
+static int fail(const std::string& s) { g_err = s; return -1; }
+
+struct anm_model {
+  std::vector<double> c;
+  std::vector<cplx> ybus;
+  std::vector<double> series;
+  int period = 0, K = 0;
+  bool env_set = false;
+};
+
+static SolverOpts solver(const anm_solver_opts* o, int& prec) {
+  SolverOpts s{1e-5, 100};
+  prec = ANM_SOLVE_F64;
+  if (o) { s.tol = o->tol; s.max_iter = o->max_iter; prec = o->precision; }
+  return s;
+}
+
+extern "C" {
+const char* anm_last_error(void) { return g_err.c_str(); }
+const char* anm_topology_name(void) { return Topo::NAME; }
+const char* anm_topology_signature(void) { return Topo::SIGNATURE; }
+int anm_device_count(void) { return 0; }
+
+int anm_model_create(const anm_network_desc* d, anm_model** out) {
+  anm_model* m = new anm_model();
+  std::string err;
+  if (!pack_constants<Topo>(*d, m->c, m->ybus, err)) { delete m; g_err = err; return -3; }
+  *out = m;
+  return 0;
+}
+void anm_model_destroy(anm_model* m) { delete m; }
+int anm_model_dims(const anm_model*, anm_dims* o) {
+  o->n_bus = Topo::NB; o->n_dev = Topo::ND; o->n_branch = Topo::NBR; o->n_load = Topo::NLOAD;
+  o->n_gen = Topo::NGEN; o->n_des = Topo::NDES; o->action_dim = Dims<Topo>::ADIM;
+  o->state_base_dim = Topo::SDIM; o->full_dim = FullState<Topo>::SIZE; o->const_doubles = Layout<Topo>::TOTAL;
+  return 0;
+}
+int anm_model_full_layout(const anm_model*, anm_full_layout* o) {
+  typedef FullState<Topo> F;
+  o->bus_p = F::BUS_P; o->bus_q = F::BUS_Q; o->bus_v_magn = F::BUS_VM; o->bus_v_ang = F::BUS_VA;
+  o->bus_i_magn = F::BUS_IM; o->bus_i_ang = F::BUS_IA; o->dev_p = F::DEV_P; o->dev_q = F::DEV_Q;
+  o->des_soc = F::DES_SOC; o->gen_p_max = F::GEN_PMAX; o->branch_p = F::BR_P; o->branch_q = F::BR_Q;
+  o->branch_s = F::BR_S; o->branch_i_magn = F::BR_IM; o->branch_i_ang = F::BR_IA; o->size = F::SIZE;
+  return 0;
+}
+int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
+  std::string err;
+  if (!pack_env<Topo>(*cfg, m->c, err)) { g_err = err; return -3; }
+  m->K = cfg->K;
+  m->series.clear();
+  m->period = 0;
+  if (cfg->series && cfg->period > 0) {
+    if (cfg->K != 1) return fail("series mode needs exactly K = 1 auxiliary variable (the time index)");
+    m->series.assign(cfg->series, cfg->series + size_t(Dims<Topo>::NEXO) * cfg->period);
+    m->period = cfg->period;
+  }
+  m->env_set = true;
+  return 0;
+}
+int anm_model_get_ybus(const anm_model* m, double* y) {
+  for (size_t k = 0; k < m->ybus.size(); ++k) { y[2 * k] = m->ybus[k].real(); y[2 * k + 1] = m->ybus[k].imag(); }
+  return 0;
+}
+
+int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const double* p_pot, const double* p_set,
+                       const double* q_set, double* soc, double* full, double* reward, double* e_loss,
+                       double* penalty, uint8_t* converged, int32_t* nr_iters, const anm_solver_opts* opts, void*) {
+  TransitionIO io{p_load, p_pot, p_set, q_set, soc, full, reward, e_loss, penalty, converged, nr_iters};
+  int prec;
+  SolverOpts so = solver(opts, prec);
+  for (int64_t e = 0; e < n; ++e) {
+    if (prec == ANM_SOLVE_F32) op_transition<Topo, float>(m->c.data(), io, so, e);
+    else op_transition<Topo, double>(m->c.data(), io, so, e);
+  }
+  return 0;
+}
+
+int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, double* soc, double* state,
+                  double* obs, uint8_t* converged, uint8_t* terminated, int32_t* timestep, int32_t* nr_iters,
+                  double* full, const anm_solver_opts* opts, void*) {
+  if (!m->env_set) return fail("anm_reset_f64: call anm_model_set_env first");
+  EnvIO io{};
+  io.K = m->K; io.init_state = init_state; io.mask = mask; io.soc = soc; io.state = state; io.obs = obs;
+  io.converged = converged; io.terminated = terminated; io.timestep = timestep; io.nr_iters = nr_iters; io.full = full;
+  int prec;
+  SolverOpts so = solver(opts, prec);
+  for (int64_t e = 0; e < n; ++e) {
+    if (prec == ANM_SOLVE_F32) op_reset<Topo, float>(m->c.data(), io, so, e);
+    else op_reset<Topo, double>(m->c.data(), io, so, e);
+  }
+  return 0;
+}
+
+int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
+                 double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
+                 double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
+                 uint64_t rng_seed, int32_t* reset_count, const anm_solver_opts* opts, void*) {
+  if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
+  const bool series = exo == nullptr;
+  if (series && m->period <= 0) return fail("anm_step_f64: no exo given and the model has no series (set_env)");
+  if (!series && m->K > 0 && !aux_next) return fail("anm_step_f64: exo given without aux_next");
+  if (autoreset && (!series || !reset_count)) return fail("anm_step_f64: autoreset needs series mode and reset_count");
+  EnvIO io{};
+  io.K = m->K; io.action = action; io.exo = exo; io.aux_next = aux_next; io.series = m->series.data();
+  io.period = m->period; io.soc = soc; io.state = state; io.terminated = terminated; io.timestep = timestep;
+  io.obs = obs; io.reward = reward; io.e_loss = e_loss; io.penalty = penalty; io.nr_iters = nr_iters; io.full = full;
+  io.autoreset = autoreset; io.rng_seed = rng_seed; io.reset_count = reset_count;
+  int prec;
+  SolverOpts so = solver(opts, prec);
+  for (int64_t e = 0; e < n; ++e) {
+    if (prec == ANM_SOLVE_F32) op_step<Topo, float>(m->c.data(), io, so, e);
+    else op_step<Topo, double>(m->c.data(), io, so, e);
+  }
+  return 0;
+}
+
+int anm_time_step_launches(anm_model*, int64_t, const double*, double*, double*, uint8_t*, int32_t*, double*,
+                           double*, double*, double*, int32_t, uint64_t, int32_t*, const anm_solver_opts*, void*,
+                           int32_t, float*) {
+  return fail("hostsim: no device timing");
+}
+
+int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t n_obs, const int32_t* index,
+                       const double* scale, const double* low, const double* high, double* obs, void*) {
+  for (int64_t e = 0; e < n; ++e)
+    for (int k = 0; k < n_obs; ++k) {
+      const double v = full[e * full_dim + index[k]] * scale[k];
+      obs[e * n_obs + k] = std::fmin(std::fmax(v, low[k]), high[k]);
+    }
+  return 0;
+}
+}

@@ -1,0 +1,61 @@
+"""CPU tier: the hipcc-built libraries load, export every symbol include/anm_mi355x.h declares,
+and the product refuses to run without a GPU (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from gym_anm_amd import _lib, codegen, errors, networks
+from gym_anm_amd.model import NetworkModel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "anm_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(anm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_lib.ABI)
+
+
+@pytest.mark.parametrize("name", ["anm6", "case30", "2bus", "3bus"])
+def test_library_exports_every_symbol(name):
+    topo = codegen.stock_topologies()[name]
+    path = codegen.build_library(topo)  # no-op when already built
+    lib = ctypes.CDLL(path)
+    for sym in _declared_symbols():
+        assert hasattr(lib, sym), "%s lacks %s" % (path, sym)
+    _lib.bind(lib)
+    assert lib.anm_topology_signature().decode() == codegen.topology_signature(topo)
+    assert lib.anm_topology_name().decode() == codegen.topology_name(topo)
+
+
+def test_no_cpu_fallback():
+    """Without a visible MI355X the product raises instead of computing anything on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    from gym_anm_amd.envs import ANM6EasyVec
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    with pytest.raises(errors.HipExtensionError):
+        BatchedSimulator(networks.anm6_network(), 0.25, 100, num_envs=4)
+    with pytest.raises(errors.HipExtensionError):
+        ANM6EasyVec(num_envs=4, device="cpu")
+
+
+def test_wrong_topology_is_rejected():
+    """A library only accepts networks with the structure it was compiled for."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hostsim_backend import hostsim_backend
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    be = hostsim_backend(NetworkModel(networks.two_bus_network(), 0.25, 100).topology())
+    with pytest.raises(errors.HipExtensionError, match="built for"):
+        BatchedSimulator(networks.anm6_network(), 0.25, 100, num_envs=1, device="cpu", _backend=be)
