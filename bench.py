@@ -176,6 +176,24 @@ def main():
     sim.backend.check(rc, "anm_time_step_launches")
     kernel_s = ms.value * 1e-3
 
+    # secondary figure: same workload with a 20-iteration cap.  Diverging solves (the only ones that
+    # ever exceed ~8 iterations) are then cut off early; on every sample tested the terminated flags
+    # are identical to the reference's cap of 100, but that is an observation, not a proof, so the
+    # headline `value` above keeps the reference's cap.
+    alt = None
+    if rank == 0 and args.max_iter == 100:
+        sim.opts.max_iter = 20
+        for i in range(10):
+            env.step(pool[i % n_pool])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            env.step(pool[i % n_pool])
+        torch.cuda.synchronize(dev)
+        alt_elapsed = time.perf_counter() - t1
+        alt = {"nr_max_iter": 20, "value_1gpu": E * args.steps / alt_elapsed, "ms_per_step": 1e3 * alt_elapsed / args.steps}
+        sim.opts.max_iter = args.max_iter
+
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(6, 18, 1, 1)
         achieved = bytes_per * E / kernel_s / 1e9
@@ -208,6 +226,8 @@ def main():
                 "note": "fp64-ALU/latency-bound (Newton-Raphson in registers), not HBM-bound: see DESIGN.md",
             },
         }  # fmt: skip
+        if alt is not None:
+            out["config"]["alt_iteration_cap"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(out), flush=True)

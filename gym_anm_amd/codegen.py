@@ -195,8 +195,11 @@ def hipcc_path():
     return None
 
 
+# -fno-slp-vectorize: with SLP on, hipcc 7.2 packs the fp32 Jacobian arithmetic of the 30-bus kernel
+# (512 registers + scratch) into v_pk_* pairs and produces wrong numbers (caught by
+# tests/test_gpu_parity.py::test_transition_golden_f32_solve[case30]); scalar f32/f64 VALU code is correct.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ftemplate-depth=4096",
-               "-fno-gpu-rdc", "-Wno-unused-value"]  # fmt: skip
+               "-fno-gpu-rdc", "-Wno-unused-value", "-fno-slp-vectorize"]  # fmt: skip
 
 
 def _sources_mtime():

@@ -162,6 +162,9 @@ class BatchedANMEnv(GymEnv):
             self._gather = self._build_gather(self.obs_values)
         self._need_full = self._gather is not None or self.obs_values is None
         self._obs_buf = None
+        self._step_args = None
+        self._reset_count_ptr = self._reset_count.data_ptr()
+        self._opts_ref = C.byref(sim.opts)
 
     # ---- hooks for task designers (anm_env.py:158-191) -----------------------------------------------
     def init_state(self):
@@ -377,9 +380,37 @@ class BatchedANMEnv(GymEnv):
         return obs, {}
 
     # ---- step (anm_env.py:333-453) -----------------------------------------------------------------------------
+    def _step_call(self, action_ptr, exo_ptr, aux_ptr):
+        """One anm_step_f64 launch on torch's current stream (all buffer pointers are persistent)."""
+        sim = self.simulator
+        dev = self.device
+        if dev.type == "cuda":
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            switch = torch.cuda.current_device() != dev.index
+        else:
+            stream, switch = None, False
+        args = self._step_args
+        if args is None:
+            args = self._step_args = (
+                sim.soc.data_ptr(), self.state.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(),
+                self._state_obs.data_ptr(), self.reward.data_ptr(), self.e_loss.data_ptr(), self.penalty.data_ptr(),
+                sim.nr_iters.data_ptr(), sim.full.data_ptr() if self._need_full else None,
+            )  # fmt: skip
+        fn = sim.backend.lib.anm_step_f64
+        if switch:
+            with torch.cuda.device(dev):
+                rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
+                        self.rng_seed, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
+        else:
+            rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
+                    self.rng_seed, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
+        if rc != 0:
+            sim.backend.check(rc, "anm_step_f64")
+
     def step(self, action):
         sim = self.simulator
-        action = torch.as_tensor(action, dtype=torch.float64, device=self.device)
+        if not (isinstance(action, torch.Tensor) and action.dtype == torch.float64 and action.device == self.device):
+            action = torch.as_tensor(action, dtype=torch.float64, device=self.device)
         if action.dim() == 1:
             action = action.unsqueeze(0)
         if action.shape != (self.num_envs, sim.dims.action_dim):
@@ -387,7 +418,8 @@ class BatchedANMEnv(GymEnv):
         if self.check_actions:  # anm_env.py:356-357 (one device reduction + sync; disable for throughput runs)
             ok = bool(((action >= self._act_low) & (action <= self._act_high)).all())
             assert ok, "Action %r (%s) invalid." % (action, type(action))
-        action = action.contiguous()
+        if not action.is_contiguous():
+            action = action.contiguous()
         exo_ptr = aux_ptr = None
         if self._series is None:
             v = torch.as_tensor(self.next_vars(self.state), dtype=torch.float64, device=self.device)
@@ -400,15 +432,7 @@ class BatchedANMEnv(GymEnv):
             exo = v[:, :n_exo].contiguous()
             aux = v[:, n_exo:].contiguous()
             exo_ptr, aux_ptr = exo.data_ptr(), (aux.data_ptr() if self.K > 0 else None)
-        with sim._device_ctx():
-            rc = sim.backend.lib.anm_step_f64(
-                sim._handle, self.num_envs, action.data_ptr(), exo_ptr, aux_ptr, sim.soc.data_ptr(),
-                self.state.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(), self._state_obs.data_ptr(),
-                self.reward.data_ptr(), self.e_loss.data_ptr(), self.penalty.data_ptr(), sim.nr_iters.data_ptr(),
-                sim.full.data_ptr() if self._need_full else None, 1 if self.autoreset else 0, self.rng_seed,
-                self._reset_count.data_ptr(), C.byref(sim.opts), _stream_ptr(self.device),
-            )  # fmt: skip
-        sim.backend.check(rc, "anm_step_f64")
+        self._step_call(action.data_ptr(), exo_ptr, aux_ptr)
         if self._obs_is_state:
             obs = self._state_obs
         else:
