@@ -119,8 +119,8 @@ def main():
     from gym_anm_amd.envs import ANM6EasyVec
 
     E = args.num_envs
-    env = ANM6EasyVec(num_envs=E, device=dev, seed=1234 + rank, tol=args.tol, max_iter=args.max_iter,
-                      precision=args.precision, autoreset=True)  # fmt: skip
+    env = ANM6EasyVec(num_envs=E, device=dev, seed=1234, tol=args.tol, max_iter=args.max_iter,
+                      precision=args.precision, autoreset=True, env_offset=rank * E)  # fmt: skip
     env.check_actions = False  # the Box check is a device reduction + host sync; actions are in the Box by construction
     env.reset(seed=1234 + rank)
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -170,7 +170,7 @@ def main():
         rc = sim.backend.lib.anm_time_step_launches(
             sim._handle, E, pool[0].data_ptr(), sim.soc.data_ptr(), env.state.data_ptr(), env._term_u8.data_ptr(),
             env.timestep.data_ptr(), env._state_obs.data_ptr(), env.reward.data_ptr(), env.e_loss.data_ptr(),
-            env.penalty.data_ptr(), 1, env.rng_seed, env._reset_count.data_ptr(), C.byref(sim.opts), stream,
+            env.penalty.data_ptr(), 1, env.rng_seed, env.env_offset, env._reset_count.data_ptr(), C.byref(sim.opts), stream,
             n_launch, C.byref(ms),
         )  # fmt: skip
     sim.backend.check(rc, "anm_time_step_launches")
@@ -197,6 +197,16 @@ def main():
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(6, 18, 1, 1)
         achieved = bytes_per * E / kernel_s / 1e9
+        # HBM bytes per launch from the PMC passes (scripts/pmc_run.sh -> profiles/pmc_traffic.json):
+        # bench.py cannot collect counters itself, so the committed figure is attached when it was
+        # measured on this very configuration, else null.
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt["num_envs"] == E and pt["nr_max_iter"] == args.max_iter and pt["precision"] == args.precision:
+                traffic = pt["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec (whole node) at num_envs=65536, ANM6Easy; NR iters to 1e-6",
             "value": total_steps / elapsed,
@@ -219,7 +229,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": "k_step<double>" if args.precision == "f64" else "k_step<float>",
                 "kernel_ms": ms.value, "launches_timed": n_launch,
                 "algorithmic_bytes_per_env_step": bytes_per,

@@ -180,8 +180,15 @@ def emit_header(topo, name=None) -> str:
 # --------------------------------------------------------------------------------------------
 # building
 # --------------------------------------------------------------------------------------------
+def _tag() -> str:
+    """Kernel-tuning experiments: ANM_BUILD_TAG=<tag> ANM_EXTRA_HIPCC_FLAGS="..." build and load
+    side-by-side variants (libanm_<topology>.<tag>.so) without touching the default library."""
+    t = os.environ.get("ANM_BUILD_TAG", "")
+    return "." + t if t else ""
+
+
 def lib_path(name: str) -> str:
-    return os.path.join(BUILD_DIR, "libanm_%s.so" % name)
+    return os.path.join(BUILD_DIR, "libanm_%s%s.so" % (name, _tag()))
 
 
 def header_path(name: str) -> str:
@@ -226,6 +233,7 @@ def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):
             "no prebuilt gfx950 library for topology '%s' (%s) and hipcc was not found to build it"
             % (name, topology_signature(topo))
         )
+    extra_flags = list(extra_flags) + os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
     cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + [
         '-DANM_TOPO_HEADER="%s"' % hdr,
         "-I", os.path.join(os.path.dirname(PKG_DIR), "include"),

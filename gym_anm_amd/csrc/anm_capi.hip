@@ -264,7 +264,7 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
 static int make_step_io(anm_model* m, const double* action, const double* exo, const double* aux_next, double* soc,
                         double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                         double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                        uint64_t rng_seed, int32_t* reset_count, EnvIO& io) {
+                        uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, EnvIO& io) {
   if (!m) return fail("anm_step_f64: null model");
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
   if (!action || !state || !terminated || !obs || !reward || !e_loss || !penalty)
@@ -293,6 +293,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   io.full = full;
   io.autoreset = autoreset;
   io.rng_seed = rng_seed;
+  io.env_offset = env_offset;
   io.reset_count = reset_count;
   return 0;
 }
@@ -313,10 +314,10 @@ static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solve
 int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
                  double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                  double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                 uint64_t rng_seed, int32_t* reset_count, const anm_solver_opts* opts, void* stream) {
+                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, const anm_solver_opts* opts, void* stream) {
   EnvIO io;
   int rc = make_step_io(m, action, exo, aux_next, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
-                        nr_iters, full, autoreset, rng_seed, reset_count, io);
+                        nr_iters, full, autoreset, rng_seed, env_offset, reset_count, io);
   if (rc) return rc;
   if (n <= 0) return 0;
   return launch_step(m, io, n, opts, static_cast<hipStream_t>(stream));
@@ -324,11 +325,11 @@ int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* ex
 
 int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double* soc, double* state,
                            uint8_t* terminated, int32_t* timestep, double* obs, double* reward, double* e_loss,
-                           double* penalty, int32_t autoreset, uint64_t rng_seed, int32_t* reset_count,
+                           double* penalty, int32_t autoreset, uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count,
                            const anm_solver_opts* opts, void* stream, int32_t n_launch, float* ms_per_launch) {
   EnvIO io;
   int rc = make_step_io(m, action, nullptr, nullptr, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
-                        nullptr, nullptr, autoreset, rng_seed, reset_count, io);
+                        nullptr, nullptr, autoreset, rng_seed, env_offset, reset_count, io);
   if (rc) return rc;
   if (n <= 0 || n_launch <= 0 || !ms_per_launch) return fail("anm_time_step_launches: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -362,5 +363,16 @@ int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t 
   if (e != hipSuccess) return fail_hip(e, "launch k_gather_obs");
   return 0;
 }
+
+#ifdef ANM_PHASE_TIMING
+// tuning builds only: copy the per-wave phase timestamps of the last launches to the host
+__attribute__((visibility("default"))) int anm_debug_phase_times(unsigned long long* out, int n_waves) {
+  std::vector<unsigned long long> tmp(size_t(ANM_N_PHASES) * ANM_MAX_WAVES);
+  if (hipMemcpyFromSymbol(tmp.data(), HIP_SYMBOL(g_anm_phase), tmp.size() * 8) != hipSuccess) return -1;
+  for (int k = 0; k < ANM_N_PHASES; ++k)
+    for (int w = 0; w < n_waves && w < ANM_MAX_WAVES; ++w) out[k * n_waves + w] = tmp[size_t(k) * ANM_MAX_WAVES + w];
+  return 0;
+}
+#endif
 
 }  // extern "C"

@@ -99,6 +99,7 @@ struct EnvIO {
   double* full;             // [E, FS] or null
   int autoreset;
   uint64_t rng_seed;
+  uint64_t env_offset;      // global index of environment 0 of this batch (RNG key)
   int32_t* reset_count;     // [E] (autoreset)
 };
 
@@ -175,6 +176,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   const bool was_term = io.terminated[e] != 0;
   const bool series = io.exo == nullptr;
   const bool resetting = was_term && io.autoreset && series;
+  ANM_PHASE(0);
 
   if (was_term && !resetting) {  // absorbing terminal state (anm_env.py:365-367)
     for (int k = 0; k < S; ++k) obs[k] = 0.0;
@@ -193,7 +195,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
     // ANM6Easy.init_state (anm6_easy.py:25-52) with a counter-based RNG
     const uint32_t epoch = uint32_t(io.reset_count[e]);
     uint32_t r[4];
-    Philox::generate(io.rng_seed, uint64_t(e), epoch, 0u, r);
+    Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 0u, r);
     aux = int((uint64_t(r[0]) * uint64_t(io.period)) >> 32);
     static_for<0, T::SDIM>([&](auto I) { s0[I] = 0.0; });
     s0[T::SDIM] = double(aux);
@@ -207,7 +209,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
         constexpr int u = g;  // uniform index
         cptr_t sd = C + L::SETDEV + SD_SIZE * T::DEV_SET[d];
         uint32_t q[4];
-        Philox::generate(io.rng_seed, uint64_t(e), epoch, 1u + u / 2, q);
+        Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 1u + u / 2, q);
         const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
         const double pm = io.series[(T::NLOAD + g) * io.period + aux];
         s0[d] = pm;
@@ -217,7 +219,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
         constexpr int u = T::NGEN + T::DEV_SLOT[d];
         cptr_t sd = C + L::SETDEV + SD_SIZE * T::DEV_SET[d];
         uint32_t q[4];
-        Philox::generate(io.rng_seed, uint64_t(e), epoch, 1u + u / 2, q);
+        Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 1u + u / 2, q);
         const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
         s0[2 * T::ND + T::DEV_SLOT[d]] = sd[SD_SOC_MIN] + (sd[SD_SOC_MAX] - sd[SD_SOC_MIN]) * uu;  // sic
       }
@@ -251,6 +253,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   }
 
   // 3. one simulator transition, shared by the step and the autoreset path
+  ANM_PHASE(1);
   transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
   if (io.nr_iters) io.nr_iters[e] = w.n_iter;
 
@@ -300,6 +303,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   }
   if (io.timestep) io.timestep[e] += 1;
   if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+  ANM_PHASE(6);
 }
 
 }  // namespace anm

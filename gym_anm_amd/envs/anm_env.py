@@ -89,7 +89,7 @@ def check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, state_bound
 class BatchedANMEnv(GymEnv):
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
                  num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
-                 _backend=None):  # fmt: skip
+                 env_offset=0, _backend=None):  # fmt: skip
         GymEnv.reset(self, seed=seed)
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
         self.aux_bounds = aux_bounds
@@ -101,6 +101,7 @@ class BatchedANMEnv(GymEnv):
         self.costs_clipping = (c1, c2)
         self.num_envs = int(num_envs)
         self.autoreset = bool(autoreset)
+        self.env_offset = int(env_offset)  # global index of environment 0 (sharded batches)
 
         self.simulator = BatchedSimulator(network, delta_t, lamb, num_envs=num_envs, device=device, tol=tol,
                                           max_iter=max_iter, precision=precision, _backend=_backend)  # fmt: skip
@@ -400,10 +401,10 @@ class BatchedANMEnv(GymEnv):
         if switch:
             with torch.cuda.device(dev):
                 rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
-                        self.rng_seed, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
+                        self.rng_seed, self.env_offset, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
         else:
             rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
-                    self.rng_seed, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
+                    self.rng_seed, self.env_offset, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
         if rc != 0:
             sim.backend.check(rc, "anm_step_f64")
 

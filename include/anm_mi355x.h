@@ -148,12 +148,14 @@ int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, cons
  *   autoreset (series mode only): an environment that is terminated on entry is re-initialised
  *        instead of stepped (Gymnasium "next step" autoreset): its initial state is drawn like
  *        ANM6Easy.init_state (anm6_easy.py:25-52) from a counter-based RNG keyed by
- *        (rng_seed, env index, reset_count[e]); reward 0, terminated 0. */
+ *        (rng_seed, env_offset + env index, reset_count[e]); reward 0, terminated 0.  env_offset is
+ *        the global index of this batch's first environment, so a batch sharded over several GPUs
+ *        draws exactly what the unsharded batch would. */
 int anm_step_f64(anm_model* m, int64_t num_envs, const double* action, const double* exo,
                  const double* aux_next, double* soc, double* state, uint8_t* terminated,
                  int32_t* timestep, double* obs, double* reward, double* e_loss, double* penalty,
                  int32_t* nr_iters, double* full, int32_t autoreset, uint64_t rng_seed,
-                 int32_t* reset_count, const anm_solver_opts* opts, void* stream);
+                 uint64_t env_offset, int32_t* reset_count, const anm_solver_opts* opts, void* stream);
 
 /* obs[e, k] = clip(full[e, index[k]] * scale[k], low[k], high[k]) for k < n_obs: the list form of
  * the observation space (anm_env.py:497-521,562-592).  index/scale/low/high are dev arrays. */
@@ -178,7 +180,8 @@ int anm_model_full_layout(const anm_model* m, anm_full_layout* out);
 int anm_time_step_launches(anm_model* m, int64_t num_envs, const double* action, double* soc,
                            double* state, uint8_t* terminated, int32_t* timestep, double* obs,
                            double* reward, double* e_loss, double* penalty, int32_t autoreset,
-                           uint64_t rng_seed, int32_t* reset_count, const anm_solver_opts* opts,
+                           uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count,
+                           const anm_solver_opts* opts,
                            void* stream, int32_t n_launch, float* ms_per_launch);
 
 #ifdef __cplusplus
