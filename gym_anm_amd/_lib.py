@@ -60,6 +60,7 @@ class FullLayout(C.Structure):
 
 
 SOLVE_F64, SOLVE_F32 = 0, 1
+IMPL_THREAD, IMPL_RADIAL = 0, 1
 
 _P = C.c_void_p  # raw device (or, for the test double, host) pointers are passed as integers
 
@@ -74,6 +75,8 @@ ABI = {
     "anm_model_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
     "anm_model_set_env": (C.c_int, [C.c_void_p, C.POINTER(EnvConfig)]),
     "anm_model_get_ybus": (C.c_int, [C.c_void_p, c_double_p]),
+    "anm_model_set_impl": (C.c_int, [C.c_void_p, C.c_int32]),
+    "anm_model_get_impl": (C.c_int, [C.c_void_p]),
     "anm_model_full_layout": (C.c_int, [C.c_void_p, C.POINTER(FullLayout)]),
     "anm_transition_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 11 + [C.POINTER(SolverOpts), _P]),
     "anm_reset_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 10 + [C.POINTER(SolverOpts), _P]),

@@ -17,6 +17,7 @@
 #include ANM_TOPO_HEADER
 #include "anm_env_ops.hpp"
 #include "anm_pack.hpp"
+#include "anm_radial.hpp"
 
 using namespace anm;
 
@@ -72,6 +73,11 @@ __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__
 }  // namespace
 
 struct anm_model {
+  int impl = ANM_IMPL_THREAD;   // which kernel family serves this model
+  bool radial_ok = false;       // the network is a tree that fits one wavefront
+  radial::Plan plan;            // per-lane tables of the lane-group kernel
+  int* d_ri = nullptr;
+  double* d_rd = nullptr;
   double* d_const = nullptr;    // device constant buffer (Layout<Topo>)
   double* d_series = nullptr;   // device exogenous series [NEXO][period]
   int period = 0;
@@ -86,6 +92,23 @@ namespace {
 int upload_const(anm_model* m) {
   hipError_t e = hipMemcpy(m->d_const, m->h_const.data(), m->h_const.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail_hip(e, "hipMemcpy(constants)");
+  if (m->radial_ok) {
+    e = hipMemcpy(m->d_rd, m->plan.hd.data(), m->plan.hd.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpy(radial tables)");
+  }
+  return 0;
+}
+
+template <class... Args>
+int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
+  const int per_wave = 64 / m->plan.d.G;
+  const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
+  if (precision == ANM_SOLVE_F32)
+    hipLaunchKernelGGL(radial::k_radial<float>, dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+  else
+    hipLaunchKernelGGL(radial::k_radial<double>, dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_radial");
   return 0;
 }
 
@@ -131,6 +154,20 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
     delete m;
     return fail_hip(e, "hipMalloc(constants)");
   }
+  if (radial::is_radial(*desc) && radial::build_plan(*desc, m->plan, err)) {
+    hipError_t e1 = hipMalloc(&m->d_ri, m->plan.hi.size() * sizeof(int));
+    hipError_t e2 = hipMalloc(&m->d_rd, m->plan.hd.size() * sizeof(double));
+    if (e1 == hipSuccess && e2 == hipSuccess &&
+        hipMemcpy(m->d_ri, m->plan.hi.data(), m->plan.hi.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
+      m->radial_ok = true;
+      // default: the lane-group kernel once the thread-per-environment working set no longer fits
+      // in registers (measured: a 30-bus feeder spills 4.7 KB/lane); ANM_IMPL=thread|radial overrides
+      m->impl = (Topo::NB > 12) ? ANM_IMPL_RADIAL : ANM_IMPL_THREAD;
+      const char* ev = getenv("ANM_IMPL");
+      if (ev && std::string(ev) == "thread") m->impl = ANM_IMPL_THREAD;
+      if (ev && std::string(ev) == "radial") m->impl = ANM_IMPL_RADIAL;
+    }
+  }
   int rc = upload_const(m);
   if (rc) {
     hipFree(m->d_const);
@@ -145,6 +182,8 @@ void anm_model_destroy(anm_model* m) {
   if (!m) return;
   if (m->d_const) hipFree(m->d_const);
   if (m->d_series) hipFree(m->d_series);
+  if (m->d_ri) hipFree(m->d_ri);
+  if (m->d_rd) hipFree(m->d_rd);
   delete m;
 }
 
@@ -181,6 +220,17 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
     return -3;
   }
   m->K = cfg->K;
+  if (m->radial_ok) {
+    radial::Plan& P = m->plan;
+    P.hd[radial::SF_C1] = cfg->clip_e_loss;
+    P.hd[radial::SF_C2] = cfg->clip_penalty;
+    P.hd[radial::SF_RTERM] = -cfg->clip_penalty / (1 - cfg->gamma);
+    P.hd[radial::SF_PERIOD] = cfg->period;
+    for (int k = 0; k < P.d.SDIM + cfg->K; ++k) {
+      if (cfg->obs_low) P.hd[P.d.off_obs_lo + k] = cfg->obs_low[k];
+      if (cfg->obs_high) P.hd[P.d.off_obs_hi + k] = cfg->obs_high[k];
+    }
+  }
   if (m->d_series) {
     hipFree(m->d_series);
     m->d_series = nullptr;
@@ -198,6 +248,17 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   m->env_set = true;
   return upload_const(m);
 }
+
+int anm_model_set_impl(anm_model* m, int32_t impl) {
+  if (!m) return fail("anm_model_set_impl: null model");
+  if (impl == ANM_IMPL_RADIAL && !m->radial_ok)
+    return fail("the lane-group kernel needs a radial (tree) network with at most 64 buses and devices");
+  if (impl != ANM_IMPL_THREAD && impl != ANM_IMPL_RADIAL) return fail("anm_model_set_impl: unknown implementation");
+  m->impl = impl;
+  return 0;
+}
+
+int anm_model_get_impl(const anm_model* m) { return m ? m->impl : -1; }
 
 int anm_model_get_ybus(const anm_model* m, double* y) {
   if (!m || !y) return fail("anm_model_get_ybus: null argument");
@@ -219,6 +280,12 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   int prec;
   SolverOpts so = solver(opts, prec);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (m->impl == ANM_IMPL_RADIAL) {
+    radial::IO rio{};
+    rio.mode = 0;
+    rio.t = io;
+    return launch_radial(m, prec, n, s, rio, so);
+  }
   cptr_t C = (cptr_t)m->d_const;
   if (prec == ANM_SOLVE_F32)
     hipLaunchKernelGGL(k_transition<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
@@ -251,6 +318,12 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
   int prec;
   SolverOpts so = solver(opts, prec);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (m->impl == ANM_IMPL_RADIAL) {
+    radial::IO rio{};
+    rio.mode = 1;
+    rio.e = io;
+    return launch_radial(m, prec, n, s, rio, so);
+  }
   cptr_t C = (cptr_t)m->d_const;
   if (prec == ANM_SOLVE_F32)
     hipLaunchKernelGGL(k_reset<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
@@ -301,6 +374,12 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
 static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solver_opts* opts, hipStream_t s) {
   int prec;
   SolverOpts so = solver(opts, prec);
+  if (m->impl == ANM_IMPL_RADIAL) {
+    radial::IO rio{};
+    rio.mode = 2;
+    rio.e = io;
+    return launch_radial(m, prec, n, s, rio, so);
+  }
   cptr_t C = (cptr_t)m->d_const;
   if (prec == ANM_SOLVE_F32)
     hipLaunchKernelGGL(k_step<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);

@@ -76,6 +76,65 @@ struct Interval {
   void geq(double coef, double rhs) { leq(-coef, -rhs); }
 };
 
+// Constants of ONE device: loads -> {p_min, p_max, Q/P}; generators / storage -> the SetDev block
+// (limits + the static part of the exact polygon projection, see project_pq in anm_device.hpp).
+inline void pack_device(const anm_network_desc& d, int k, double* out) {
+  const double inf = std::numeric_limits<double>::infinity();
+  const int typ = d.dev_type[k];
+  if (typ == DEV_LOAD) {
+    out[0] = d.dev_pmin[k];
+    out[1] = d.dev_pmax[k];
+    out[2] = d.dev_qp[k];
+    return;
+  }
+  if (typ == DEV_SLACK) return;
+  double* sd = out;
+  const bool des = typ == DEV_STORAGE;
+  sd[SD_PMIN] = d.dev_pmin[k];
+  sd[SD_PMAX] = d.dev_pmax[k];
+  sd[SD_QMIN] = d.dev_qmin[k];
+  sd[SD_QMAX] = d.dev_qmax[k];
+  sd[SD_SOC_MIN] = des ? d.dev_soc_min[k] : 0.0;
+  sd[SD_SOC_MAX] = des ? d.dev_soc_max[k] : 0.0;
+  sd[SD_EFF] = des ? d.dev_eff[k] : 1.0;
+  // slanted constraints: k0: q <= tau1 p + rho1, k1: q >= tau2 p + rho2,
+  //                      k2: q >= tau3 p + rho3, k3: q <= tau4 p + rho4   (devices.py:294-296,486-514)
+  double tau[4], rho[4], sense[4];
+  const double sgn[4] = {+1.0, -1.0, -1.0, +1.0};
+  for (int j = 0; j < 4; ++j) {
+    tau[j] = d.dev_tau[4 * k + j];
+    rho[j] = d.dev_rho[4 * k + j];
+    const bool on = (j < 2 || des) && std::isfinite(tau[j]) && std::isfinite(rho[j]);
+    sense[j] = on ? sgn[j] : 0.0;
+    if (!on) { tau[j] = 0.0; rho[j] = sgn[j] * inf; }
+  }
+  const double ql = sd[SD_QMIN], qu = sd[SD_QMAX];
+  auto others = [&](double a, double b, int self_h, int self_s) {
+    Interval iv;                       // constraints on the line q = a p + b
+    if (self_h != 0) iv.geq(a, ql - b);  // q >= ql
+    if (self_h != 1) iv.leq(a, qu - b);  // q <= qu
+    for (int j = 0; j < 4; ++j) {
+      if (j == self_s || sense[j] == 0.0) continue;
+      if (sense[j] > 0) iv.leq(a - tau[j], rho[j] - b);  // a p + b <= tau_j p + rho_j
+      else iv.geq(a - tau[j], rho[j] - b);
+    }
+    return iv;
+  };
+  Interval h0 = others(0.0, ql, 0, -1), h1 = others(0.0, qu, 1, -1);
+  sd[SD_HLO_LO] = h0.lo; sd[SD_HLO_HI] = h0.hi;
+  sd[SD_HHI_LO] = h1.lo; sd[SD_HHI_HI] = h1.hi;
+  for (int j = 0; j < 4; ++j) {
+    double* s = &sd[SD_SL + 6 * j];
+    Interval iv = others(tau[j], rho[j], -1, j);
+    s[SL_TAU] = tau[j];
+    s[SL_RHO] = rho[j];
+    s[SL_INV] = 1.0 / (1.0 + tau[j] * tau[j]);
+    s[SL_LO] = iv.lo;
+    s[SL_HI] = iv.hi;
+    s[SL_SENSE] = sense[j];
+  }
+}
+
 template <class T>
 inline bool pack_constants(const anm_network_desc& d, std::vector<double>& C, std::vector<cplx>& Y, std::string& err) {
   typedef Layout<T> L;
@@ -117,58 +176,8 @@ inline bool pack_constants(const anm_network_desc& d, std::vector<double>& C, st
   }
   for (int k = 0; k < T::ND; ++k) {
     const int typ = T::DEV_TYPE[k];
-    if (typ == DEV_LOAD) {
-      double* c = &C[L::LOAD + 3 * T::DEV_SLOT[k]];
-      c[0] = d.dev_pmin[k];
-      c[1] = d.dev_pmax[k];
-      c[2] = d.dev_qp[k];
-    } else if (typ != DEV_SLACK) {
-      double* sd = &C[L::SETDEV + SD_SIZE * T::DEV_SET[k]];
-      const bool des = typ == DEV_STORAGE;
-      sd[SD_PMIN] = d.dev_pmin[k];
-      sd[SD_PMAX] = d.dev_pmax[k];
-      sd[SD_QMIN] = d.dev_qmin[k];
-      sd[SD_QMAX] = d.dev_qmax[k];
-      sd[SD_SOC_MIN] = des ? d.dev_soc_min[k] : 0.0;
-      sd[SD_SOC_MAX] = des ? d.dev_soc_max[k] : 0.0;
-      sd[SD_EFF] = des ? d.dev_eff[k] : 1.0;
-      // slanted constraints: k0: q <= tau1 p + rho1, k1: q >= tau2 p + rho2,
-      //                      k2: q >= tau3 p + rho3, k3: q <= tau4 p + rho4   (devices.py:294-296,486-514)
-      double tau[4], rho[4], sense[4];
-      const double sgn[4] = {+1.0, -1.0, -1.0, +1.0};
-      for (int j = 0; j < 4; ++j) {
-        tau[j] = d.dev_tau[4 * k + j];
-        rho[j] = d.dev_rho[4 * k + j];
-        const bool on = (j < 2 || des) && std::isfinite(tau[j]) && std::isfinite(rho[j]);
-        sense[j] = on ? sgn[j] : 0.0;
-        if (!on) { tau[j] = 0.0; rho[j] = sgn[j] * inf; }
-      }
-      const double ql = sd[SD_QMIN], qu = sd[SD_QMAX];
-      auto others = [&](double a, double b, int self_h, int self_s) {
-        Interval iv;                       // constraints on the line q = a p + b
-        if (self_h != 0) iv.geq(a, ql - b);  // q >= ql
-        if (self_h != 1) iv.leq(a, qu - b);  // q <= qu
-        for (int j = 0; j < 4; ++j) {
-          if (j == self_s || sense[j] == 0.0) continue;
-          if (sense[j] > 0) iv.leq(a - tau[j], rho[j] - b);  // a p + b <= tau_j p + rho_j
-          else iv.geq(a - tau[j], rho[j] - b);
-        }
-        return iv;
-      };
-      Interval h0 = others(0.0, ql, 0, -1), h1 = others(0.0, qu, 1, -1);
-      sd[SD_HLO_LO] = h0.lo; sd[SD_HLO_HI] = h0.hi;
-      sd[SD_HHI_LO] = h1.lo; sd[SD_HHI_HI] = h1.hi;
-      for (int j = 0; j < 4; ++j) {
-        double* s = &sd[SD_SL + 6 * j];
-        Interval iv = others(tau[j], rho[j], -1, j);
-        s[SL_TAU] = tau[j];
-        s[SL_RHO] = rho[j];
-        s[SL_INV] = 1.0 / (1.0 + tau[j] * tau[j]);
-        s[SL_LO] = iv.lo;
-        s[SL_HI] = iv.hi;
-        s[SL_SENSE] = sense[j];
-      }
-    }
+    if (typ == DEV_LOAD) pack_device(d, k, &C[L::LOAD + 3 * T::DEV_SLOT[k]]);
+    else if (typ != DEV_SLACK) pack_device(d, k, &C[L::SETDEV + SD_SIZE * T::DEV_SET[k]]);
   }
   return true;
 }

@@ -1,0 +1,659 @@
+// anm_radial.hpp -- lane-group kernel for RADIAL (tree) networks of any size up to 64 buses.
+//
+// The thread-per-environment kernels (anm_device.hpp) keep a whole environment in one thread's
+// registers; that is the fastest mapping while the working set fits (ANM6: 0 bytes of scratch)
+// but a 30-bus feeder needs ~600 doubles per environment and spills (512 registers + 4.7 KB of
+// scratch per lane).  Here one environment is spread over a group of G = 8/16/32/64 lanes of ONE
+// wavefront; lane l plays three roles at once:
+//     bus l+1 (and the branch that joins it to its parent bus),   device l.
+// The tree structure replaces the general sparse LU: every Newton iteration is
+//   V, E  -> LDS;  each lane sums its row of Y V from its parent and its children (LDS gathers);
+//   mismatch + group-wide inf-norm (shuffle butterfly);
+//   2x2 Jacobian blocks: own diagonal + the two couplings with the parent bus;
+//   block elimination leaves -> roots, one tree level per step (children publish their Schur
+//   complement and reduced right-hand side in LDS, parents gather them in bus order);
+//   back substitution roots -> leaves.
+// Same reference semantics as anm_device.hpp (see the citations there); results differ from the
+// thread-per-environment kernels only by summation order (~1e-16).  Nothing here is compile-time
+// specialised: the per-lane tables built by build_plan() drive one generic kernel.
+#pragma once
+
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "anm_device.hpp"
+#include "anm_env_ops.hpp"
+#include "anm_pack.hpp"
+
+namespace anm {
+namespace radial {
+
+enum IField : int { IF_PARENT = 0, IF_DEPTH, IF_CH_BEG, IF_CH_END, IF_BD_BEG, IF_BD_END, IF_BR_INDEX, IF_BR_FROM,
+                    IF_DEV_TYPE, IF_DEV_SLOT, IF_DEV_SET, IF_COUNT };
+enum DField : int { DF_YBB_RE = 0, DF_YBB_IM, DF_YBP_RE, DF_YBP_IM, DF_YPB_RE, DF_YPB_IM, DF_VMIN, DF_VMAX, DF_BRC,
+                    DF_COUNT = DF_BRC + 9 };
+enum SField : int { SF_BASE = 0, SF_DT, SF_LAMB, SF_C1, SF_C2, SF_RTERM, SF_PERIOD, SF_Y00_RE, SF_Y00_IM,
+                    SF_SLACK_VMIN, SF_SLACK_VMAX, SF_COUNT = 16 };
+constexpr int DEV_NONE = -99;
+constexpr int KMAX = 8;
+
+struct Dims {
+  int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, max_depth, slack_dev;
+  int off_lists;                       // ints: [IF_COUNT][G] then child / bus-device lists
+  int off_lane, off_dev, off_obs_lo, off_obs_hi, n_double;  // doubles
+  // offsets inside one row of the full-state dump (same order as FullState<T>)
+  int f_bus_p, f_bus_q, f_bus_vm, f_bus_va, f_bus_im, f_bus_ia, f_dev_p, f_dev_q, f_des_soc, f_gen_pmax, f_br_p,
+      f_br_q, f_br_s, f_br_im, f_br_ia;
+};
+
+struct Plan {
+  Dims d;
+  std::vector<int> hi;
+  std::vector<double> hd;
+  const int* di = nullptr;     // device copies
+  const double* dd = nullptr;
+};
+
+inline bool is_radial(const anm_network_desc& n) {
+  if (n.n_branch != n.n_bus - 1 || n.n_bus < 2 || n.n_bus - 1 > 64 || n.n_dev > 64) return false;
+  std::vector<std::vector<int>> adj(n.n_bus);
+  for (int b = 0; b < n.n_branch; ++b) {
+    adj[n.br_from[b]].push_back(n.br_to[b]);
+    adj[n.br_to[b]].push_back(n.br_from[b]);
+  }
+  std::vector<int> seen(n.n_bus, 0);
+  std::queue<int> q;
+  q.push(0);
+  seen[0] = 1;
+  int cnt = 1;
+  while (!q.empty()) {
+    int u = q.front();
+    q.pop();
+    for (int v : adj[u])
+      if (!seen[v]) { seen[v] = 1; ++cnt; q.push(v); }
+  }
+  return cnt == n.n_bus;
+}
+
+// Tables for one network.  `base` = the constant buffer of the thread-per-env layout is NOT needed:
+// everything is rebuilt from the description (same formulas as pack_constants).
+inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
+  if (!is_radial(n)) { err = "network is not a radial tree with <= 64 buses/devices"; return false; }
+  Dims& d = P.d;
+  d.NB = n.n_bus; d.ND = n.n_dev; d.NBR = n.n_branch;
+  d.NLOAD = d.NGEN = d.NDES = 0;
+  std::vector<int> slot(n.n_dev, -1), sset(n.n_dev, -1);
+  d.slack_dev = -1;
+  for (int k = 0; k < n.n_dev; ++k) {
+    const int t = n.dev_type[k];
+    if (t == DEV_LOAD) slot[k] = d.NLOAD++;
+    else if (t == DEV_CLASSICAL || t == DEV_RENEWABLE) slot[k] = d.NGEN++;
+    else if (t == DEV_STORAGE) slot[k] = d.NDES++;
+    else d.slack_dev = k;
+  }
+  d.NSET = 0;
+  for (int k = 0; k < n.n_dev; ++k)
+    if (n.dev_type[k] == DEV_CLASSICAL || n.dev_type[k] == DEV_RENEWABLE || n.dev_type[k] == DEV_STORAGE) sset[k] = d.NSET++;
+  d.SDIM = 2 * d.ND + d.NDES + d.NGEN;
+  int need = std::max(std::max(d.NB - 1, d.ND), d.NBR);
+  d.G = 8;
+  while (d.G < need) d.G *= 2;
+  const int G = d.G;
+  // full-state layout
+  d.f_bus_p = 0; d.f_bus_q = d.f_bus_p + d.NB; d.f_bus_vm = d.f_bus_q + d.NB; d.f_bus_va = d.f_bus_vm + d.NB;
+  d.f_bus_im = d.f_bus_va + d.NB; d.f_bus_ia = d.f_bus_im + d.NB; d.f_dev_p = d.f_bus_ia + d.NB;
+  d.f_dev_q = d.f_dev_p + d.ND; d.f_des_soc = d.f_dev_q + d.ND; d.f_gen_pmax = d.f_des_soc + d.NDES;
+  d.f_br_p = d.f_gen_pmax + d.NGEN; d.f_br_q = d.f_br_p + d.NBR; d.f_br_s = d.f_br_q + d.NBR;
+  d.f_br_im = d.f_br_s + d.NBR; d.f_br_ia = d.f_br_im + d.NBR; d.FS = d.f_br_ia + d.NBR;
+
+  // tree rooted at the slack bus: BFS gives parent bus and the branch to it
+  std::vector<std::vector<std::pair<int, int>>> adj(d.NB);  // (neighbour, branch)
+  for (int b = 0; b < d.NBR; ++b) {
+    adj[n.br_from[b]].push_back({n.br_to[b], b});
+    adj[n.br_to[b]].push_back({n.br_from[b], b});
+  }
+  std::vector<int> parent(d.NB, -2), pbranch(d.NB, -1), depth(d.NB, -1);
+  std::queue<int> q;
+  q.push(0);
+  parent[0] = -1;
+  while (!q.empty()) {
+    int u = q.front();
+    q.pop();
+    for (auto& e : adj[u])
+      if (parent[e.first] == -2) {
+        parent[e.first] = u;
+        pbranch[e.first] = e.second;
+        depth[e.first] = (u == 0) ? 0 : depth[u] + 1;
+        q.push(e.first);
+      }
+  }
+  d.max_depth = 0;
+  for (int b = 1; b < d.NB; ++b) d.max_depth = std::max(d.max_depth, depth[b]);
+
+  // admittances exactly like build_ybus / pack_constants
+  std::vector<cplx> Y(size_t(d.NB) * d.NB, cplx(0, 0));
+  std::vector<cplx> aff(d.NBR), aft(d.NBR), att(d.NBR), atf(d.NBR);
+  for (int b = 0; b < d.NBR; ++b) {
+    const int f = n.br_from[b], t = n.br_to[b];
+    const cplx ys(n.br_series[2 * b], n.br_series[2 * b + 1]), sh(n.br_shunt[2 * b], n.br_shunt[2 * b + 1]);
+    const cplx tap(n.br_tap[2 * b], n.br_tap[2 * b + 1]);
+    Y[f * d.NB + t] = -ys / std::conj(tap);
+    Y[t * d.NB + f] = -ys / tap;
+    Y[f * d.NB + f] += (ys + sh) / (std::abs(tap) * std::abs(tap));
+    Y[t * d.NB + t] += ys + sh;
+    aff[b] = (ys + sh) / (std::abs(tap) * std::abs(tap));
+    aft[b] = -ys / std::conj(tap);
+    att[b] = ys + sh;
+    atf[b] = -ys / tap;
+  }
+
+  // ---- int tables
+  P.hi.assign(size_t(IF_COUNT) * G, 0);
+  auto I = [&](int f, int l) -> int& { return P.hi[size_t(f) * G + l]; };
+  std::vector<int> lists;
+  for (int l = 0; l < G; ++l) {
+    I(IF_PARENT, l) = -1; I(IF_DEPTH, l) = -1; I(IF_BR_INDEX, l) = -1; I(IF_DEV_TYPE, l) = DEV_NONE;
+    I(IF_DEV_SLOT, l) = -1; I(IF_DEV_SET, l) = -1;
+  }
+  for (int l = 0; l + 1 < d.NB; ++l) {
+    const int b = l + 1;
+    I(IF_PARENT, l) = parent[b] == 0 ? -1 : parent[b] - 1;
+    I(IF_DEPTH, l) = depth[b];
+    I(IF_BR_INDEX, l) = pbranch[b];
+    I(IF_BR_FROM, l) = n.br_from[pbranch[b]] == b ? 1 : 0;
+    I(IF_CH_BEG, l) = int(lists.size());
+    for (int c = 1; c < d.NB; ++c)
+      if (parent[c] == b) lists.push_back(c - 1);  // ascending bus order
+    I(IF_CH_END, l) = int(lists.size());
+  }
+  for (int l = 0; l + 1 < d.NB; ++l) {
+    const int b = l + 1;
+    I(IF_BD_BEG, l) = int(lists.size());
+    for (int k = 0; k < d.ND; ++k)
+      if (n.dev_bus[k] == b) lists.push_back(k);  // ascending device order (simulator.py:547-549)
+    I(IF_BD_END, l) = int(lists.size());
+  }
+  for (int k = 0; k < d.ND; ++k) {
+    I(IF_DEV_TYPE, k) = n.dev_type[k];
+    I(IF_DEV_SLOT, k) = slot[k];
+    I(IF_DEV_SET, k) = sset[k];
+  }
+  d.off_lists = int(P.hi.size());
+  P.hi.insert(P.hi.end(), lists.begin(), lists.end());
+  P.hi.push_back(0);
+
+  // ---- double tables
+  d.off_lane = SF_COUNT;
+  d.off_dev = d.off_lane + DF_COUNT * G;
+  d.off_obs_lo = d.off_dev + d.ND * SD_SIZE;
+  d.off_obs_hi = d.off_obs_lo + d.SDIM + KMAX;
+  d.n_double = d.off_obs_hi + d.SDIM + KMAX;
+  const double inf = std::numeric_limits<double>::infinity();
+  P.hd.assign(d.n_double, 0.0);
+  P.hd[SF_BASE] = n.base_mva; P.hd[SF_DT] = n.delta_t; P.hd[SF_LAMB] = n.lamb;
+  P.hd[SF_C1] = inf; P.hd[SF_C2] = inf; P.hd[SF_RTERM] = -inf;
+  P.hd[SF_Y00_RE] = Y[0].real(); P.hd[SF_Y00_IM] = Y[0].imag();
+  P.hd[SF_SLACK_VMIN] = n.bus_vmin[0]; P.hd[SF_SLACK_VMAX] = n.bus_vmax[0];
+  for (int k = 0; k < d.SDIM + KMAX; ++k) { P.hd[d.off_obs_lo + k] = -inf; P.hd[d.off_obs_hi + k] = inf; }
+  auto D = [&](int f, int l) -> double& { return P.hd[d.off_lane + size_t(f) * G + l]; };
+  for (int l = 0; l + 1 < d.NB; ++l) {
+    const int b = l + 1, p = parent[b], br = pbranch[b];
+    D(DF_YBB_RE, l) = Y[b * d.NB + b].real(); D(DF_YBB_IM, l) = Y[b * d.NB + b].imag();
+    D(DF_YBP_RE, l) = Y[b * d.NB + p].real(); D(DF_YBP_IM, l) = Y[b * d.NB + p].imag();
+    D(DF_YPB_RE, l) = Y[p * d.NB + b].real(); D(DF_YPB_IM, l) = Y[p * d.NB + b].imag();
+    D(DF_VMIN, l) = n.bus_vmin[b]; D(DF_VMAX, l) = n.bus_vmax[b];
+    const cplx c4[4] = {aff[br], aft[br], att[br], atf[br]};
+    for (int j = 0; j < 4; ++j) { D(DF_BRC + 2 * j, l) = c4[j].real(); D(DF_BRC + 2 * j + 1, l) = c4[j].imag(); }
+    D(DF_BRC + 8, l) = n.br_rate[br];
+  }
+  // device constants: reuse the thread-per-env packing of one device (anm_pack.hpp) through a
+  // single-device shim so that the projection tables are computed by exactly the same code
+  for (int k = 0; k < d.ND; ++k) {
+    double* sd = &P.hd[d.off_dev + k * SD_SIZE];
+    pack_device(n, k, sd);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+struct IO {
+  int mode;  // 0 transition, 1 reset, 2 step
+  TransitionIO t;
+  EnvIO e;
+};
+
+enum { A_VR = 0, A_VI, A_ER, A_EI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N };  // LDS arrays
+
+template <class JT>
+__global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ ri, const double* __restrict__ rd, IO io,
+                                              SolverOpts so, int64_t n_env) {
+  __shared__ double sh[A_N][64];
+  const int t = threadIdx.x;
+  const int G = d.G;
+  const int l = t & (G - 1);
+  const int gb = t - l;
+  const int per_wave = 64 / G;
+  const int64_t e = int64_t(blockIdx.x) * per_wave + (t / G);
+  const bool env_ok = e < n_env;
+  const int64_t ee = env_ok ? e : 0;  // inactive groups compute on env 0 and never store
+  auto RI = [&](int f) { return ri[f * G + l]; };
+  auto RD = [&](int f) { return rd[d.off_lane + f * G + l]; };
+  cptr_t C = (cptr_t)rd;
+  const double base = rd[SF_BASE], dt = rd[SF_DT];
+
+  const bool isbus = l < d.NB - 1;
+  const int parent = RI(IF_PARENT), depth = RI(IF_DEPTH);
+  const int ch_beg = RI(IF_CH_BEG), ch_end = RI(IF_CH_END);
+  const int typ = RI(IF_DEV_TYPE), slot = RI(IF_DEV_SLOT), sset = RI(IF_DEV_SET);
+  const int* lists = ri + d.off_lists;
+  const int mode = io.mode;
+  const int K = io.e.K;
+  const int S = d.SDIM + K;
+
+  // ---------------- inputs per device lane -------------------------------------------------
+  bool skip = false;        // env in the absorbing terminal state (step mode, no autoreset)
+  bool resetting = false;
+  int aux = 0;
+  double in_p = 0.0, in_q = 0.0, in_pot = 0.0, soc = 0.0, s0_q = 0.0;
+  double soc_req = 0.0;     // reset: requested SoC (MWh slot)
+  if (mode == 0) {
+    if (typ == DEV_LOAD) in_p = io.t.p_load[ee * d.NLOAD + slot];
+    else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
+      in_pot = io.t.p_pot[ee * d.NGEN + slot];
+      in_p = io.t.p_set[ee * d.NSET + sset];
+      in_q = io.t.q_set[ee * d.NSET + sset];
+    } else if (typ == DEV_STORAGE) {
+      in_p = io.t.p_set[ee * d.NSET + sset];
+      in_q = io.t.q_set[ee * d.NSET + sset];
+      soc = io.t.soc[ee * d.NDES + slot];
+    }
+  } else {
+    const bool was_term = (mode == 2) && io.e.terminated[ee] != 0;
+    const bool series = io.e.exo == nullptr;
+    resetting = (mode == 1) || (was_term && io.e.autoreset && series);
+    skip = (mode == 2) && was_term && !resetting;
+    if (mode == 1 && io.e.mask && !io.e.mask[ee]) skip = true;
+    const double* s0 = nullptr;
+    double s0_p = 0.0, s0_pm = 0.0;
+    if (mode == 1) {
+      s0 = io.e.init_state + ee * S;
+      if (typ != DEV_NONE) { s0_p = s0[l]; s0_q = s0[d.ND + l]; }
+      if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) s0_pm = s0[2 * d.ND + d.NDES + slot];
+      if (typ == DEV_STORAGE) soc_req = s0[2 * d.ND + slot];
+    } else if (resetting) {  // autoreset: ANM6Easy.init_state with the counter-based RNG
+      const uint32_t epoch = uint32_t(io.e.reset_count[ee]);
+      uint32_t r[4];
+      Philox::generate(io.e.rng_seed, io.e.env_offset + uint64_t(ee), epoch, 0u, r);
+      aux = int((uint64_t(r[0]) * uint64_t(io.e.period)) >> 32);
+      cptr_t sd = C + d.off_dev + l * SD_SIZE;
+      if (typ == DEV_LOAD) s0_p = io.e.series[slot * io.e.period + aux];
+      else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
+        const int u = slot;
+        uint32_t qd[4];
+        Philox::generate(io.e.rng_seed, io.e.env_offset + uint64_t(ee), epoch, 1u + u / 2, qd);
+        const double uu = Philox::u01(qd[2 * (u % 2)], qd[2 * (u % 2) + 1]);
+        s0_p = s0_pm = io.e.series[(d.NLOAD + slot) * io.e.period + aux];
+        s0_q = sd[SD_QMIN] + (sd[SD_QMAX] - sd[SD_QMIN]) * uu;
+      } else if (typ == DEV_STORAGE) {
+        const int u = d.NGEN + slot;
+        uint32_t qd[4];
+        Philox::generate(io.e.rng_seed, io.e.env_offset + uint64_t(ee), epoch, 1u + u / 2, qd);
+        const double uu = Philox::u01(qd[2 * (u % 2)], qd[2 * (u % 2) + 1]);
+        soc_req = sd[SD_SOC_MIN] + (sd[SD_SOC_MAX] - sd[SD_SOC_MIN]) * uu;
+      }
+    }
+    if (resetting) {
+      if (mode == 1) aux = 0;
+      in_p = s0_p;
+      in_q = s0_q;
+      in_pot = s0_pm;
+      if (typ == DEV_STORAGE) {
+        cptr_t sd = C + d.off_dev + l * SD_SIZE;
+        soc = (s0_p <= 0.0) ? sd[SD_SOC_MIN] : sd[SD_SOC_MAX];  // simulator.py:273-278
+      }
+    } else if (!skip) {
+      const double* a = io.e.action + ee * (2 * (d.NGEN + d.NDES));
+      if (series) {
+        const double av = io.e.state[ee * S + d.SDIM];
+        aux = int(fmod(av + 1.0, double(io.e.period)));
+        if (typ == DEV_LOAD) in_p = io.e.series[slot * io.e.period + aux];
+        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.series[(d.NLOAD + slot) * io.e.period + aux];
+      } else {
+        if (typ == DEV_LOAD) in_p = io.e.exo[ee * (d.NLOAD + d.NGEN) + slot];
+        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.exo[ee * (d.NLOAD + d.NGEN) + d.NLOAD + slot];
+      }
+      if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) { in_p = a[slot]; in_q = a[d.NGEN + slot]; }
+      else if (typ == DEV_STORAGE) {
+        in_p = a[2 * d.NGEN + slot];
+        in_q = a[2 * d.NGEN + d.NDES + slot];
+        soc = io.e.soc[ee * d.NDES + slot];
+      }
+    }
+  }
+
+  // ---------------- device maps (lane = device) ---------------------------------------------
+  double dev_p = 0.0, dev_q = 0.0, p_pot = 0.0;
+  {
+    cptr_t sd = C + d.off_dev + l * SD_SIZE;
+    if (typ == DEV_LOAD) {
+      const double p = fmin(fmax(in_p / base, sd[0]), sd[1]);
+      dev_p = p;
+      dev_q = p * sd[2];
+    } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
+      p_pot = fmin(fmax(in_pot / base, sd[SD_PMIN]), sd[SD_PMAX]);
+      project_pq<2>(sd, in_p / base, in_q / base, sd[SD_PMIN], fmin(sd[SD_PMAX], p_pot), dev_p, dev_q);
+    } else if (typ == DEV_STORAGE) {
+      const double eff = sd[SD_EFF];
+      const double s_lo = (soc - sd[SD_SOC_MAX]) / (dt * eff);
+      const double s_hi = eff * (soc - sd[SD_SOC_MIN]) / dt;
+      project_pq<4>(sd, in_p / base, in_q / base, fmax(sd[SD_PMIN], s_lo), fmin(sd[SD_PMAX], s_hi), dev_p, dev_q);
+      const double ns = (dev_p <= 0.0) ? (soc - dt * eff * dev_p) : (soc - dt * dev_p / eff);
+      soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
+    }
+  }
+  sh[A_S0][t] = dev_p;
+  sh[A_S1][t] = dev_q;
+  __syncthreads();
+  double bus_p = 0.0, bus_q = 0.0;
+  if (isbus)
+    for (int k = RI(IF_BD_BEG); k < RI(IF_BD_END); ++k) {
+      const int dd = lists[k];
+      bus_p += sh[A_S0][gb + dd];
+      bus_q += sh[A_S1][gb + dd];
+    }
+  __syncthreads();
+
+  // ---------------- Newton-Raphson (lane = bus) ----------------------------------------------
+  const double ybb_r = RD(DF_YBB_RE), ybb_i = RD(DF_YBB_IM), ybp_r = RD(DF_YBP_RE), ybp_i = RD(DF_YBP_IM);
+  const double ypb_r = RD(DF_YPB_RE), ypb_i = RD(DF_YPB_IM);
+  double th = 0.0, vm = 1.0, cs = 1.0, sn = 0.0;
+  double vr = 1.0, vi = 0.0, ir = 0.0, ii = 0.0, vpr = 1.0, vpi = 0.0;
+  int it = 0;
+  double diff = 0.0;
+  bool active = true;
+  const int pl = gb + (parent >= 0 ? parent : 0);
+  for (;;) {
+    // ---- V, E, contribution to the parent's current
+    vr = vm * cs;
+    vi = vm * sn;
+    const double sg = (vm > 0.0) ? 1.0 : ((vm < 0.0) ? -1.0 : NAN);
+    const double er = sg * cs, ei = sg * sn;
+    sh[A_VR][t] = vr; sh[A_VI][t] = vi; sh[A_ER][t] = er; sh[A_EI][t] = ei;
+    sh[A_UPR][t] = ypb_r * vr - ypb_i * vi;
+    sh[A_UPI][t] = ypb_r * vi + ypb_i * vr;
+    __syncthreads();
+    double epr = 1.0, epi = 0.0;
+    vpr = 1.0; vpi = 0.0;
+    if (parent >= 0) { vpr = sh[A_VR][pl]; vpi = sh[A_VI][pl]; epr = sh[A_ER][pl]; epi = sh[A_EI][pl]; }
+    ir = ybb_r * vr - ybb_i * vi + ybp_r * vpr - ybp_i * vpi;
+    ii = ybb_r * vi + ybb_i * vr + ybp_r * vpi + ybp_i * vpr;
+    for (int k = ch_beg; k < ch_end; ++k) {
+      const int c = gb + lists[k];
+      ir += sh[A_UPR][c];
+      ii += sh[A_UPI][c];
+    }
+    // ---- mismatch and its inf-norm over the group
+    const double sr = vr * ir + vi * ii, si = vi * ir - vr * ii;
+    const double fr = sr - bus_p, fi = si - bus_q;
+    double a = isbus ? fmax(fabs(fr), fabs(fi)) : 0.0;
+    double nanf = (isbus && (fr != fr || fi != fi)) ? 1.0 : 0.0;
+    for (int m = 1; m < G; m <<= 1) {
+      a = fmax(a, __shfl_xor(a, m, G));
+      nanf = fmax(nanf, __shfl_xor(nanf, m, G));
+    }
+    const double nd = (nanf > 0.0) ? NAN : a;
+    if (it == 0) diff = nd;            // initial evaluation
+    else if (active) diff = nd;
+    const bool was_active = active;
+    active = (diff > so.tol) && (it < so.max_iter);
+    (void)was_active;
+    __syncthreads();
+    if (!__any(active && env_ok && !skip)) break;
+    // ---- Jacobian blocks: own diagonal, coupling with the parent (row b / col p and row p / col b)
+    Blk<JT> Dg, Jbp, Jpb;
+    {
+      // diagonal: U = V conj(Ybb); W = U conj(V); B = U conj(E)
+      const double ur = vr * ybb_r + vi * ybb_i, ui = vi * ybb_r - vr * ybb_i;
+      const double wr = ur * vr + ui * vi, wi = ui * vr - ur * vi;
+      const double br = ur * er + ui * ei, bi = ui * er - ur * ei;
+      const double dr = er * ir + ei * ii, di = ei * ir - er * ii;
+      Dg = Blk<JT>{JT(-(si - wi)), JT(dr + br), JT(sr - wr), JT(di + bi)};
+    }
+    {
+      const double ur = vr * ybp_r + vi * ybp_i, ui = vi * ybp_r - vr * ybp_i;       // V_b conj(Y_bp)
+      const double wr = ur * vpr + ui * vpi, wi = ui * vpr - ur * vpi;
+      const double br = ur * epr + ui * epi, bi = ui * epr - ur * epi;
+      Jbp = Blk<JT>{JT(wi), JT(br), JT(-wr), JT(bi)};
+      const double u2r = vpr * ypb_r + vpi * ypb_i, u2i = vpi * ypb_r - vpr * ypb_i;   // V_p conj(Y_pb)
+      const double w2r = u2r * vr + u2i * vi, w2i = u2i * vr - u2r * vi;
+      const double b2r = u2r * er + u2i * ei, b2i = u2i * er - u2r * ei;
+      Jpb = Blk<JT>{JT(w2i), JT(b2r), JT(-w2r), JT(b2i)};
+    }
+    JT r0 = JT(fr), r1 = JT(fi);
+    // ---- elimination, deepest level first
+    for (int lev = d.max_depth; lev >= 0; --lev) {
+      if (isbus && depth == lev) {
+        for (int k = ch_beg; k < ch_end; ++k) {
+          const int c = gb + lists[k];
+          Dg.a -= JT(sh[A_S0][c]); Dg.b -= JT(sh[A_S1][c]); Dg.c -= JT(sh[A_S2][c]); Dg.d -= JT(sh[A_S3][c]);
+          r0 -= JT(sh[A_L0][c]); r1 -= JT(sh[A_L1][c]);
+        }
+        Dg = blk_inv(Dg);
+        if (parent >= 0) {
+          const Blk<JT> Lk = blk_mul(Jpb, Dg);
+          const Blk<JT> Sc = blk_mul(Lk, Jbp);
+          sh[A_S0][t] = double(Sc.a); sh[A_S1][t] = double(Sc.b); sh[A_S2][t] = double(Sc.c); sh[A_S3][t] = double(Sc.d);
+          sh[A_L0][t] = double(Lk.a * r0 + Lk.b * r1);
+          sh[A_L1][t] = double(Lk.c * r0 + Lk.d * r1);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- back substitution, roots first (dx published in A_L0/A_L1)
+    JT d0 = JT(0), d1 = JT(0);
+    for (int lev = 0; lev <= d.max_depth; ++lev) {
+      if (isbus && depth == lev) {
+        JT a0 = r0, a1 = r1;
+        if (parent >= 0) {
+          const JT p0 = JT(sh[A_UPR][pl]), p1 = JT(sh[A_UPI][pl]);
+          a0 -= Jbp.a * p0 + Jbp.b * p1;
+          a1 -= Jbp.c * p0 + Jbp.d * p1;
+        }
+        d0 = Dg.a * a0 + Dg.b * a1;
+        d1 = Dg.c * a0 + Dg.d * a1;
+        sh[A_UPR][t] = double(d0);
+        sh[A_UPI][t] = double(d1);
+      }
+      __syncthreads();
+    }
+    // ---- update (group-uniform `active`)
+    const double am = (active && isbus) ? 1.0 : 0.0;
+    const double dth = double(d0) * am;
+    vm = fma(-double(d1), am, vm);
+    th -= dth;
+    if (fabs(dth) <= 0.78) {
+      double sd_, cd_;
+      sincos_kernel(dth, 0, sd_, cd_);
+      const double c0 = cs, s0v = sn;
+      cs = fma(c0, cd_, s0v * sd_);
+      sn = fma(s0v, cd_, -(c0 * sd_));
+    } else if (fabs(th) <= 1.0e5) {
+      sincos_small(th, sn, cs);
+    } else if (fabs(th) < 4.0e15) {
+      sincos_medium(th, sn, cs);
+    } else {
+      double sv, cv;
+      sincos(th, &sv, &cv);
+      sn = sv; cs = cv;
+    }
+    it = active ? it + 1 : it;
+  }
+  const bool conv_nan = (diff != diff);
+  const bool converged = !conv_nan && (diff <= so.tol);
+
+  // ---------------- slack injection, branch flows, reward --------------------------------------
+  // I_0 = Y_00 + sum over the buses attached to the slack of Y_0b V_b  (fixed butterfly order)
+  double s0r = (isbus && parent < 0) ? (ypb_r * vr - ypb_i * vi) : 0.0;
+  double s0i = (isbus && parent < 0) ? (ypb_r * vi + ypb_i * vr) : 0.0;
+  for (int m = 1; m < G; m <<= 1) {
+    s0r += __shfl_xor(s0r, m, G);
+    s0i += __shfl_xor(s0i, m, G);
+  }
+  const double i0r = rd[SF_Y00_RE] + s0r, i0i = rd[SF_Y00_IM] + s0i;
+  const double slack_p = (i0r != i0r) ? INFINITY : i0r;
+  const double slack_q = (i0i != i0i) ? INFINITY : -i0i;
+  if (typ == DEV_SLACK) { dev_p = slack_p; dev_q = slack_q; }
+
+  double br_pf = 0, br_qf = 0, br_s = 0, br_ifr = 0, br_ifi = 0, pen = 0.0;
+  if (isbus) {
+    const bool from = RI(IF_BR_FROM) != 0;
+    const double vfr = from ? vr : vpr, vfi = from ? vi : vpi, vtr = from ? vpr : vr, vti = from ? vpi : vi;
+    const double c0 = RD(DF_BRC + 0), c1 = RD(DF_BRC + 1), c2 = RD(DF_BRC + 2), c3 = RD(DF_BRC + 3);
+    const double c4 = RD(DF_BRC + 4), c5 = RD(DF_BRC + 5), c6 = RD(DF_BRC + 6), c7 = RD(DF_BRC + 7);
+    br_ifr = c0 * vfr - c1 * vfi + c2 * vtr - c3 * vti;
+    br_ifi = c0 * vfi + c1 * vfr + c2 * vti + c3 * vtr;
+    const double itr = c4 * vtr - c5 * vti + c6 * vfr - c7 * vfi;
+    const double iti = c4 * vti + c5 * vtr + c6 * vfi + c7 * vfr;
+    br_pf = vfr * br_ifr + vfi * br_ifi;
+    br_qf = vfi * br_ifr - vfr * br_ifi;
+    const double pt = vtr * itr + vti * iti, qt = vti * itr - vtr * iti;
+    const double sf = sqrt(br_pf * br_pf + br_qf * br_qf), st = sqrt(pt * pt + qt * qt);
+    const double sgn = (br_pf > 0.0) ? 1.0 : ((br_pf < 0.0) ? -1.0 : ((br_pf == 0.0) ? 0.0 : NAN));
+    const double smax = (sf != sf || st != st) ? NAN : fmax(sf, st);
+    br_s = sgn * smax;
+    const double over = fabs(br_s) - RD(DF_BRC + 8);
+    pen += (over != over) ? NAN : fmax(0.0, over);
+    const double vmag = fabs(vm);
+    const double hi = vmag - RD(DF_VMAX), lo = RD(DF_VMIN) - vmag;
+    pen += (vmag != vmag) ? NAN : (fmax(0.0, hi) + fmax(0.0, lo));
+  }
+  if (l == 0) pen += fmax(0.0, 1.0 - rd[SF_SLACK_VMAX]) + fmax(0.0, rd[SF_SLACK_VMIN] - 1.0);
+  double el = 0.0;
+  if (typ != DEV_NONE && typ != DEV_STORAGE) el += dev_p;
+  if (typ == DEV_RENEWABLE) {
+    const double curt = p_pot - dev_p;
+    el += (curt != curt) ? NAN : fmax(0.0, curt);
+  }
+  for (int m = 1; m < G; m <<= 1) {
+    pen += __shfl_xor(pen, m, G);
+    el += __shfl_xor(el, m, G);
+  }
+  const double e_loss = el * dt, penalty = pen * (dt * rd[SF_LAMB]);
+  const double reward = -(e_loss + penalty);
+
+  if (!env_ok) return;
+
+  // ---------------- outputs ------------------------------------------------------------------
+  double* full = (mode == 0) ? io.t.full : io.e.full;
+  auto write_full = [&]() {
+    if (!full) return;
+    double* f = full + e * d.FS;
+    if (isbus) {
+      const int b = l + 1;
+      f[d.f_bus_p + b] = bus_p; f[d.f_bus_q + b] = bus_q;
+      f[d.f_bus_vm + b] = hypot(vr, vi); f[d.f_bus_va + b] = atan2(vi, vr);
+      f[d.f_bus_im + b] = hypot(ir, ii); f[d.f_bus_ia + b] = atan2(ii, ir);
+      const int bi = RI(IF_BR_INDEX);
+      f[d.f_br_p + bi] = br_pf; f[d.f_br_q + bi] = br_qf; f[d.f_br_s + bi] = br_s;
+      const double mag = hypot(br_ifr, br_ifi);
+      f[d.f_br_im + bi] = (mag == 0.0) ? 0.0 : (br_ifr / mag) * mag;
+      f[d.f_br_ia + bi] = atan2(br_ifi, br_ifr);
+    }
+    if (l == 0) {
+      f[d.f_bus_p] = slack_p; f[d.f_bus_q] = slack_q; f[d.f_bus_vm] = 1.0; f[d.f_bus_va] = 0.0;
+      f[d.f_bus_im] = hypot(i0r, i0i); f[d.f_bus_ia] = atan2(i0i, i0r);
+    }
+    if (typ != DEV_NONE) { f[d.f_dev_p + l] = dev_p; f[d.f_dev_q + l] = dev_q; }
+    if (typ == DEV_STORAGE) f[d.f_des_soc + slot] = soc;
+    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) f[d.f_gen_pmax + slot] = p_pot;
+  };
+
+  if (mode == 0) {
+    if (typ == DEV_STORAGE) io.t.soc[e * d.NDES + slot] = soc;
+    if (l == 0) {
+      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
+      io.t.converged[e] = converged ? 1 : 0;
+      if (io.t.nr_iters) io.t.nr_iters[e] = it;
+    }
+    write_full();
+    return;
+  }
+
+  double* state = io.e.state + e * S;
+  double* obs = io.e.obs + e * S;
+  cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
+  auto put = [&](int k, double v) {
+    state[k] = v;
+    obs[k] = fmin(fmax(v, lo[k]), hi[k]);
+  };
+  if (skip) {
+    if (mode == 2) {  // absorbing terminal state
+      for (int k = l; k < S; k += G) obs[k] = 0.0;
+      if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
+    }
+    return;
+  }
+  if (l == 0 && io.e.nr_iters) io.e.nr_iters[e] = it;
+  if (resetting) {
+    if (typ == DEV_STORAGE) {
+      soc = soc_req / base;  // simulator.py:284-288
+      io.e.soc[e * d.NDES + slot] = soc;
+    }
+    if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
+    if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
+    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) put(2 * d.ND + d.NDES + slot, p_pot * base);
+    if (mode == 1) {
+      const double* s0 = io.e.init_state + e * S;
+      for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
+      if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
+    } else {
+      if (l == 0) {
+        put(d.SDIM, double(aux));
+        io.e.reset_count[e] += 1;
+        io.e.terminated[e] = converged ? 0 : 1;
+        if (io.e.timestep) io.e.timestep[e] = 0;
+        io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
+      }
+    }
+    write_full();
+    return;
+  }
+  // regular step
+  if (typ == DEV_STORAGE) io.e.soc[e * d.NDES + slot] = soc;
+  const bool term = !converged;
+  if (!term) {
+    if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
+    if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
+    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) put(2 * d.ND + d.NDES + slot, p_pot * base);
+    if (io.e.exo == nullptr) {
+      if (l == 0) put(d.SDIM, double(aux));
+    } else {
+      for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * K + k]);
+    }
+  } else {
+    for (int k = l; k < S; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+  }
+  if (l == 0) {
+    const double c1 = rd[SF_C1], c2 = rd[SF_C2];
+    io.e.terminated[e] = term ? 1 : 0;
+    if (!term) {
+      const double sg2 = (e_loss > 0.0) ? 1.0 : ((e_loss < 0.0) ? -1.0 : 0.0);
+      const double elc = sg2 * fmin(fabs(e_loss), c1);
+      const double pn = fmin(fmax(penalty, 0.0), c2);
+      io.e.e_loss[e] = elc; io.e.penalty[e] = pn; io.e.reward[e] = -(elc + pn);
+    } else {
+      io.e.reward[e] = rd[SF_RTERM]; io.e.e_loss[e] = c1; io.e.penalty[e] = c2;
+    }
+    if (io.e.timestep) io.e.timestep[e] += 1;
+  }
+  write_full();
+}
+#endif  // __HIPCC__
+
+}  // namespace radial
+}  // namespace anm

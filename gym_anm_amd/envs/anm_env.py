@@ -89,7 +89,7 @@ def check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, state_bound
 class BatchedANMEnv(GymEnv):
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
                  num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
-                 env_offset=0, _backend=None):  # fmt: skip
+                 env_offset=0, impl=None, _backend=None):  # fmt: skip
         GymEnv.reset(self, seed=seed)
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
         self.aux_bounds = aux_bounds
@@ -104,7 +104,7 @@ class BatchedANMEnv(GymEnv):
         self.env_offset = int(env_offset)  # global index of environment 0 (sharded batches)
 
         self.simulator = BatchedSimulator(network, delta_t, lamb, num_envs=num_envs, device=device, tol=tol,
-                                          max_iter=max_iter, precision=precision, _backend=_backend)  # fmt: skip
+                                          max_iter=max_iter, precision=precision, impl=impl, _backend=_backend)  # fmt: skip
         sim = self.simulator
         self.device = sim.device
         check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, sim.state_bounds)

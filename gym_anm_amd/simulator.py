@@ -73,7 +73,7 @@ class StateView:
 
 class BatchedSimulator:
     def __init__(self, network, delta_t, lamb, num_envs=1, device="cuda", tol=1e-5, max_iter=100,
-                 precision="f64", _backend=None):  # fmt: skip
+                 precision="f64", impl=None, _backend=None):  # fmt: skip
         self.model = NetworkModel(network, delta_t, lamb)
         m = self.model
         self.baseMVA, self.delta_t, self.lamb = m.baseMVA, delta_t, lamb
@@ -105,6 +105,10 @@ class BatchedSimulator:
         desc, self._keep = _lib.network_desc(m)
         with self._device_ctx():
             self.backend.check(self.backend.lib.anm_model_create(C.byref(desc), C.byref(self._handle)), "anm_model_create")
+        if impl is not None:  # "thread" (one thread per env) | "radial" (lane group per env); None = library default
+            code = {"thread": _lib.IMPL_THREAD, "radial": _lib.IMPL_RADIAL}[impl]
+            self.backend.check(self.backend.lib.anm_model_set_impl(self._handle, code), "anm_model_set_impl")
+        self.impl = {0: "thread", 1: "radial"}[self.backend.lib.anm_model_get_impl(self._handle)]
         dims = _lib.Dims()
         self.backend.check(self.backend.lib.anm_model_dims(self._handle, C.byref(dims)), "anm_model_dims")
         self.dims = dims

@@ -104,6 +104,18 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out);
 void anm_model_destroy(anm_model* m);
 int anm_model_dims(const anm_model* m, anm_dims* out);
 int anm_model_set_env(anm_model* m, const anm_env_config* cfg);
+/* Two kernel families implement the same entry points:
+ *   ANM_IMPL_THREAD  one GPU thread per environment, topology compiled in, state in registers
+ *                    (default while the network fits: <= 12 buses);
+ *   ANM_IMPL_RADIAL  one lane group (8..64 lanes of a wavefront) per environment, lane = bus /
+ *                    branch / device, tree elimination through LDS; radial networks up to 64 buses
+ *                    (default above 12 buses).
+ * The environment variable ANM_IMPL=thread|radial overrides the default at model creation. */
+#define ANM_IMPL_THREAD 0
+#define ANM_IMPL_RADIAL 1
+int anm_model_set_impl(anm_model* m, int32_t impl);
+int anm_model_get_impl(const anm_model* m);
+
 /* copy the nodal admittance matrix the library built (simulator.py:183-199) to host memory:
  * y[n_bus*n_bus*2] row-major (re, im). */
 int anm_model_get_ybus(const anm_model* m, double* y_host);

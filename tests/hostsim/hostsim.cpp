@@ -78,6 +78,11 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   m->env_set = true;
   return 0;
 }
+int anm_model_set_impl(anm_model*, int32_t impl) {
+  if (impl != ANM_IMPL_THREAD) return fail("hostsim: only the thread-per-environment templates have a host build");
+  return 0;
+}
+int anm_model_get_impl(const anm_model*) { return ANM_IMPL_THREAD; }
 int anm_model_get_ybus(const anm_model* m, double* y) {
   for (size_t k = 0; k < m->ybus.size(); ++k) { y[2 * k] = m->ybus[k].real(); y[2 * k + 1] = m->ybus[k].imag(); }
   return 0;

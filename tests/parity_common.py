@@ -33,11 +33,12 @@ def full_slices(sim):
     return {k: slice(off[k], off[k] + cnt[k]) for k in off}
 
 
-def check_transition_against_golden(name, net, device, backend=None, precision="f64", atol=ATOL, check_iters=True):
+def check_transition_against_golden(name, net, device, backend=None, precision="f64", atol=ATOL, check_iters=True,
+                                    impl=None):
     g = np.load(os.path.join(GOLDEN, "transition_%s.npz" % name))
     M = len(g["n_iter"])
     sim = BatchedSimulator(net, float(g["delta_t"]), float(g["lamb"]), num_envs=M, device=device,
-                           precision=precision, _backend=backend)  # fmt: skip
+                           precision=precision, impl=impl, _backend=backend)  # fmt: skip
     npt.assert_allclose(sim.device_ybus(), g["Y_bus"], rtol=1e-15, atol=0)
     sim.soc.copy_(torch.as_tensor(g["soc0"]))
     state, r, e, p, conv = sim.transition(g["P_load"], g["P_pot"], g["P_set"], g["Q_set"])

@@ -297,3 +297,106 @@ def test_generic_mode_next_vars_hook():
         obs, r, term, _, _ = env.step(torch.as_tensor(g["actions"][:, t], device=DEV))
         npt.assert_allclose(obs.cpu().numpy(), g["obs"][:, t], atol=1e-7)
         npt.assert_allclose(r.cpu().numpy(), g["reward"][:, t], rtol=1e-9, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------
+# lane-group ("radial") kernel family: same entry points, one wavefront lane per bus / device
+# ---------------------------------------------------------------------------------------------
+RADIAL_NETS = ["anm6", "2bus", "case30"]
+
+
+@pytest.mark.parametrize("name", RADIAL_NETS)
+def test_radial_transition_golden(name):
+    sim = pc.check_transition_against_golden(name, NETS[name], DEV, impl="radial")
+    assert sim.impl == "radial"
+
+
+@pytest.mark.parametrize("name", ["anm6", "case30"])
+def test_radial_transition_golden_f32_solve(name):
+    pc.check_transition_against_golden(name, NETS[name], DEV, precision="f32", atol=2e-6, check_iters=False, impl="radial")
+
+
+def test_radial_is_default_for_large_feeders_and_refused_for_meshed():
+    from gym_anm_amd import errors
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    assert BatchedSimulator(NETS["case30"], 0.25, 100, num_envs=4, device=DEV).impl == "radial"
+    assert BatchedSimulator(NETS["anm6"], 0.25, 100, num_envs=4, device=DEV).impl == "thread"
+    with pytest.raises(errors.HipExtensionError, match="radial"):
+        BatchedSimulator(NETS["3bus"], 0.5, 100, num_envs=4, device=DEV, impl="radial")
+
+
+def test_radial_anm6easy_episodes():
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    env = pc.run_episodes(lambda n: ANM6EasyVec(num_envs=n, device=DEV, impl="radial"))
+    assert env.simulator.impl == "radial"
+
+
+def test_radial_equals_thread_kernels_with_autoreset():
+    """Both kernel families on the same 8192 environments for 10 steps, in-kernel autoreset on:
+    same flags, same RNG draws, values within summation-order round-off."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 8192
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=5, autoreset=True, impl=i) for i in ("thread", "radial")]
+    for env in envs:
+        env.check_actions = False
+        env.reset(seed=5)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    lo = torch.as_tensor(envs[0].action_space.low, device=DEV)
+    hi = torch.as_tensor(envs[0].action_space.high, device=DEV)
+    for t in range(10):
+        a = lo + (hi - lo) * torch.rand((E_, 6), generator=gen, dtype=torch.float64, device=DEV)
+        outs = [env.step(a) for env in envs]
+        (o0, r0, t0, _, _), (o1, r1, t1, _, _) = outs
+        assert bool((t0 == t1).all())
+        npt.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=0, atol=1e-9)
+        npt.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=1e-10, atol=1e-9)
+        ok = ~t0
+        npt.assert_array_equal(envs[0].simulator.nr_iters[ok].cpu().numpy(), envs[1].simulator.nr_iters[ok].cpu().numpy())
+        npt.assert_array_equal(envs[0]._reset_count.cpu().numpy(), envs[1]._reset_count.cpu().numpy())
+        npt.assert_array_equal(envs[0].timestep.cpu().numpy(), envs[1].timestep.cpu().numpy())
+    assert int(envs[0]._reset_count.sum()) > 0
+
+
+def test_radial_reset_case30_matches_thread():
+    """Simulator-level reset + env-level reset of the 30-bus feeder through both families."""
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    class Env30(BatchedANMEnv):
+        def __init__(self, **kw):
+            super().__init__(NETS["case30"], "state", 0, 0.25, 0.995, 100, costs_clipping=(1, 100), **kw)
+
+        def next_vars(self, s_t):
+            return self._exo
+
+    rng = np.random.default_rng(3)
+    E_ = 512
+    envs = [Env30(num_envs=E_, device=DEV, impl=i) for i in ("thread", "radial")]
+    m = envs[0].simulator.model
+    b = m.baseMVA
+    s0 = np.zeros((E_, envs[0].state_N))
+    D = m.N_device
+    for k in range(D):
+        lo = m.dev_p_min[k] * b if np.isfinite(m.dev_p_min[k]) else -10
+        hi_ = m.dev_p_max[k] * b if np.isfinite(m.dev_p_max[k]) else 10
+        s0[:, k] = rng.uniform(lo, hi_, E_) * 0.5
+        s0[:, D + k] = rng.uniform(-1, 1, E_)
+    s0[:, 2 * D : 2 * D + m.N_des] = rng.uniform(0, 50, (E_, m.N_des))
+    s0[:, 2 * D + m.N_des :] = rng.uniform(0, 20, (E_, m.N_non_slack_gen))
+    obs = [env.reset(options={"init_state": s0})[0].cpu().numpy() for env in envs]
+    npt.assert_allclose(obs[1], obs[0], rtol=0, atol=1e-8)
+    npt.assert_array_equal(envs[0].pfe_converged.cpu().numpy(), envs[1].pfe_converged.cpu().numpy())
+    exo = torch.as_tensor(rng.uniform(-5, 5, (E_, m.N_load + m.N_non_slack_gen)), device=DEV)
+    lo_a, hi_a = m.action_bounds()
+    for t in range(3):
+        a = torch.as_tensor(rng.uniform(lo_a, hi_a, (E_, len(lo_a))), device=DEV)
+        outs = []
+        for env in envs:
+            env._exo = exo
+            env.check_actions = False
+            outs.append(env.step(a))
+        npt.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=1e-8)
+        npt.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=1e-9, atol=1e-8)
+        assert bool((outs[0][2] == outs[1][2]).all())
