@@ -85,6 +85,43 @@ def cpu_baseline(budget_s=12.0):
     }  # fmt: skip
 
 
+def case30_side_figure(dev, E=16384, n=20):
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    out = {}
+    for cap in (100, 20):
+        sim = BatchedSimulator(networks.synthetic_radial_network(30, 0), 0.25, 100, num_envs=E, device=dev,
+                               tol=1e-6, max_iter=cap)  # fmt: skip
+        m, b = sim.model, sim.model.baseMVA
+        g = torch.Generator(device=dev).manual_seed(0)
+
+        def U(lo, hi):
+            lo, hi = torch.as_tensor(lo, device=dev), torch.as_tensor(hi, device=dev)
+            return lo + (hi - lo) * torch.rand((E, lo.numel()), generator=g, dtype=torch.float64, device=dev)
+
+        pl = U(m.dev_p_min[m.load_idx] * b, 0 * m.dev_p_min[m.load_idx])
+        pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * b)
+        ps = U(m.dev_p_min[m.setp_idx] * b, m.dev_p_max[m.setp_idx] * b)
+        qs = U(m.dev_q_min[m.setp_idx] * b, m.dev_q_max[m.setp_idx] * b)
+        soc = U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx])
+        for _ in range(3):
+            sim.soc.copy_(soc)
+            sim.transition(pl, pp, ps, qs)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            sim.soc.copy_(soc)
+            sim.transition(pl, pp, ps, qs)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / n
+        out["case30_radial_16384_cap%d" % cap] = {
+            "env_steps_per_s": E / dt, "us_per_launch": dt * 1e6, "impl": sim.impl,
+            "converged_frac": float(sim.pfe_converged.double().mean()),
+        }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +231,15 @@ def main():
         alt = {"nr_max_iter": 20, "value_1gpu": E * args.steps / alt_elapsed, "ms_per_step": 1e3 * alt_elapsed / args.steps}
         sim.opts.max_iter = args.max_iter
 
+    # BASELINE.json config 4 as a side figure (not the headline): 30-bus radial feeder, 16384 envs,
+    # Simulator.transition with the full electrical-state dump, lane-group kernel family.
+    other = None
+    if rank == 0 and world == 1:
+        try:
+            other = case30_side_figure(dev)
+        except Exception as ex:  # never let the side figure break the headline line
+            other = {"error": str(ex)[:200]}
+
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(6, 18, 1, 1)
         achieved = bytes_per * E / kernel_s / 1e9
@@ -238,6 +284,8 @@ def main():
         }  # fmt: skip
         if alt is not None:
             out["config"]["alt_iteration_cap"] = alt
+        if other is not None:
+            out["config"]["other_workloads"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(out), flush=True)

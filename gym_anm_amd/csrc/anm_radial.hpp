@@ -40,7 +40,7 @@ constexpr int KMAX = 8;
 
 struct Dims {
   int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, max_depth, slack_dev;
-  int off_lists;                       // ints: [IF_COUNT][G] then child / bus-device lists
+  int off_lists, n_lists;              // ints: [IF_COUNT][G] then child / bus-device lists (n_lists <= 256)
   int off_lane, off_dev, off_obs_lo, off_obs_hi, n_double;  // doubles
   // offsets inside one row of the full-state dump (same order as FullState<T>)
   int f_bus_p, f_bus_q, f_bus_vm, f_bus_va, f_bus_im, f_bus_ia, f_dev_p, f_dev_q, f_des_soc, f_gen_pmax, f_br_p,
@@ -180,6 +180,8 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     I(IF_DEV_SET, k) = sset[k];
   }
   d.off_lists = int(P.hi.size());
+  d.n_lists = int(lists.size());
+  if (d.n_lists > 256) { err = "radial plan: index lists exceed the LDS table"; return false; }
   P.hi.insert(P.hi.end(), lists.begin(), lists.end());
   P.hi.push_back(0);
 
@@ -227,12 +229,26 @@ struct IO {
   EnvIO e;
 };
 
+// A workgroup is exactly one wavefront and a wavefront's LDS operations complete in program
+// order, so publishing values for the other lanes needs no s_barrier and no counter drain: only
+// the compiler must be kept from moving LDS accesses across the hand-over point.
+#define ANM_GROUP_SYNC()                                         \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+  } while (0)
+
 enum { A_VR = 0, A_VI, A_ER, A_EI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N };  // LDS arrays
 
+#ifndef ANM_RADIAL_WAVES
+#define ANM_RADIAL_WAVES 1
+#endif
 template <class JT>
-__global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ ri, const double* __restrict__ rd, IO io,
+__global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const int* __restrict__ ri, const double* __restrict__ rd, IO io,
                                               SolverOpts so, int64_t n_env) {
   __shared__ double sh[A_N][64];
+  __shared__ int sh_lists[256];  // children / bus-device index lists (read every Newton iteration)
   const int t = threadIdx.x;
   const int G = d.G;
   const int l = t & (G - 1);
@@ -250,7 +266,12 @@ __global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ r
   const int parent = RI(IF_PARENT), depth = RI(IF_DEPTH);
   const int ch_beg = RI(IF_CH_BEG), ch_end = RI(IF_CH_END);
   const int typ = RI(IF_DEV_TYPE), slot = RI(IF_DEV_SLOT), sset = RI(IF_DEV_SET);
-  const int* lists = ri + d.off_lists;
+  {
+    const int* glists = ri + d.off_lists;
+    for (int k = t; k < d.n_lists; k += 64) sh_lists[k] = glists[k];
+    ANM_GROUP_SYNC();
+  }
+  const int* lists = sh_lists;
   const int mode = io.mode;
   const int K = io.e.K;
   const int S = d.SDIM + K;
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ r
   }
   sh[A_S0][t] = dev_p;
   sh[A_S1][t] = dev_q;
-  __syncthreads();
+  ANM_GROUP_SYNC();
   double bus_p = 0.0, bus_q = 0.0;
   if (isbus)
     for (int k = RI(IF_BD_BEG); k < RI(IF_BD_END); ++k) {
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ r
       bus_p += sh[A_S0][gb + dd];
       bus_q += sh[A_S1][gb + dd];
     }
-  __syncthreads();
+  ANM_GROUP_SYNC();
 
   // ---------------- Newton-Raphson (lane = bus) ----------------------------------------------
   const double ybb_r = RD(DF_YBB_RE), ybb_i = RD(DF_YBB_IM), ybp_r = RD(DF_YBP_RE), ybp_i = RD(DF_YBP_IM);
@@ -386,7 +407,7 @@ __global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ r
     sh[A_VR][t] = vr; sh[A_VI][t] = vi; sh[A_ER][t] = er; sh[A_EI][t] = ei;
     sh[A_UPR][t] = ypb_r * vr - ypb_i * vi;
     sh[A_UPI][t] = ypb_r * vi + ypb_i * vr;
-    __syncthreads();
+    ANM_GROUP_SYNC();
     double epr = 1.0, epi = 0.0;
     vpr = 1.0; vpi = 0.0;
     if (parent >= 0) { vpr = sh[A_VR][pl]; vpi = sh[A_VI][pl]; epr = sh[A_ER][pl]; epi = sh[A_EI][pl]; }
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ r
     const bool was_active = active;
     active = (diff > so.tol) && (it < so.max_iter);
     (void)was_active;
-    __syncthreads();
+    ANM_GROUP_SYNC();
     if (!__any(active && env_ok && !skip)) break;
     // ---- Jacobian blocks: own diagonal, coupling with the parent (row b / col p and row p / col b)
     Blk<JT> Dg, Jbp, Jpb;
@@ -452,7 +473,7 @@ __global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ r
           sh[A_L1][t] = double(Lk.c * r0 + Lk.d * r1);
         }
       }
-      __syncthreads();
+      ANM_GROUP_SYNC();
     }
     // ---- back substitution, roots first (dx published in A_L0/A_L1)
     JT d0 = JT(0), d1 = JT(0);
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(64) void k_radial(Dims d, const int* __restrict__ r
         sh[A_UPR][t] = double(d0);
         sh[A_UPI][t] = double(d1);
       }
-      __syncthreads();
+      ANM_GROUP_SYNC();
     }
     // ---- update (group-uniform `active`)
     const double am = (active && isbus) ? 1.0 : 0.0;

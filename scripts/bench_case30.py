@@ -19,11 +19,15 @@ def inputs(sim, seed):
 def run(name, net, E, impl, prec="f64", n=30, full=True):
     sim = BatchedSimulator(net, 0.25, 100, num_envs=E, device=DEV, impl=impl, precision=prec)
     pl, pp, ps, qs, soc = inputs(sim, 0)
+    # the SoC is restored before every launch so that each launch does identical work (otherwise the
+    # storage units drift to their limits and the share of diverging solves changes from launch to launch)
     for _ in range(3):
+        sim.soc.copy_(soc)
         sim.transition(pl, pp, ps, qs)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(n):
+        sim.soc.copy_(soc)
         sim.transition(pl, pp, ps, qs)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
@@ -31,12 +35,13 @@ def run(name, net, E, impl, prec="f64", n=30, full=True):
     print("%-8s %-7s %s E=%-7d %9.1f us/launch  %.3e env-steps/s  converged %.4f  mean iters %.2f" % (
         name, impl, prec, E, dt * 1e6, E / dt, conv, float(sim.nr_iters.double().mean())))
 
-n30 = networks.synthetic_radial_network(30, 0)
-for E in (16384, 65536, 262144):
+if __name__ == '__main__':
+  n30 = networks.synthetic_radial_network(30, 0)
+  for E in (16384, 65536, 262144):
     run("case30", n30, E, "radial")
-run("case30", n30, 16384, "radial", "f32")
-run("case30", n30, 16384, "thread", n=5)
-a6 = networks.anm6_network()
-for E in (65536, 262144):
+  run("case30", n30, 16384, "radial", "f32")
+  run("case30", n30, 16384, "thread", n=5)
+  a6 = networks.anm6_network()
+  for E in (65536, 262144):
     run("anm6", a6, E, "radial")
     run("anm6", a6, E, "thread")

@@ -5,8 +5,9 @@ import torch
 from gym_anm_amd.envs import ANM6EasyVec
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 prec = sys.argv[2] if len(sys.argv) > 2 else "f64"
+impl = sys.argv[3] if len(sys.argv) > 3 else None
 for mi in (10, 60):
-    env = ANM6EasyVec(num_envs=E, device="cuda:0", seed=1, precision=prec)
+    env = ANM6EasyVec(num_envs=E, device="cuda:0", seed=1, precision=prec, impl=impl)
     env.check_actions = False
     env.reset(seed=1)
     env.simulator.opts.tol = 0.0
@@ -20,4 +21,4 @@ for mi in (10, 60):
     for _ in range(n):
         env.step(a); env._term_u8.zero_()
     torch.cuda.synchronize()
-    print(prec, E, "max_iter", mi, "us/step", (time.perf_counter() - t) / n * 1e6, "iters", int(env.simulator.nr_iters.max()))
+    print(impl, prec, E, "max_iter", mi, "us/step", (time.perf_counter() - t) / n * 1e6, "iters", int(env.simulator.nr_iters.max()))
