@@ -105,6 +105,7 @@ class Backend:
         self.lib = bind(cdll)
         self.device_type = device_type  # "cuda" for the product; the test double says "cpu"
         self.path = path
+        self.generic = False  # True: library compiled for another topology, lane-group kernel only
 
     def check(self, rc, what):
         if rc != 0:
@@ -118,12 +119,45 @@ class Backend:
 _CACHE = {}
 
 
-def load_for_topology(topo) -> Backend:
-    """Build (if needed) and load the gfx950 library specialised for ``topo``."""
+def _is_tree(topo) -> bool:
+    n_bus, branches, devices = topo
+    if len(branches) != n_bus - 1 or n_bus - 1 > 64 or len(devices) > 64:
+        return False
+    adj = {i: [] for i in range(n_bus)}
+    for f, t in branches:
+        adj[f].append(t)
+        adj[t].append(f)
+    seen, todo = {0}, [0]
+    while todo:
+        for v in adj[todo.pop()]:
+            if v not in seen:
+                seen.add(v)
+                todo.append(v)
+    return len(seen) == n_bus
+
+
+def load_for_topology(topo, impl=None) -> Backend:
+    """Load the gfx950 library that serves ``topo``.
+
+    * a library specialised for this topology (thread-per-environment kernels + the generic
+      lane-group kernel) when it exists or when it is worth building (networks up to 12 buses);
+    * otherwise, for radial networks, any already-built library in *generic* mode: the lane-group
+      kernel is table-driven and needs no per-topology compilation;
+    * otherwise build the specialised library with hipcc (meshed networks above 12 buses)."""
     name = codegen.topology_name(topo)
     if name in _CACHE:
         return _CACHE[name]
     path = codegen.lib_path(name)
+    if not os.path.exists(path) and _is_tree(topo) and (impl == "radial" or (impl is None and topo[0] > 12)):
+        for cand in sorted(os.listdir(codegen.BUILD_DIR)) if os.path.isdir(codegen.BUILD_DIR) else []:
+            if cand.startswith("libanm_") and cand.endswith(".so") and cand.count(".") == 1:
+                gpath = os.path.join(codegen.BUILD_DIR, cand)
+                try:
+                    be = Backend(C.CDLL(gpath), "cuda", gpath)
+                except OSError:
+                    continue
+                be.generic = True
+                return be
     if not os.path.exists(path):
         path = codegen.build_library(topo)  # raises HipExtensionError when hipcc is unavailable
     try:

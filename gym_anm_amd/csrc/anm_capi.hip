@@ -74,6 +74,7 @@ __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__
 
 struct anm_model {
   int impl = ANM_IMPL_THREAD;   // which kernel family serves this model
+  bool tpe_ok = false;          // the network has the topology this library was compiled for
   bool radial_ok = false;       // the network is a tree that fits one wavefront
   radial::Plan plan;            // per-lane tables of the lane-group kernel
   int* d_ri = nullptr;
@@ -90,8 +91,11 @@ struct anm_model {
 namespace {
 
 int upload_const(anm_model* m) {
-  hipError_t e = hipMemcpy(m->d_const, m->h_const.data(), m->h_const.size() * sizeof(double), hipMemcpyHostToDevice);
-  if (e != hipSuccess) return fail_hip(e, "hipMemcpy(constants)");
+  hipError_t e = hipSuccess;
+  if (m->tpe_ok) {
+    e = hipMemcpy(m->d_const, m->h_const.data(), m->h_const.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpy(constants)");
+  }
   if (m->radial_ok) {
     e = hipMemcpy(m->d_rd, m->plan.hd.data(), m->plan.hd.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail_hip(e, "hipMemcpy(radial tables)");
@@ -143,16 +147,14 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
   if (!desc || !out) return fail("anm_model_create: null argument");
   anm_model* m = new (std::nothrow) anm_model();
   if (!m) return fail("out of host memory");
-  std::string err;
-  if (!pack_constants<Topo>(*desc, m->h_const, m->ybus, err)) {
-    delete m;
-    g_err = err;
-    return -3;
-  }
-  hipError_t e = hipMalloc(&m->d_const, m->h_const.size() * sizeof(double));
-  if (e != hipSuccess) {
-    delete m;
-    return fail_hip(e, "hipMalloc(constants)");
+  std::string err, err_topo;
+  m->tpe_ok = pack_constants<Topo>(*desc, m->h_const, m->ybus, err_topo);
+  if (m->tpe_ok) {
+    hipError_t e = hipMalloc(&m->d_const, m->h_const.size() * sizeof(double));
+    if (e != hipSuccess) {
+      delete m;
+      return fail_hip(e, "hipMalloc(constants)");
+    }
   }
   if (radial::is_radial(*desc) && radial::build_plan(*desc, m->plan, err)) {
     hipError_t e1 = hipMalloc(&m->d_ri, m->plan.hi.size() * sizeof(int));
@@ -162,16 +164,36 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
       m->radial_ok = true;
       // default: the lane-group kernel once the thread-per-environment working set no longer fits
       // in registers (measured: a 30-bus feeder spills 4.7 KB/lane); ANM_IMPL=thread|radial overrides
-      m->impl = (Topo::NB > 12) ? ANM_IMPL_RADIAL : ANM_IMPL_THREAD;
+      m->impl = (!m->tpe_ok || desc->n_bus > 12) ? ANM_IMPL_RADIAL : ANM_IMPL_THREAD;
       const char* ev = getenv("ANM_IMPL");
-      if (ev && std::string(ev) == "thread") m->impl = ANM_IMPL_THREAD;
+      if (ev && std::string(ev) == "thread" && m->tpe_ok) m->impl = ANM_IMPL_THREAD;
       if (ev && std::string(ev) == "radial") m->impl = ANM_IMPL_RADIAL;
+    }
+  }
+  if (!m->tpe_ok && !m->radial_ok) {
+    // neither the compiled topology nor a tree the generic lane-group kernel can take
+    if (m->d_ri) hipFree(m->d_ri);
+    if (m->d_rd) hipFree(m->d_rd);
+    delete m;
+    g_err = err_topo;
+    return -3;
+  }
+  if (!m->tpe_ok) {  // generic (radial-only) model: dense Y_bus for diagnostics
+    const int NB = desc->n_bus;
+    m->ybus.assign(size_t(NB) * NB, cplx(0, 0));
+    for (int b = 0; b < desc->n_branch; ++b) {
+      const int f = desc->br_from[b], t = desc->br_to[b];
+      const cplx ys(desc->br_series[2 * b], desc->br_series[2 * b + 1]), sh(desc->br_shunt[2 * b], desc->br_shunt[2 * b + 1]);
+      const cplx tap(desc->br_tap[2 * b], desc->br_tap[2 * b + 1]);
+      m->ybus[f * NB + t] = -ys / std::conj(tap);
+      m->ybus[t * NB + f] = -ys / tap;
+      m->ybus[f * NB + f] += (ys + sh) / (std::abs(tap) * std::abs(tap));
+      m->ybus[t * NB + t] += ys + sh;
     }
   }
   int rc = upload_const(m);
   if (rc) {
-    hipFree(m->d_const);
-    delete m;
+    anm_model_destroy(m);
     return rc;
   }
   *out = m;
@@ -189,6 +211,13 @@ void anm_model_destroy(anm_model* m) {
 
 int anm_model_dims(const anm_model* m, anm_dims* out) {
   if (!m || !out) return fail("anm_model_dims: null argument");
+  if (!m->tpe_ok) {
+    const radial::Dims& d = m->plan.d;
+    out->n_bus = d.NB; out->n_dev = d.ND; out->n_branch = d.NBR; out->n_load = d.NLOAD; out->n_gen = d.NGEN;
+    out->n_des = d.NDES; out->action_dim = 2 * (d.NGEN + d.NDES); out->state_base_dim = d.SDIM;
+    out->full_dim = d.FS; out->const_doubles = d.n_double;
+    return 0;
+  }
   out->n_bus = Topo::NB;
   out->n_dev = Topo::ND;
   out->n_branch = Topo::NBR;
@@ -204,6 +233,14 @@ int anm_model_dims(const anm_model* m, anm_dims* out) {
 
 int anm_model_full_layout(const anm_model* m, anm_full_layout* o) {
   if (!m || !o) return fail("anm_model_full_layout: null argument");
+  if (!m->tpe_ok) {
+    const radial::Dims& d = m->plan.d;
+    o->bus_p = d.f_bus_p; o->bus_q = d.f_bus_q; o->bus_v_magn = d.f_bus_vm; o->bus_v_ang = d.f_bus_va;
+    o->bus_i_magn = d.f_bus_im; o->bus_i_ang = d.f_bus_ia; o->dev_p = d.f_dev_p; o->dev_q = d.f_dev_q;
+    o->des_soc = d.f_des_soc; o->gen_p_max = d.f_gen_pmax; o->branch_p = d.f_br_p; o->branch_q = d.f_br_q;
+    o->branch_s = d.f_br_s; o->branch_i_magn = d.f_br_im; o->branch_i_ang = d.f_br_ia; o->size = d.FS;
+    return 0;
+  }
   typedef FullState<Topo> F;
   o->bus_p = F::BUS_P; o->bus_q = F::BUS_Q; o->bus_v_magn = F::BUS_VM; o->bus_v_ang = F::BUS_VA;
   o->bus_i_magn = F::BUS_IM; o->bus_i_ang = F::BUS_IA; o->dev_p = F::DEV_P; o->dev_q = F::DEV_Q;
@@ -215,7 +252,8 @@ int anm_model_full_layout(const anm_model* m, anm_full_layout* o) {
 int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   if (!m || !cfg) return fail("anm_model_set_env: null argument");
   std::string err;
-  if (!pack_env<Topo>(*cfg, m->h_const, err)) {
+  if (cfg->K < 0 || cfg->K > radial::KMAX) return fail("K (number of aux variables) must be in [0, 8]");
+  if (m->tpe_ok && !pack_env<Topo>(*cfg, m->h_const, err)) {
     g_err = err;
     return -3;
   }
@@ -238,7 +276,8 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   m->period = 0;
   if (cfg->series && cfg->period > 0) {
     if (cfg->K != 1) return fail("series mode needs exactly K = 1 auxiliary variable (the time index)");
-    const size_t bytes = sizeof(double) * size_t(Dims<Topo>::NEXO) * size_t(cfg->period);
+    const size_t nexo = m->tpe_ok ? size_t(Dims<Topo>::NEXO) : size_t(m->plan.d.NLOAD + m->plan.d.NGEN);
+    const size_t bytes = sizeof(double) * nexo * size_t(cfg->period);
     hipError_t e = hipMalloc(&m->d_series, bytes ? bytes : 8);
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(series)");
     e = hipMemcpy(m->d_series, cfg->series, bytes, hipMemcpyHostToDevice);
@@ -254,6 +293,8 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
   if (impl == ANM_IMPL_RADIAL && !m->radial_ok)
     return fail("the lane-group kernel needs a radial (tree) network with at most 64 buses and devices");
   if (impl != ANM_IMPL_THREAD && impl != ANM_IMPL_RADIAL) return fail("anm_model_set_impl: unknown implementation");
+  if (impl == ANM_IMPL_THREAD && !m->tpe_ok)
+    return fail("this library was compiled for another topology: only the generic lane-group kernel is available");
   m->impl = impl;
   return 0;
 }
@@ -342,7 +383,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
   if (!action || !state || !terminated || !obs || !reward || !e_loss || !penalty)
     return fail("anm_step_f64: null argument");
-  if (Topo::NDES > 0 && !soc) return fail("anm_step_f64: null soc");
+  if ((m->tpe_ok ? Topo::NDES : m->plan.d.NDES) > 0 && !soc) return fail("anm_step_f64: null soc");
   const bool series = exo == nullptr;
   if (series && m->period <= 0) return fail("anm_step_f64: no exo given and the model has no series (set_env)");
   if (!series && m->K > 0 && !aux_next) return fail("anm_step_f64: exo given without aux_next");

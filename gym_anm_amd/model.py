@@ -93,7 +93,9 @@ def _check_case(network):
 class NetworkModel:
     """Flat constants of one network (all arrays ordered like the reference orders its dicts)."""
 
-    def __init__(self, network: dict, delta_t: float, lamb: float):
+    def __init__(self, network: dict, delta_t: float, lamb: float, require_solvable: bool = True):
+        """``require_solvable=False`` only parses and builds the constants (what the reference's
+        ``Simulator.__init__`` does); the default also checks what its power-flow solver assumes."""
         _check_case(network)
         self.baseMVA = network["baseMVA"]
         self.delta_t = delta_t
@@ -101,7 +103,11 @@ class NetworkModel:
         self._parse_buses(network["bus"])
         self._parse_branches(network["branch"])
         self._parse_devices(network["device"])
-        self._require_solver_assumptions()
+        self.br_f = np.array([self.bus_index[b] for b in self.br_f_id], dtype=np.int32)
+        self.br_t = np.array([self.bus_index[b] for b in self.br_t_id], dtype=np.int32)
+        self.dev_bus = np.array([self.bus_index[b] for b in self.dev_bus_id], dtype=np.int32)
+        if require_solvable:
+            self.require_solver_assumptions()
         self._build_ybus()
         self._bus_bounds()
 
@@ -371,7 +377,7 @@ class NetworkModel:
         d.update(soc_min=soc_min, soc_max=soc_max, eff=eff)
 
     # -- what the reference's power-flow solver silently assumes ------------------------------
-    def _require_solver_assumptions(self):
+    def require_solver_assumptions(self):
         if self.bus_ids != list(range(self.N_bus)):
             raise E.UnsupportedNetworkError(
                 "bus IDs must be 0..N-1 (got %s): the reference's Newton-Raphson indexes Y_bus by bus ID "
@@ -382,9 +388,6 @@ class NetworkModel:
                 "the slack bus must have the smallest bus ID: the reference's Newton-Raphson pins the first bus "
                 "to 1+0j whatever its type (solve_load_flow.py:116,157-160,171)."
             )
-        self.br_f = np.array([self.bus_index[b] for b in self.br_f_id], dtype=np.int32)
-        self.br_t = np.array([self.bus_index[b] for b in self.br_t_id], dtype=np.int32)
-        self.dev_bus = np.array([self.bus_index[b] for b in self.dev_bus_id], dtype=np.int32)
 
     def _build_ybus(self):  # simulator.py:183-199
         n = self.N_bus

@@ -86,7 +86,7 @@ class BatchedSimulator:
         self.state = None
         self.pfe_converged = None
 
-        self.backend = _backend if _backend is not None else _lib.load_for_topology(m.topology())
+        self.backend = _backend if _backend is not None else _lib.load_for_topology(m.topology(), impl)
         self.device = torch.device(device)
         if self.backend.device_type == "cuda":
             if not torch.cuda.is_available() or self.backend.lib.anm_device_count() < 1:

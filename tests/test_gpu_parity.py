@@ -400,3 +400,94 @@ def test_radial_reset_case30_matches_thread():
         npt.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=1e-8)
         npt.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=1e-9, atol=1e-8)
         assert bool((outs[0][2] == outs[1][2]).all())
+
+
+# ---------------------------------------------------------------------------------------------
+# randomised topologies: oracle on the same seeded inputs
+# ---------------------------------------------------------------------------------------------
+def _random_inputs(sim, seed):
+    m, b, E_ = sim.model, sim.model.baseMVA, sim.num_envs
+    rng = np.random.default_rng(seed)
+
+    def U(lo, hi, wild=1.0):
+        lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+        c, h = 0.5 * (lo + hi), 0.5 * (hi - lo) * wild
+        return rng.uniform(c - h, c + h, size=(E_, len(lo)))
+
+    pl = U(m.dev_p_min[m.load_idx] * b * 0.6, 0 * m.dev_p_min[m.load_idx])
+    pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * b, 1.2)
+    ps = U(m.dev_p_min[m.setp_idx] * b, m.dev_p_max[m.setp_idx] * b, 1.3)
+    qs = U(m.dev_q_min[m.setp_idx] * b, m.dev_q_max[m.setp_idx] * b, 1.3)
+    soc = U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx])
+    return pl, pp, ps, qs, soc
+
+
+def _compare_with_oracle(sim, net, inputs, n_check):
+    import anm_oracle as O
+
+    pl, pp, ps, qs, soc = inputs
+    sim.soc.copy_(torch.as_tensor(soc))
+    st, r, e, p, conv = sim.transition(pl, pp, ps, qs)
+    full = sim.full.cpu().numpy()
+    sl = pc.full_slices(sim)
+    n = O.parse_network(net, sim.delta_t, sim.lamb)
+    n_conv = 0
+    for k in range(n_check):
+        out = O.transition(n, pl[k], pp[k], ps[k], qs[k], soc[k], sparse=False)
+        assert out["converged"] == bool(conv[k]), k
+        npt.assert_allclose(full[k, sl["dev_p"]][1:], out["dev_p"][1:], rtol=0, atol=1e-12)
+        npt.assert_allclose(sim.soc[k].cpu().numpy(), out["soc_after"], rtol=0, atol=1e-12)
+        if not out["converged"]:
+            continue
+        n_conv += 1
+        assert int(sim.nr_iters[k]) == out["n_iter"], k
+        npt.assert_allclose(full[k, sl["bus_v_magn"]], np.abs(out["V"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[k, sl["bus_v_ang"]], np.angle(out["V"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[k, sl["branch_s"]], out["br_s"], rtol=0, atol=1e-9)
+        npt.assert_allclose(full[k, sl["dev_p"]], out["dev_p"], rtol=0, atol=1e-9)
+        npt.assert_allclose(float(r[k]), out["reward"], rtol=1e-9, atol=1e-8)
+    return n_conv
+
+
+@pytest.mark.parametrize("n_bus,seed", [(3, 1), (5, 2), (9, 3), (17, 4), (33, 5), (48, 6), (64, 7)])
+def test_random_radial_networks_generic_lane_group_kernel(n_bus, seed):
+    """Arbitrary radial networks need no per-topology build: the table-driven lane-group kernel of
+    any already-built library serves them (G = 8 .. 64 lanes per environment)."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    net = networks.synthetic_radial_network(n_bus, seed)
+    E_ = 200
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=E_, device=DEV, impl="radial")
+    assert sim.impl == "radial"
+    npt.assert_allclose(sim.device_ybus(), sim.model.Y_bus, rtol=1e-15, atol=0)
+    n_conv = _compare_with_oracle(sim, net, _random_inputs(sim, seed), 40)
+    assert n_conv >= 20
+
+
+@pytest.mark.parametrize("n_bus,seed", [(4, 11), (7, 12)])
+def test_new_topology_is_compiled_on_first_use(n_bus, seed):
+    """A topology without a prebuilt library is specialised with hipcc on first use
+    (thread-per-environment kernels) and agrees with the oracle and with the lane-group kernel."""
+    from gym_anm_amd import codegen, networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    if codegen.hipcc_path() is None:
+        pytest.skip("hipcc not available on this box")
+    net = networks.synthetic_radial_network(n_bus, seed)
+    E_ = 128
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=E_, device=DEV, impl="thread")
+    assert sim.impl == "thread" and not sim.backend.generic
+    inputs = _random_inputs(sim, seed)
+    _compare_with_oracle(sim, net, inputs, 30)
+    sim2 = BatchedSimulator(net, 0.25, 100, num_envs=E_, device=DEV, impl="radial")
+    sim2.soc.copy_(torch.as_tensor(inputs[4]))
+    sim2.transition(*inputs[:4])
+    ok = (sim.pfe_converged & sim2.pfe_converged).cpu().numpy()
+    assert bool((sim.pfe_converged == sim2.pfe_converged).all())
+    sl = pc.full_slices(sim)
+    f1, f2 = sim.full.cpu().numpy()[ok], sim2.full.cpu().numpy()[ok]
+    for key in sl:
+        if key.endswith("_i_ang"):  # the angle of a ~zero current is ill-conditioned
+            continue
+        npt.assert_allclose(f2[:, sl[key]], f1[:, sl[key]], rtol=0, atol=1e-9, err_msg=key)
