@@ -147,7 +147,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -207,7 +207,8 @@ def main():
         rc = sim.backend.lib.anm_time_step_launches(
             sim._handle, E, pool[0].data_ptr(), sim.soc.data_ptr(), env.state.data_ptr(), env._term_u8.data_ptr(),
             env.timestep.data_ptr(), env._state_obs.data_ptr(), env.reward.data_ptr(), env.e_loss.data_ptr(),
-            env.penalty.data_ptr(), 1, env.rng_seed, env.env_offset, env._reset_count.data_ptr(), C.byref(sim.opts), stream,
+            env.penalty.data_ptr(), 1, env.rng_seed, env.env_offset, env._reset_count.data_ptr(), env._aux_index_ptr,
+            C.byref(sim.opts), stream,
             n_launch, C.byref(ms),
         )  # fmt: skip
     sim.backend.check(rc, "anm_time_step_launches")

@@ -57,6 +57,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(cptr_t C, EnvIO io, SolverOpts s
   op_step<Topo, JT>(C, io, so, e);
 }
 
+// coalesced-row variant of k_step (series mode, K = 1, no full dump): see op_step_rows
+template <class JT>
+__global__ __launch_bounds__(BLOCK) void k_step_rows(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+  __shared__ double lds[64 * (Topo::SDIM + 2)];
+  op_step_rows<Topo, JT>(C, io, so, n, lds);
+}
+
 __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__ full, int n_obs,
                              const int32_t* __restrict__ index, const double* __restrict__ scale,
                              const double* __restrict__ low, const double* __restrict__ high,
@@ -339,7 +346,7 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
 
 int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, double* soc, double* state,
                   double* obs, uint8_t* converged, uint8_t* terminated, int32_t* timestep, int32_t* nr_iters,
-                  double* full, const anm_solver_opts* opts, void* stream) {
+                  double* full, int32_t* aux_index, const anm_solver_opts* opts, void* stream) {
   if (!m) return fail("anm_reset_f64: null model");
   if (!m->env_set) return fail("anm_reset_f64: call anm_model_set_env first");
   if (n <= 0) return 0;
@@ -356,6 +363,7 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
   io.timestep = timestep;
   io.nr_iters = nr_iters;
   io.full = full;
+  io.aux_index = aux_index;
   int prec;
   SolverOpts so = solver(opts, prec);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -378,7 +386,7 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
 static int make_step_io(anm_model* m, const double* action, const double* exo, const double* aux_next, double* soc,
                         double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                         double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                        uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, EnvIO& io) {
+                        uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, EnvIO& io) {
   if (!m) return fail("anm_step_f64: null model");
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
   if (!action || !state || !terminated || !obs || !reward || !e_loss || !penalty)
@@ -409,6 +417,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   io.rng_seed = rng_seed;
   io.env_offset = env_offset;
   io.reset_count = reset_count;
+  io.aux_index = aux_index;
   return 0;
 }
 
@@ -422,6 +431,15 @@ static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solve
     return launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
+  if (io.aux_index && io.exo == nullptr && io.K == 1 && io.full == nullptr) {
+    if (prec == ANM_SOLVE_F32)
+      hipLaunchKernelGGL(k_step_rows<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    else
+      hipLaunchKernelGGL(k_step_rows<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_rows");
+    return 0;
+  }
   if (prec == ANM_SOLVE_F32)
     hipLaunchKernelGGL(k_step<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
   else
@@ -434,10 +452,11 @@ static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solve
 int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
                  double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                  double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, const anm_solver_opts* opts, void* stream) {
+                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_solver_opts* opts,
+                 void* stream) {
   EnvIO io;
   int rc = make_step_io(m, action, exo, aux_next, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
-                        nr_iters, full, autoreset, rng_seed, env_offset, reset_count, io);
+                        nr_iters, full, autoreset, rng_seed, env_offset, reset_count, aux_index, io);
   if (rc) return rc;
   if (n <= 0) return 0;
   return launch_step(m, io, n, opts, static_cast<hipStream_t>(stream));
@@ -446,10 +465,10 @@ int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* ex
 int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double* soc, double* state,
                            uint8_t* terminated, int32_t* timestep, double* obs, double* reward, double* e_loss,
                            double* penalty, int32_t autoreset, uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count,
-                           const anm_solver_opts* opts, void* stream, int32_t n_launch, float* ms_per_launch) {
+                           int32_t* aux_index, const anm_solver_opts* opts, void* stream, int32_t n_launch, float* ms_per_launch) {
   EnvIO io;
   int rc = make_step_io(m, action, nullptr, nullptr, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
-                        nullptr, nullptr, autoreset, rng_seed, env_offset, reset_count, io);
+                        nullptr, nullptr, autoreset, rng_seed, env_offset, reset_count, aux_index, io);
   if (rc) return rc;
   if (n <= 0 || n_launch <= 0 || !ms_per_launch) return fail("anm_time_step_launches: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -101,6 +101,7 @@ struct EnvIO {
   uint64_t rng_seed;
   uint64_t env_offset;      // global index of environment 0 of this batch (RNG key)
   int32_t* reset_count;     // [E] (autoreset)
+  int32_t* aux_index;       // [E] series mode: compact copy of the time index (optional)
 };
 
 // Split an init_state row (anm_env.py / simulator.py:248-268) into transition inputs.
@@ -131,7 +132,7 @@ ANM_HD void inputs_from_init_state(cptr_t C, const double* s0, EnvWork<T>& w,
 }
 
 // Tail of Simulator.reset / ANMEnv.reset: SoC overwritten with the requested one, state & obs built.
-template <class T>
+template <class T, int KCAP = Layout<T>::KMAX>
 ANM_HD void finish_reset(cptr_t C, EnvWork<T>& w, const double* s0, int K, double* soc, double* state,
                          double* obs) {
   typedef Layout<T> L;
@@ -141,11 +142,15 @@ ANM_HD void finish_reset(cptr_t C, EnvWork<T>& w, const double* s0, int K, doubl
     soc[E] = w.soc[E];
   });
   write_state_obs<T>(C, w, state, obs);
-  for (int k = 0; k < K; ++k) {
-    const double a = s0[T::SDIM + k];
-    state[T::SDIM + k] = a;
-    obs[T::SDIM + k] = fmin(fmax(a, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]);
-  }
+  // constant indices + predicate (not a runtime-indexed loop): callers keep these rows in registers
+  static_for<0, KCAP>([&](auto Kc) {
+    constexpr int k = Kc;
+    if (k < K) {
+      const double a = s0[T::SDIM + k];
+      state[T::SDIM + k] = a;
+      obs[T::SDIM + k] = fmin(fmax(a, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]);
+    }
+  });
 }
 
 template <class T, class JT>
@@ -163,29 +168,61 @@ ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   io.terminated[e] = 0;
   if (io.timestep) io.timestep[e] = 0;
   if (io.nr_iters) io.nr_iters[e] = w.n_iter;
+  if (io.aux_index && io.K == 1) io.aux_index[e] = int32_t(s0[T::SDIM]);
   if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
 }
 
-template <class T, class JT>
-ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
+// ---------------------------------------------------------------------------------------------
+// ANMEnv.step for ONE environment, as a pure function of its inputs (StepIn -> StepOut); the two
+// I/O layers below (plain per-environment loads/stores, and wave-cooperative coalesced rows on the
+// GPU) share it.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct StepIn {
+  bool was_term;
+  double action[Dims<T>::ADIM > 0 ? Dims<T>::ADIM : 1];
+  double exo[Dims<T>::NEXO > 0 ? Dims<T>::NEXO : 1];   // generic mode only
+  double soc[T::NDES > 0 ? T::NDES : 1];
+  double aux_prev;                                       // series mode: time index before the step
+  int reset_count;
+};
+
+template <class T, int KCAP = Layout<T>::KMAX>  // KCAP: compile-time cap on the number of aux variables
+struct StepOut {
+  double state[T::SDIM + KCAP], obs[T::SDIM + KCAP];
+  bool write_state, write_obs;     // absorbing terminal state: only the (zero) observation is written
+  double reward, e_loss, penalty;
+  bool write_costs;                // e_loss / penalty are left untouched in the absorbing state
+  int terminated;                  // -1: leave as is
+  int timestep_op;                 // 0 leave, 1 set to 0, 2 increment
+  int n_iter;
+  double soc[T::NDES > 0 ? T::NDES : 1];
+  bool write_soc;
+  bool inc_reset;
+  int aux;
+};
+
+template <class T, class JT, int KCAP>
+ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepIn<T>& in,
+                         StepOut<T, KCAP>& out, EnvWork<T>& w) {
   typedef Layout<T> L;
   typedef Dims<T> D;
-  const int S = T::SDIM + io.K;
-  double* state = io.state + e * S;
-  double* obs = io.obs + e * S;
-  const bool was_term = io.terminated[e] != 0;
   const bool series = io.exo == nullptr;
-  const bool resetting = was_term && io.autoreset && series;
+  const bool resetting = in.was_term && io.autoreset && series;
   ANM_PHASE(0);
+  out.write_state = out.write_obs = out.write_costs = out.write_soc = out.inc_reset = false;
+  out.terminated = -1;
+  out.timestep_op = 0;
+  out.n_iter = 0;
+  out.aux = 0;
+  out.reward = out.e_loss = out.penalty = 0.0;
 
-  if (was_term && !resetting) {  // absorbing terminal state (anm_env.py:365-367)
-    for (int k = 0; k < S; ++k) obs[k] = 0.0;
-    io.reward[e] = 0.0;
-    if (io.nr_iters) io.nr_iters[e] = 0;
+  if (in.was_term && !resetting) {  // absorbing terminal state (anm_env.py:365-367)
+    static_for<0, T::SDIM + KCAP>([&](auto Kc) { out.obs[Kc] = 0.0; });
+    out.write_obs = true;
     return;
   }
 
-  EnvWork<T> w;
   double P_load[T::NLOAD > 0 ? T::NLOAD : 1], P_pot[T::NGEN > 0 ? T::NGEN : 1];
   double P_set[T::NSET > 0 ? T::NSET : 1], Q_set[T::NSET > 0 ? T::NSET : 1];
   double s0[T::SDIM + 1];  // sampled initial state (autoreset only; K == 1 in series mode)
@@ -193,7 +230,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
 
   if (resetting) {
     // ANM6Easy.init_state (anm6_easy.py:25-52) with a counter-based RNG
-    const uint32_t epoch = uint32_t(io.reset_count[e]);
+    const uint32_t epoch = uint32_t(in.reset_count);
     uint32_t r[4];
     Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 0u, r);
     aux = int((uint64_t(r[0]) * uint64_t(io.period)) >> 32);
@@ -228,82 +265,202 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   } else {
     // 1. exogenous variables (next_vars, anm6_easy.py:54-65 in series mode)
     if (series) {
-      const double a = state[T::SDIM];
-      aux = int(fmod(a + 1.0, double(io.period)));
+      aux = int(fmod(in.aux_prev + 1.0, double(io.period)));
       static_for<0, T::NLOAD>([&](auto I) { P_load[I] = io.series[I * io.period + aux]; });
       static_for<0, T::NGEN>([&](auto I) { P_pot[I] = io.series[(T::NLOAD + I) * io.period + aux]; });
     } else {
-      static_for<0, T::NLOAD>([&](auto I) { P_load[I] = io.exo[e * D::NEXO + I]; });
-      static_for<0, T::NGEN>([&](auto I) { P_pot[I] = io.exo[e * D::NEXO + T::NLOAD + I]; });
+      static_for<0, T::NLOAD>([&](auto I) { P_load[I] = in.exo[I]; });
+      static_for<0, T::NGEN>([&](auto I) { P_pot[I] = in.exo[T::NLOAD + I]; });
     }
     // 2. action layout [P_gen.., Q_gen.., P_des.., Q_des..] by ascending device id (anm_env.py:393-410)
-    const double* a = io.action + e * D::ADIM;
     static_for<0, T::ND>([&](auto Di) {
       constexpr int d = Di;
       constexpr int typ = T::DEV_TYPE[d];
       if constexpr (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
-        P_set[T::DEV_SET[d]] = a[T::DEV_SLOT[d]];
-        Q_set[T::DEV_SET[d]] = a[T::NGEN + T::DEV_SLOT[d]];
+        P_set[T::DEV_SET[d]] = in.action[T::DEV_SLOT[d]];
+        Q_set[T::DEV_SET[d]] = in.action[T::NGEN + T::DEV_SLOT[d]];
       } else if constexpr (typ == DEV_STORAGE) {
-        P_set[T::DEV_SET[d]] = a[2 * T::NGEN + T::DEV_SLOT[d]];
-        Q_set[T::DEV_SET[d]] = a[2 * T::NGEN + T::NDES + T::DEV_SLOT[d]];
+        P_set[T::DEV_SET[d]] = in.action[2 * T::NGEN + T::DEV_SLOT[d]];
+        Q_set[T::DEV_SET[d]] = in.action[2 * T::NGEN + T::NDES + T::DEV_SLOT[d]];
       }
     });
-    static_for<0, T::NDES>([&](auto I) { w.soc[I] = io.soc[e * T::NDES + I]; });
+    static_for<0, T::NDES>([&](auto I) { w.soc[I] = in.soc[I]; });
   }
+  out.aux = aux;
 
   // 3. one simulator transition, shared by the step and the autoreset path
   ANM_PHASE(1);
   transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
-  if (io.nr_iters) io.nr_iters[e] = w.n_iter;
+  out.n_iter = w.n_iter;
+  out.write_soc = true;
+  out.write_state = out.write_obs = true;
 
   if (resetting) {
-    finish_reset<T>(C, w, s0, 1, io.soc + e * T::NDES, state, obs);
-    io.reset_count[e] += 1;
-    io.terminated[e] = w.converged ? 0 : 1;  // not converged: try another draw at the next call
-    if (io.timestep) io.timestep[e] = 0;
-    io.reward[e] = 0.0;
-    io.e_loss[e] = 0.0;
-    io.penalty[e] = 0.0;
-    if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+    finish_reset<T, 1>(C, w, s0, 1, out.soc, out.state, out.obs);
+    out.inc_reset = true;
+    out.terminated = w.converged ? 0 : 1;  // not converged: try another draw at the next call
+    out.timestep_op = 1;
+    out.write_costs = true;  // reward = e_loss = penalty = 0
     return;
   }
 
-  static_for<0, T::NDES>([&](auto I) { io.soc[e * T::NDES + I] = w.soc[I]; });
+  static_for<0, T::NDES>([&](auto I) { out.soc[I] = w.soc[I]; });
   const bool term = !w.converged;
-  io.terminated[e] = term ? 1 : 0;
+  out.terminated = term ? 1 : 0;
+  out.write_costs = true;
   const double c1 = C[L::SCALARS + SC_C1], c2 = C[L::SCALARS + SC_C2];
   if (!term) {
     // reward clipping (anm_env.py:423-427)
     const double sg = (w.e_loss > 0.0) ? 1.0 : ((w.e_loss < 0.0) ? -1.0 : 0.0);
     const double el = sg * fmin(fabs(w.e_loss), c1);
     const double pn = fmin(fmax(w.penalty, 0.0), c2);
-    io.e_loss[e] = el;
-    io.penalty[e] = pn;
-    io.reward[e] = -(el + pn);
-    write_state_obs<T>(C, w, state, obs);
+    out.e_loss = el;
+    out.penalty = pn;
+    out.reward = -(el + pn);
+    write_state_obs<T>(C, w, out.state, out.obs);
     if (series) {
-      state[T::SDIM] = double(aux);
-      obs[T::SDIM] = fmin(fmax(double(aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]);
+      out.state[T::SDIM] = double(aux);
+      out.obs[T::SDIM] = fmin(fmax(double(aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]);
     } else {
-      for (int k = 0; k < io.K; ++k) {
-        const double v = io.aux_next[e * io.K + k];
-        state[T::SDIM + k] = v;
-        obs[T::SDIM + k] = fmin(fmax(v, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]);
-      }
+      static_for<0, KCAP>([&](auto Kc) {
+        constexpr int k = Kc;
+        if (k < io.K) {
+          const double v = io.aux_next[e * io.K + k];
+          out.state[T::SDIM + k] = v;
+          out.obs[T::SDIM + k] = fmin(fmax(v, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]);
+        }
+      });
     }
   } else {
-    io.reward[e] = C[L::SCALARS + SC_RTERM];  // -c2 / (1 - gamma)
-    io.e_loss[e] = c1;
-    io.penalty[e] = c2;
-    for (int k = 0; k < S; ++k) {
-      state[k] = 0.0;
-      obs[k] = 0.0;
-    }
+    out.reward = C[L::SCALARS + SC_RTERM];  // -c2 / (1 - gamma)
+    out.e_loss = c1;
+    out.penalty = c2;
+    static_for<0, T::SDIM + KCAP>([&](auto Kc) {
+      out.state[Kc] = 0.0;
+      out.obs[Kc] = 0.0;
+    });
   }
-  if (io.timestep) io.timestep[e] += 1;
-  if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+  out.timestep_op = 2;
+}
+
+// everything of StepOut except the state / obs rows
+template <class T, int KCAP>
+ANM_HD void store_step_scalars(const EnvIO& io, int64_t e, const StepOut<T, KCAP>& o) {
+  if (o.write_soc) static_for<0, T::NDES>([&](auto I) { io.soc[e * T::NDES + I] = o.soc[I]; });
+  if (o.terminated >= 0) io.terminated[e] = uint8_t(o.terminated);
+  io.reward[e] = o.reward;
+  if (o.write_costs) {
+    io.e_loss[e] = o.e_loss;
+    io.penalty[e] = o.penalty;
+  }
+  if (io.nr_iters) io.nr_iters[e] = o.n_iter;
+  if (io.timestep) {
+    if (o.timestep_op == 1) io.timestep[e] = 0;
+    else if (o.timestep_op == 2) io.timestep[e] += 1;
+  }
+  if (o.inc_reset) io.reset_count[e] += 1;
+}
+
+// I/O layer 1: plain per-environment loads and stores (host test double, generic mode, `full` dumps)
+template <class T, class JT>
+ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
+  typedef Dims<T> D;
+  const int S = T::SDIM + io.K;
+  StepIn<T> in;
+  StepOut<T> out;
+  EnvWork<T> w;
+  in.was_term = io.terminated[e] != 0;
+  static_for<0, D::ADIM>([&](auto I) { in.action[I] = io.action[e * D::ADIM + I]; });
+  if (io.exo) static_for<0, D::NEXO>([&](auto I) { in.exo[I] = io.exo[e * D::NEXO + I]; });
+  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[e * T::NDES + I]; });
+  in.aux_prev = io.exo ? 0.0 : io.state[e * S + T::SDIM];
+  in.reset_count = (io.autoreset && io.reset_count) ? io.reset_count[e] : 0;
+  step_compute<T, JT, Layout<T>::KMAX>(C, io, so, e, in, out, w);
+  double* state = io.state + e * S;
+  double* obs = io.obs + e * S;
+  static_for<0, T::SDIM + Layout<T>::KMAX>([&](auto Kc) {
+    constexpr int k = Kc;
+    if (k < S) {
+      if (out.write_state) state[k] = out.state[k];
+      if (out.write_obs) obs[k] = out.obs[k];
+    }
+  });
+  store_step_scalars<T, Layout<T>::KMAX>(io, e, out);
+  if (io.full && out.write_state) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
   ANM_PHASE(6);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#if defined(__HIPCC__)
+// I/O layer 2 (GPU, series mode, K = 1): one wavefront = 64 consecutive environments whose action /
+// state / obs rows are contiguous in memory.  Rows travel through LDS so that every global access is
+// a fully coalesced 512-byte wave transaction (the plain layer issues 16-byte stores with a 144-byte
+// lane stride: every store instruction touches 64 cache lines and partial lines are written twice).
+// The time index is kept in a compact int32 array instead of being re-read from the state rows.
+template <class T, class JT>
+__device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n, double* lds) {
+  typedef Dims<T> D;
+  constexpr int S = T::SDIM + 1;
+  constexpr int SP = S + 1;  // padded row stride (odd number of doubles: conflict-free column access)
+  const int lane = threadIdx.x;
+  const int64_t e0 = int64_t(blockIdx.x) * 64;
+  const int64_t e = e0 + lane;
+  const bool valid = e < n;
+  const int64_t ec = valid ? e : n - 1;
+  const int rows = int((n - e0) < 64 ? (n - e0) : 64);
+  StepIn<T> in;
+  StepOut<T, 1> out;
+  EnvWork<T> w;
+  // ---- coalesced loads: 64 x ADIM doubles of actions
+  {
+    const double* g = io.action + e0 * D::ADIM;
+    constexpr int AP = D::ADIM + 1;
+    for (int j = 0; j < D::ADIM; ++j) {
+      const int idx = j * 64 + lane;
+      if (idx < rows * D::ADIM) lds[(idx / D::ADIM) * AP + (idx % D::ADIM)] = g[idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int lr = valid ? lane : rows - 1;
+    static_for<0, D::ADIM>([&](auto I) { in.action[I] = lds[lr * AP + I]; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  in.was_term = io.terminated[ec] != 0;
+  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
+  in.aux_prev = double(io.aux_index[ec]);
+  in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
+  step_compute<T, JT, 1>(C, io, so, ec, in, out, w);
+  if (valid) {
+    store_step_scalars<T, 1>(io, e, out);
+    if (out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
+  }
+  // ---- coalesced stores of the state and obs rows
+  auto store_rows = [&](double* gbase, const double* row, bool wr) {
+    const unsigned long long mask = __ballot(wr && valid);
+    static_for<0, S>([&](auto K) { lds[lane * SP + K] = row[K]; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int l = lane / S, k = lane % S;  // element (row l, column k) of flat index j*64 + lane
+    constexpr int dq = 64 / S, dr = 64 % S;
+    for (int j = 0; j < S; ++j) {
+      if ((mask >> l) & 1ull) gbase[j * 64 + lane] = lds[l * SP + k];
+      l += dq;
+      k += dr;
+      if (k >= S) { k -= S; ++l; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  store_rows(io.state + e0 * S, out.state, out.write_state);
+  store_rows(io.obs + e0 * S, out.obs, out.write_obs);
+  ANM_PHASE(6);
+}
+#endif
+#endif
 
 }  // namespace anm

@@ -165,6 +165,12 @@ class BatchedANMEnv(GymEnv):
         self._obs_buf = None
         self._step_args = None
         self._reset_count_ptr = self._reset_count.data_ptr()
+        # compact time index next to `state` (series mode, thread-per-environment family): enables the
+        # coalesced-row step kernel
+        self._aux_index = None
+        if self._series is not None and K == 1 and sim.impl == "thread" and self._obs_is_state:
+            self._aux_index = torch.zeros(E_, dtype=torch.int32, device=self.device)
+        self._aux_index_ptr = None if self._aux_index is None else self._aux_index.data_ptr()
         self._opts_ref = C.byref(sim.opts)
 
     # ---- hooks for task designers (anm_env.py:158-191) -----------------------------------------------
@@ -325,7 +331,8 @@ class BatchedANMEnv(GymEnv):
                 sim._handle, self.num_envs, init_state.data_ptr(), None if mask_u8 is None else mask_u8.data_ptr(),
                 sim.soc.data_ptr(), self.state.data_ptr(), self._state_obs.data_ptr(), self._conv_u8.data_ptr(),
                 self._term_u8.data_ptr(), self.timestep.data_ptr(), sim.nr_iters.data_ptr(),
-                sim.full.data_ptr() if self._need_full else None, C.byref(sim.opts), _stream_ptr(self.device),
+                sim.full.data_ptr() if self._need_full else None, self._aux_index_ptr, C.byref(sim.opts),
+                _stream_ptr(self.device),
             )  # fmt: skip
         sim.backend.check(rc, "anm_reset_f64")
 
@@ -401,10 +408,10 @@ class BatchedANMEnv(GymEnv):
         if switch:
             with torch.cuda.device(dev):
                 rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
-                        self.rng_seed, self.env_offset, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
+                        self.rng_seed, self.env_offset, self._reset_count_ptr, self._aux_index_ptr, self._opts_ref, stream)  # fmt: skip
         else:
             rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
-                    self.rng_seed, self.env_offset, self._reset_count_ptr, self._opts_ref, stream)  # fmt: skip
+                    self.rng_seed, self.env_offset, self._reset_count_ptr, self._aux_index_ptr, self._opts_ref, stream)  # fmt: skip
         if rc != 0:
             sim.backend.check(rc, "anm_step_f64")
 

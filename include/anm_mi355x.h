@@ -148,8 +148,8 @@ int anm_transition_f64(anm_model* m, int64_t num_envs, const double* p_load, con
  * clears terminated/timestep of the environments it touches. */
 int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, const uint8_t* mask,
                   double* soc, double* state, double* obs, uint8_t* converged, uint8_t* terminated,
-                  int32_t* timestep, int32_t* nr_iters, double* full, const anm_solver_opts* opts,
-                  void* stream);
+                  int32_t* timestep, int32_t* nr_iters, double* full, int32_t* aux_index,
+                  const anm_solver_opts* opts, void* stream);
 
 /* ANMEnv.step for num_envs environments.
  *   in : action [E, action_dim];  exo [E, n_load+n_gen] MW and aux_next [E, K] (the output of
@@ -162,12 +162,18 @@ int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, cons
  *        ANM6Easy.init_state (anm6_easy.py:25-52) from a counter-based RNG keyed by
  *        (rng_seed, env_offset + env index, reset_count[e]); reward 0, terminated 0.  env_offset is
  *        the global index of this batch's first environment, so a batch sharded over several GPUs
- *        draws exactly what the unsharded batch would. */
+ *        draws exactly what the unsharded batch would.
+ *   aux_index (optional, series mode, K = 1): int32 [E] compact copy of the time index kept by the
+ *        library next to `state`; when given (and `full` is NULL) the thread-per-environment family
+ *        uses its coalesced-row kernel: action / state / obs rows move through LDS as whole-wave
+ *        512-byte transactions and the time index is not re-read from the state rows.  Must be the
+ *        same buffer in anm_reset_f64 and anm_step_f64. */
 int anm_step_f64(anm_model* m, int64_t num_envs, const double* action, const double* exo,
                  const double* aux_next, double* soc, double* state, uint8_t* terminated,
                  int32_t* timestep, double* obs, double* reward, double* e_loss, double* penalty,
                  int32_t* nr_iters, double* full, int32_t autoreset, uint64_t rng_seed,
-                 uint64_t env_offset, int32_t* reset_count, const anm_solver_opts* opts, void* stream);
+                 uint64_t env_offset, int32_t* reset_count, int32_t* aux_index,
+                 const anm_solver_opts* opts, void* stream);
 
 /* obs[e, k] = clip(full[e, index[k]] * scale[k], low[k], high[k]) for k < n_obs: the list form of
  * the observation space (anm_env.py:497-521,562-592).  index/scale/low/high are dev arrays. */
@@ -193,7 +199,7 @@ int anm_time_step_launches(anm_model* m, int64_t num_envs, const double* action,
                            double* state, uint8_t* terminated, int32_t* timestep, double* obs,
                            double* reward, double* e_loss, double* penalty, int32_t autoreset,
                            uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count,
-                           const anm_solver_opts* opts,
+                           int32_t* aux_index, const anm_solver_opts* opts,
                            void* stream, int32_t n_launch, float* ms_per_launch);
 
 #ifdef __cplusplus

@@ -103,11 +103,11 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
 
 int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, double* soc, double* state,
                   double* obs, uint8_t* converged, uint8_t* terminated, int32_t* timestep, int32_t* nr_iters,
-                  double* full, const anm_solver_opts* opts, void*) {
+                  double* full, int32_t* aux_index, const anm_solver_opts* opts, void*) {
   if (!m->env_set) return fail("anm_reset_f64: call anm_model_set_env first");
   EnvIO io{};
   io.K = m->K; io.init_state = init_state; io.mask = mask; io.soc = soc; io.state = state; io.obs = obs;
-  io.converged = converged; io.terminated = terminated; io.timestep = timestep; io.nr_iters = nr_iters; io.full = full;
+  io.converged = converged; io.terminated = terminated; io.timestep = timestep; io.nr_iters = nr_iters; io.full = full; io.aux_index = aux_index;
   int prec;
   SolverOpts so = solver(opts, prec);
   for (int64_t e = 0; e < n; ++e) {
@@ -120,7 +120,7 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
 int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
                  double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                  double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, const anm_solver_opts* opts, void*) {
+                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_solver_opts* opts, void*) {
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
   const bool series = exo == nullptr;
   if (series && m->period <= 0) return fail("anm_step_f64: no exo given and the model has no series (set_env)");
@@ -142,7 +142,7 @@ int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* ex
 }
 
 int anm_time_step_launches(anm_model*, int64_t, const double*, double*, double*, uint8_t*, int32_t*, double*,
-                           double*, double*, double*, int32_t, uint64_t, uint64_t, int32_t*, const anm_solver_opts*, void*,
+                           double*, double*, double*, int32_t, uint64_t, uint64_t, int32_t*, int32_t*, const anm_solver_opts*, void*,
                            int32_t, float*) {
   return fail("hostsim: no device timing");
 }
