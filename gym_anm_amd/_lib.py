@@ -79,7 +79,8 @@ ABI = {
     "anm_model_get_impl": (C.c_int, [C.c_void_p]),
     "anm_model_full_layout": (C.c_int, [C.c_void_p, C.POINTER(FullLayout)]),
     "anm_transition_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 11 + [C.POINTER(SolverOpts), _P]),
-    "anm_reset_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 11 + [C.POINTER(SolverOpts), _P]),
+    "anm_reset_f64": (C.c_int, [C.c_void_p, C.c_int64, _P, _P, C.c_uint64, C.c_uint64] + [_P] * 10
+                      + [C.POINTER(SolverOpts), _P]),
     "anm_step_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 13 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,
                                                                       C.POINTER(SolverOpts), _P]),
     "anm_gather_obs_f64": (C.c_int, [C.c_int64, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),

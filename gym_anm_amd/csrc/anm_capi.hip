@@ -110,7 +110,6 @@ int upload_const(anm_model* m) {
   return 0;
 }
 
-template <class... Args>
 int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
   const int per_wave = 64 / m->plan.d.G;
   const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
@@ -344,16 +343,24 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   return 0;
 }
 
-int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, double* soc, double* state,
+int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, uint64_t rng_seed,
+                  uint64_t env_offset, int32_t* reset_count, double* soc, double* state,
                   double* obs, uint8_t* converged, uint8_t* terminated, int32_t* timestep, int32_t* nr_iters,
                   double* full, int32_t* aux_index, const anm_solver_opts* opts, void* stream) {
   if (!m) return fail("anm_reset_f64: null model");
   if (!m->env_set) return fail("anm_reset_f64: call anm_model_set_env first");
   if (n <= 0) return 0;
-  if (!init_state || !state || !obs || !converged || !terminated) return fail("anm_reset_f64: null argument");
+  if (!state || !obs || !converged || !terminated) return fail("anm_reset_f64: null argument");
+  if (!init_state && (m->period <= 0 || m->K != 1 || !reset_count))
+    return fail("anm_reset_f64: drawing initial states on the device needs a series-mode model and reset_count");
   EnvIO io{};
   io.K = m->K;
   io.init_state = init_state;
+  io.series = m->d_series;
+  io.period = m->period;
+  io.rng_seed = rng_seed;
+  io.env_offset = env_offset;
+  io.reset_count = reset_count;
   io.mask = mask;
   io.soc = soc;
   io.state = state;

@@ -153,6 +153,46 @@ ANM_HD void finish_reset(cptr_t C, EnvWork<T>& w, const double* s0, int K, doubl
   });
 }
 
+// ANM6Easy.init_state (anm6_easy.py:25-52) generalised to any series-mode task, drawn on the device:
+// time index uniform in [0, period), loads and generator potentials from the series at that index,
+// generator Q uniform in its p.u. range (stored in the MVAr slot, sic), storage SoC uniform in its
+// p.u. range (stored in the MWh slot, sic).  Counter-based: (seed, global env index, epoch).
+template <class T>
+ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32_t epoch, double (&s0)[T::SDIM + 1]) {
+  typedef Layout<T> L;
+  uint32_t r[4];
+  Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 0u, r);
+  const int aux = int((uint64_t(r[0]) * uint64_t(io.period)) >> 32);
+  static_for<0, T::SDIM>([&](auto I) { s0[I] = 0.0; });
+  s0[T::SDIM] = double(aux);
+  static_for<0, T::ND>([&](auto Di) {
+    constexpr int d = Di;
+    constexpr int typ = T::DEV_TYPE[d];
+    if constexpr (typ == DEV_LOAD) {
+      s0[d] = io.series[T::DEV_SLOT[d] * io.period + aux];
+    } else if constexpr (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
+      constexpr int g = T::DEV_SLOT[d];
+      constexpr int u = g;  // uniform index
+      cptr_t sd = C + L::SETDEV + SD_SIZE * T::DEV_SET[d];
+      uint32_t q[4];
+      Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 1u + u / 2, q);
+      const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
+      const double pm = io.series[(T::NLOAD + g) * io.period + aux];
+      s0[d] = pm;
+      s0[2 * T::ND + T::NDES + g] = pm;
+      s0[T::ND + d] = sd[SD_QMIN] + (sd[SD_QMAX] - sd[SD_QMIN]) * uu;
+    } else if constexpr (typ == DEV_STORAGE) {
+      constexpr int u = T::NGEN + T::DEV_SLOT[d];
+      cptr_t sd = C + L::SETDEV + SD_SIZE * T::DEV_SET[d];
+      uint32_t q[4];
+      Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 1u + u / 2, q);
+      const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
+      s0[2 * T::ND + T::DEV_SLOT[d]] = sd[SD_SOC_MIN] + (sd[SD_SOC_MAX] - sd[SD_SOC_MIN]) * uu;
+    }
+  });
+  return aux;
+}
+
 template <class T, class JT>
 ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   if (io.mask && !io.mask[e]) return;
@@ -160,7 +200,12 @@ ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   EnvWork<T> w;
   double P_load[T::NLOAD > 0 ? T::NLOAD : 1], P_pot[T::NGEN > 0 ? T::NGEN : 1];
   double P_set[T::NSET > 0 ? T::NSET : 1], Q_set[T::NSET > 0 ? T::NSET : 1];
-  const double* s0 = io.init_state + e * S;
+  double s0_drawn[T::SDIM + 1];
+  const double* s0 = io.init_state ? io.init_state + e * S : s0_drawn;
+  if (!io.init_state) {  // device sampler (series mode, K = 1): same draws as the autoreset path
+    sample_series_init_state<T>(C, io, e, uint32_t(io.reset_count[e]), s0_drawn);
+    io.reset_count[e] += 1;
+  }
   inputs_from_init_state<T>(C, s0, w, P_load, P_pot, P_set, Q_set);
   transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
   finish_reset<T>(C, w, s0, io.K, io.soc + e * T::NDES, io.state + e * S, io.obs + e * S);
@@ -229,38 +274,7 @@ ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, co
   int aux = 0;
 
   if (resetting) {
-    // ANM6Easy.init_state (anm6_easy.py:25-52) with a counter-based RNG
-    const uint32_t epoch = uint32_t(in.reset_count);
-    uint32_t r[4];
-    Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 0u, r);
-    aux = int((uint64_t(r[0]) * uint64_t(io.period)) >> 32);
-    static_for<0, T::SDIM>([&](auto I) { s0[I] = 0.0; });
-    s0[T::SDIM] = double(aux);
-    static_for<0, T::ND>([&](auto Di) {
-      constexpr int d = Di;
-      constexpr int typ = T::DEV_TYPE[d];
-      if constexpr (typ == DEV_LOAD) {
-        s0[d] = io.series[T::DEV_SLOT[d] * io.period + aux];
-      } else if constexpr (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
-        constexpr int g = T::DEV_SLOT[d];
-        constexpr int u = g;  // uniform index
-        cptr_t sd = C + L::SETDEV + SD_SIZE * T::DEV_SET[d];
-        uint32_t q[4];
-        Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 1u + u / 2, q);
-        const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
-        const double pm = io.series[(T::NLOAD + g) * io.period + aux];
-        s0[d] = pm;
-        s0[2 * T::ND + T::NDES + g] = pm;
-        s0[T::ND + d] = sd[SD_QMIN] + (sd[SD_QMAX] - sd[SD_QMIN]) * uu;  // p.u. range, MVAr slot (sic)
-      } else if constexpr (typ == DEV_STORAGE) {
-        constexpr int u = T::NGEN + T::DEV_SLOT[d];
-        cptr_t sd = C + L::SETDEV + SD_SIZE * T::DEV_SET[d];
-        uint32_t q[4];
-        Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 1u + u / 2, q);
-        const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
-        s0[2 * T::ND + T::DEV_SLOT[d]] = sd[SD_SOC_MIN] + (sd[SD_SOC_MAX] - sd[SD_SOC_MIN]) * uu;  // sic
-      }
-    });
+    aux = sample_series_init_state<T>(C, io, e, uint32_t(in.reset_count), s0);
     inputs_from_init_state<T>(C, s0, w, P_load, P_pot, P_set, Q_set);
   } else {
     // 1. exogenous variables (next_vars, anm6_easy.py:54-65 in series mode)

@@ -76,8 +76,7 @@ inline bool is_radial(const anm_network_desc& n) {
   return cnt == n.n_bus;
 }
 
-// Tables for one network.  `base` = the constant buffer of the thread-per-env layout is NOT needed:
-// everything is rebuilt from the description (same formulas as pack_constants).
+// Per-lane tables for one network, built from the description alone (same formulas as pack_constants).
 inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   if (!is_radial(n)) { err = "network is not a radial tree with <= 64 buses/devices"; return false; }
   Dims& d = P.d;
@@ -209,8 +208,8 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     for (int j = 0; j < 4; ++j) { D(DF_BRC + 2 * j, l) = c4[j].real(); D(DF_BRC + 2 * j + 1, l) = c4[j].imag(); }
     D(DF_BRC + 8, l) = n.br_rate[br];
   }
-  // device constants: reuse the thread-per-env packing of one device (anm_pack.hpp) through a
-  // single-device shim so that the projection tables are computed by exactly the same code
+  // device constants: the per-device packing of anm_pack.hpp, so that the projection tables are
+  // computed by exactly the same code as for the thread-per-environment kernels
   for (int k = 0; k < d.ND; ++k) {
     double* sd = &P.hd[d.off_dev + k * SD_SIZE];
     pack_device(n, k, sd);
@@ -279,6 +278,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   // ---------------- inputs per device lane -------------------------------------------------
   bool skip = false;        // env in the absorbing terminal state (step mode, no autoreset)
   bool resetting = false;
+  bool sampled = false;     // initial state drawn by the in-kernel RNG (autoreset, or reset without init_state)
   int aux = 0;
   double in_p = 0.0, in_q = 0.0, in_pot = 0.0, soc = 0.0, s0_q = 0.0;
   double soc_req = 0.0;     // reset: requested SoC (MWh slot)
@@ -301,7 +301,8 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (mode == 1 && io.e.mask && !io.e.mask[ee]) skip = true;
     const double* s0 = nullptr;
     double s0_p = 0.0, s0_pm = 0.0;
-    if (mode == 1) {
+    sampled = resetting && !(mode == 1 && io.e.init_state);
+    if (mode == 1 && io.e.init_state) {
       s0 = io.e.init_state + ee * S;
       if (typ != DEV_NONE) { s0_p = s0[l]; s0_q = s0[d.ND + l]; }
       if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) s0_pm = s0[2 * d.ND + d.NDES + slot];
@@ -329,7 +330,6 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       }
     }
     if (resetting) {
-      if (mode == 1) aux = 0;
       in_p = s0_p;
       in_q = s0_q;
       in_pot = s0_pm;
@@ -430,9 +430,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     const double nd = (nanf > 0.0) ? NAN : a;
     if (it == 0) diff = nd;            // initial evaluation
     else if (active) diff = nd;
-    const bool was_active = active;
     active = (diff > so.tol) && (it < so.max_iter);
-    (void)was_active;
     ANM_GROUP_SYNC();
     if (!__any(active && env_ok && !skip)) break;
     // ---- Jacobian blocks: own diagonal, coupling with the parent (row b / col p and row p / col b)
@@ -629,8 +627,12 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
     if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) put(2 * d.ND + d.NDES + slot, p_pot * base);
     if (mode == 1) {
-      const double* s0 = io.e.init_state + e * S;
-      for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
+      if (sampled) {
+        if (l == 0) { put(d.SDIM, double(aux)); io.e.reset_count[e] += 1; }
+      } else {
+        const double* s0 = io.e.init_state + e * S;
+        for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
+      }
       if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
     } else {
       if (l == 0) {

@@ -328,7 +328,8 @@ class BatchedANMEnv(GymEnv):
         sim = self.simulator
         with sim._device_ctx():
             rc = sim.backend.lib.anm_reset_f64(
-                sim._handle, self.num_envs, init_state.data_ptr(), None if mask_u8 is None else mask_u8.data_ptr(),
+                sim._handle, self.num_envs, None if init_state is None else init_state.data_ptr(),
+                None if mask_u8 is None else mask_u8.data_ptr(), self.rng_seed, self.env_offset, self._reset_count_ptr,
                 sim.soc.data_ptr(), self.state.data_ptr(), self._state_obs.data_ptr(), self._conv_u8.data_ptr(),
                 self._term_u8.data_ptr(), self.timestep.data_ptr(), sim.nr_iters.data_ptr(),
                 sim.full.data_ptr() if self._need_full else None, self._aux_index_ptr, C.byref(sim.opts),
@@ -347,6 +348,8 @@ class BatchedANMEnv(GymEnv):
         if seed is not None:
             self.rng_seed = int(seed)
         options = options or {}
+        if options.get("sampler") == "device":
+            return self._reset_on_device(options.get("mask"))
         mask = options.get("mask")
         mask_u8 = None
         if mask is not None:
@@ -386,6 +389,32 @@ class BatchedANMEnv(GymEnv):
             self.observation_space = Box(low=-np.ones(n) * np.inf, high=np.ones(n) * np.inf)
             self.observation_N = n
         return obs, {}
+
+    def _reset_on_device(self, mask=None):
+        """``reset(options={"sampler": "device"})`` (series-mode tasks): initial states are drawn inside
+        the reset kernel by the counter-based RNG that also serves autoreset, keyed by
+        ``(seed, env_offset + env, reset_count[env])``, instead of by ``init_state()`` on the host.
+        Environments whose first power flow does not converge are redrawn, up to the reference's
+        limit of 100 attempts (anm_env.py:266-289)."""
+        if self._series is None:
+            raise E.EnvInitializationError("the device sampler needs a series-mode task")
+        if mask is None:
+            todo = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
+        else:
+            todo = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        touched = todo.bool()
+        for attempt in range(100):
+            self._launch_reset(None, todo)
+            todo = todo * (1 - self._conv_u8)
+            if not bool(todo.any()):
+                break
+        else:
+            raise E.EnvInitializationError(
+                "No non-terminal state found out of 100 initial states for environment %s" % type(self).__name__
+            )
+        self.e_loss[touched] = 0.0
+        self.penalty[touched] = 0.0
+        return self.observation(self.state), {}
 
     # ---- step (anm_env.py:333-453) -----------------------------------------------------------------------------
     def _step_call(self, action_ptr, exo_ptr, aux_ptr):

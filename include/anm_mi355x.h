@@ -145,9 +145,12 @@ int anm_transition_f64(anm_model* m, int64_t num_envs, const double* p_load, con
 /* Simulator.reset(init_state) + the tail of ANMEnv.reset, for every environment with mask[e] != 0
  * (mask NULL = all).  init_state [E, state_base_dim + K] uses the reference layout
  * [P_dev MW, Q_dev MVAr, soc MWh, P_max MW, aux].  Writes soc, state, obs, converged;
- * clears terminated/timestep of the environments it touches. */
+ * clears terminated/timestep of the environments it touches.
+ * init_state == NULL (series mode): the initial states are drawn inside the kernel like
+ * ANM6Easy.init_state (anm6_easy.py:25-52) from the counter-based RNG keyed by
+ * (rng_seed, env_offset + env, reset_count[env]); reset_count[env] is then incremented. */
 int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, const uint8_t* mask,
-                  double* soc, double* state, double* obs, uint8_t* converged, uint8_t* terminated,
+                  uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, double* soc, double* state, double* obs, uint8_t* converged, uint8_t* terminated,
                   int32_t* timestep, int32_t* nr_iters, double* full, int32_t* aux_index,
                   const anm_solver_opts* opts, void* stream);
 

@@ -101,12 +101,17 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   return 0;
 }
 
-int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, double* soc, double* state,
+int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8_t* mask, uint64_t rng_seed,
+                  uint64_t env_offset, int32_t* reset_count, double* soc, double* state,
                   double* obs, uint8_t* converged, uint8_t* terminated, int32_t* timestep, int32_t* nr_iters,
                   double* full, int32_t* aux_index, const anm_solver_opts* opts, void*) {
   if (!m->env_set) return fail("anm_reset_f64: call anm_model_set_env first");
   EnvIO io{};
+  if (!init_state && (m->period <= 0 || m->K != 1 || !reset_count))
+    return fail("anm_reset_f64: drawing initial states on the device needs a series-mode model and reset_count");
   io.K = m->K; io.init_state = init_state; io.mask = mask; io.soc = soc; io.state = state; io.obs = obs;
+  io.series = m->series.data(); io.period = m->period; io.rng_seed = rng_seed; io.env_offset = env_offset;
+  io.reset_count = reset_count;
   io.converged = converged; io.terminated = terminated; io.timestep = timestep; io.nr_iters = nr_iters; io.full = full; io.aux_index = aux_index;
   int prec;
   SolverOpts so = solver(opts, prec);

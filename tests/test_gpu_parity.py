@@ -491,3 +491,29 @@ def test_new_topology_is_compiled_on_first_use(n_bus, seed):
         if key.endswith("_i_ang"):  # the angle of a ~zero current is ill-conditioned
             continue
         npt.assert_allclose(f2[:, sl[key]], f1[:, sl[key]], rtol=0, atol=1e-9, err_msg=key)
+
+
+@pytest.mark.parametrize("impl", ["thread", "radial"])
+def test_device_sampler_reset(impl):
+    """reset(options={"sampler": "device"}) on both kernel families: the in-kernel draws equal the host
+    restatement of the counter-based RNG and the oracle's reset of that state."""
+    import anm_oracle as O
+    from gym_anm_amd import networks, rng
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 4096
+    env = ANM6EasyVec(num_envs=E_, device=DEV, seed=21, env_offset=7 * E_, impl=impl)
+    obs, _ = env.reset(seed=21, options={"sampler": "device"})
+    assert not bool(env.terminated.any()) and bool((env._reset_count == 1).all())
+    for e in range(0, E_, 401):
+        s0 = rng.series_init_state(env.simulator.model, env._series, 21, 7 * E_ + e, 0)
+        o_ref, conv = O.OracleEnv(networks.anm6_network(), sparse=False).reset_to(s0)
+        assert conv
+        npt.assert_allclose(obs[e].cpu().numpy(), o_ref, rtol=0, atol=1e-9)
+    # stepping after a device-sampled reset works and stays inside the Box
+    env.check_actions = False
+    a = torch.zeros((E_, 6), dtype=torch.float64, device=DEV)
+    o, r, term, _, _ = env.step(a)
+    low = torch.as_tensor(env.observation_space.low, device=DEV)
+    high = torch.as_tensor(env.observation_space.high, device=DEV)
+    assert bool(((o >= low) & (o <= high)).all())

@@ -35,3 +35,35 @@ def test_transition_golden_f32_solve(name):
 def test_anm6easy_episodes():
     net = NETS["anm6"]
     pc.run_episodes(lambda n: ANM6EasyVec(num_envs=n, device="cpu", _backend=_backend(net)))
+
+
+def test_device_sampler_reset():
+    """reset(options={"sampler": "device"}): initial states drawn inside the reset kernel equal the host
+    restatement of the counter-based RNG (gym_anm_amd/rng.py) + the oracle's reset; masked variant."""
+    import numpy.testing as npt
+
+    import anm_oracle as O
+    from gym_anm_amd import networks, rng
+
+    net = NETS["anm6"]
+    E_ = 96
+    env = ANM6EasyVec(num_envs=E_, device="cpu", seed=21, env_offset=1000, _backend=_backend(net))
+    obs, _ = env.reset(seed=21, options={"sampler": "device"})
+    assert not bool(env.terminated.any()) and bool((env.timestep == 0).all())
+    assert bool((env._reset_count == 1).all())
+    for e in range(0, E_, 7):
+        s0 = rng.series_init_state(env.simulator.model, env._series, 21, 1000 + e, 0)
+        orc = O.OracleEnv(networks.anm6_network(), sparse=False)
+        o_ref, conv = orc.reset_to(s0)
+        assert conv
+        npt.assert_allclose(obs[e].numpy(), o_ref, rtol=0, atol=1e-9)
+    # masked: only the selected environments are redrawn (with their next epoch)
+    before = env.state.clone()
+    mask = torch.zeros(E_, dtype=torch.bool)
+    mask[::3] = True
+    obs2, _ = env.reset(options={"sampler": "device", "mask": mask})
+    npt.assert_array_equal(env.state[~mask].numpy(), before[~mask].numpy())
+    assert bool((env._reset_count[mask] == 2).all()) and bool((env._reset_count[~mask] == 1).all())
+    s0 = rng.series_init_state(env.simulator.model, env._series, 21, 1000 + 3, 1)
+    o_ref, _ = O.OracleEnv(networks.anm6_network(), sparse=False).reset_to(s0)
+    npt.assert_allclose(obs2[3].numpy(), o_ref, rtol=0, atol=1e-9)
