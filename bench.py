@@ -208,7 +208,7 @@ def main():
             sim._handle, E, pool[0].data_ptr(), sim.soc.data_ptr(), env.state.data_ptr(), env._term_u8.data_ptr(),
             env.timestep.data_ptr(), env._state_obs.data_ptr(), env.reward.data_ptr(), env.e_loss.data_ptr(),
             env.penalty.data_ptr(), 1, env.rng_seed, env.env_offset, env._reset_count.data_ptr(), env._aux_index_ptr,
-            C.byref(sim.opts), stream,
+            env._ws_ref, C.byref(sim.opts), stream,
             n_launch, C.byref(ms),
         )  # fmt: skip
     sim.backend.check(rc, "anm_time_step_launches")

@@ -47,6 +47,10 @@ class EnvConfig(C.Structure):
     ]  # fmt: skip
 
 
+class StepWs(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("n_doubles", C.c_int64), ("iter_cap", C.c_int32), ("parity", C.c_int32)]
+
+
 class SolverOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32)]
 
@@ -75,6 +79,7 @@ ABI = {
     "anm_model_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
     "anm_model_set_env": (C.c_int, [C.c_void_p, C.POINTER(EnvConfig)]),
     "anm_model_get_ybus": (C.c_int, [C.c_void_p, c_double_p]),
+    "anm_step_ws_record_doubles": (C.c_int, []),
     "anm_model_set_impl": (C.c_int, [C.c_void_p, C.c_int32]),
     "anm_model_get_impl": (C.c_int, [C.c_void_p]),
     "anm_model_full_layout": (C.c_int, [C.c_void_p, C.POINTER(FullLayout)]),
@@ -82,10 +87,11 @@ ABI = {
     "anm_reset_f64": (C.c_int, [C.c_void_p, C.c_int64, _P, _P, C.c_uint64, C.c_uint64] + [_P] * 10
                       + [C.POINTER(SolverOpts), _P]),
     "anm_step_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 13 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,
-                                                                      C.POINTER(SolverOpts), _P]),
+                                                                      C.POINTER(StepWs), C.POINTER(SolverOpts), _P]),
     "anm_gather_obs_f64": (C.c_int, [C.c_int64, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "anm_time_step_launches": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 9 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,
-                                                                              C.POINTER(SolverOpts), _P, C.c_int32,
+                                                                              C.POINTER(StepWs), C.POINTER(SolverOpts), _P,
+                                                                              C.c_int32,
                                                                               C.POINTER(C.c_float)]),
 }  # fmt: skip
 

@@ -202,11 +202,14 @@ def hipcc_path():
     return None
 
 
+# -ffp-contract=on: a*b+c is fused only inside one source expression (front-end rule), never across
+# statements by the back end, so every kernel that instantiates the same template computes the same bits
+# (the two-launch step is bit-identical to the one-launch step; measured cost: none).
 # -fno-slp-vectorize: with SLP on, hipcc 7.2 packs the fp32 Jacobian arithmetic of the 30-bus kernel
 # (512 registers + scratch) into v_pk_* pairs and produces wrong numbers (caught by
 # tests/test_gpu_parity.py::test_transition_golden_f32_solve[case30]); scalar f32/f64 VALU code is correct.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ftemplate-depth=4096",
-               "-fno-gpu-rdc", "-Wno-unused-value", "-fno-slp-vectorize"]  # fmt: skip
+               "-fno-gpu-rdc", "-Wno-unused-value", "-fno-slp-vectorize", "-ffp-contract=on"]  # fmt: skip
 
 
 def _sources_mtime():

@@ -64,6 +64,13 @@ __global__ __launch_bounds__(BLOCK) void k_step_rows(cptr_t C, EnvIO io, SolverO
   op_step_rows<Topo, JT>(C, io, so, n, lds);
 }
 
+template <class JT>
+__global__ __launch_bounds__(BLOCK) void k_step_stragglers(cptr_t C, EnvIO io, SolverOpts so) {
+  op_step_stragglers<Topo, JT>(C, io, so);
+}
+
+__global__ void k_step_scatter(EnvIO io) { op_step_scatter<Topo>(io); }
+
 __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__ full, int n_obs,
                              const int32_t* __restrict__ index, const double* __restrict__ scale,
                              const double* __restrict__ low, const double* __restrict__ high,
@@ -294,6 +301,8 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   return upload_const(m);
 }
 
+int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
+
 int anm_model_set_impl(anm_model* m, int32_t impl) {
   if (!m) return fail("anm_model_set_impl: null model");
   if (impl == ANM_IMPL_RADIAL && !m->radial_ok)
@@ -393,7 +402,8 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
 static int make_step_io(anm_model* m, const double* action, const double* exo, const double* aux_next, double* soc,
                         double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                         double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                        uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, EnvIO& io) {
+                        uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_step_ws* ws,
+                        EnvIO& io) {
   if (!m) return fail("anm_step_f64: null model");
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
   if (!action || !state || !terminated || !obs || !reward || !e_loss || !penalty)
@@ -425,6 +435,15 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   io.env_offset = env_offset;
   io.reset_count = reset_count;
   io.aux_index = aux_index;
+  io.ws = nullptr;
+  if (ws && ws->buf && m->tpe_ok) {
+    const int64_t cap = (ws->n_doubles - Rec<Topo>::HEADER) / Rec<Topo>::SIZE;
+    if (cap < 1 || ws->iter_cap < 1) return fail("anm_step_f64: step workspace too small or iter_cap < 1");
+    io.ws = ws->buf;
+    io.ws_cap = cap;
+    io.iter_cap = ws->iter_cap;
+    io.parity = ws->parity & 1;
+  }
   return 0;
 }
 
@@ -445,6 +464,20 @@ static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solve
       hipLaunchKernelGGL(k_step_rows<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_rows");
+    if (io.ws && io.iter_cap < so.max_iter) {
+      // second launch: the handed-over solves, grid-stride over the records (count lives on the device)
+      const unsigned g2 = unsigned((io.ws_cap + BLOCK - 1) / BLOCK);  // covers every record
+      if (prec == ANM_SOLVE_F32)
+        hipLaunchKernelGGL(k_step_stragglers<float>, dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+      else
+        hipLaunchKernelGGL(k_step_stragglers<double>, dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+      e2 = hipGetLastError();
+      if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_stragglers");
+      const unsigned g3 = unsigned((io.ws_cap + 255) / 256);
+      hipLaunchKernelGGL(k_step_scatter, dim3(g3), dim3(256), 0, s, io);
+      e2 = hipGetLastError();
+      if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_scatter");
+    }
     return 0;
   }
   if (prec == ANM_SOLVE_F32)
@@ -459,11 +492,11 @@ static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solve
 int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
                  double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                  double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_solver_opts* opts,
-                 void* stream) {
+                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_step_ws* ws,
+                 const anm_solver_opts* opts, void* stream) {
   EnvIO io;
   int rc = make_step_io(m, action, exo, aux_next, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
-                        nr_iters, full, autoreset, rng_seed, env_offset, reset_count, aux_index, io);
+                        nr_iters, full, autoreset, rng_seed, env_offset, reset_count, aux_index, ws, io);
   if (rc) return rc;
   if (n <= 0) return 0;
   return launch_step(m, io, n, opts, static_cast<hipStream_t>(stream));
@@ -472,10 +505,11 @@ int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* ex
 int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double* soc, double* state,
                            uint8_t* terminated, int32_t* timestep, double* obs, double* reward, double* e_loss,
                            double* penalty, int32_t autoreset, uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count,
-                           int32_t* aux_index, const anm_solver_opts* opts, void* stream, int32_t n_launch, float* ms_per_launch) {
+                           int32_t* aux_index, anm_step_ws* ws, const anm_solver_opts* opts, void* stream, int32_t n_launch,
+                           float* ms_per_launch) {
   EnvIO io;
   int rc = make_step_io(m, action, nullptr, nullptr, soc, state, terminated, timestep, obs, reward, e_loss, penalty,
-                        nullptr, nullptr, autoreset, rng_seed, env_offset, reset_count, aux_index, io);
+                        nullptr, nullptr, autoreset, rng_seed, env_offset, reset_count, aux_index, ws, io);
   if (rc) return rc;
   if (n <= 0 || n_launch <= 0 || !ms_per_launch) return fail("anm_time_step_launches: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -484,7 +518,13 @@ int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double
   if ((e = hipEventCreate(&t0)) != hipSuccess) return fail_hip(e, "hipEventCreate");
   if ((e = hipEventCreate(&t1)) != hipSuccess) return fail_hip(e, "hipEventCreate");
   hipEventRecord(t0, s);
-  for (int k = 0; k < n_launch && rc == 0; ++k) rc = launch_step(m, io, n, opts, s);
+  for (int k = 0; k < n_launch && rc == 0; ++k) {
+    rc = launch_step(m, io, n, opts, s);
+    if (io.ws) {
+      io.parity ^= 1;
+      ws->parity ^= 1;
+    }
+  }
   hipEventRecord(t1, s);
   e = hipEventSynchronize(t1);
   float ms = 0.f;

@@ -102,6 +102,10 @@ struct EnvIO {
   uint64_t env_offset;      // global index of environment 0 of this batch (RNG key)
   int32_t* reset_count;     // [E] (autoreset)
   int32_t* aux_index;       // [E] series mode: compact copy of the time index (optional)
+  double* ws;               // two-phase step: workspace (counters + straggler records) or null
+  int64_t ws_cap;           // number of straggler records the workspace can hold
+  int iter_cap;             // two-phase step: Newton iterations done by the first launch
+  int parity;               // two-phase step: which of the two counters this step uses
 };
 
 // Split an init_state row (anm_env.py / simulator.py:248-268) into transition inputs.
@@ -247,34 +251,36 @@ struct StepOut {
   int aux;
 };
 
-template <class T, class JT, int KCAP>
-ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepIn<T>& in,
-                         StepOut<T, KCAP>& out, EnvWork<T>& w) {
-  typedef Layout<T> L;
-  typedef Dims<T> D;
-  const bool series = io.exo == nullptr;
-  const bool resetting = in.was_term && io.autoreset && series;
-  ANM_PHASE(0);
-  out.write_state = out.write_obs = out.write_costs = out.write_soc = out.inc_reset = false;
-  out.terminated = -1;
-  out.timestep_op = 0;
-  out.n_iter = 0;
-  out.aux = 0;
-  out.reward = out.e_loss = out.penalty = 0.0;
+// what step_end needs to know about how the step started
+template <class T>
+struct StepCtx {
+  bool absorbing;   // env was terminated and is not being re-initialised: nothing to solve
+  bool resetting;   // autoreset: the transition is the first one of a freshly drawn initial state
+  int aux;          // new time index (series mode)
+  double soc_req[T::NDES > 0 ? T::NDES : 1];  // resetting: SoC requested by the drawn state (MWh slot)
+};
 
-  if (in.was_term && !resetting) {  // absorbing terminal state (anm_env.py:365-367)
-    static_for<0, T::SDIM + KCAP>([&](auto Kc) { out.obs[Kc] = 0.0; });
-    out.write_obs = true;
-    return;
-  }
+// first half of a step: inputs -> device maps, bus sums, up to `iter_cap` Newton iterations
+template <class T, class JT>
+ANM_HD void step_begin(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepIn<T>& in, StepCtx<T>& ctx,
+                       EnvWork<T>& w, PFState<T>& st, int iter_cap) {
+  typedef Layout<T> L;
+  const bool series = io.exo == nullptr;
+  ctx.resetting = in.was_term && io.autoreset && series;
+  ctx.absorbing = in.was_term && !ctx.resetting;
+  ctx.aux = 0;
+  st.active = false;
+  st.it = 0;
+  ANM_PHASE(0);
+  if (ctx.absorbing) return;
 
   double P_load[T::NLOAD > 0 ? T::NLOAD : 1], P_pot[T::NGEN > 0 ? T::NGEN : 1];
   double P_set[T::NSET > 0 ? T::NSET : 1], Q_set[T::NSET > 0 ? T::NSET : 1];
-  double s0[T::SDIM + 1];  // sampled initial state (autoreset only; K == 1 in series mode)
   int aux = 0;
-
-  if (resetting) {
+  if (ctx.resetting) {
+    double s0[T::SDIM + 1];  // sampled initial state (K == 1 in series mode)
     aux = sample_series_init_state<T>(C, io, e, uint32_t(in.reset_count), s0);
+    static_for<0, T::NDES>([&](auto I) { ctx.soc_req[I] = s0[2 * T::ND + I]; });
     inputs_from_init_state<T>(C, s0, w, P_load, P_pot, P_set, Q_set);
   } else {
     // 1. exogenous variables (next_vars, anm6_easy.py:54-65 in series mode)
@@ -300,16 +306,40 @@ ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, co
     });
     static_for<0, T::NDES>([&](auto I) { w.soc[I] = in.soc[I]; });
   }
-  out.aux = aux;
-
+  ctx.aux = aux;
   // 3. one simulator transition, shared by the step and the autoreset path
   ANM_PHASE(1);
-  transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
+  transition_begin<T, JT>(C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, iter_cap);
+  (void)L::TOTAL;
+}
+
+// second half: solution -> flows, reward, clipping, terminal handling, state and observation rows
+template <class T, int KCAP>
+ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepCtx<T>& ctx, EnvWork<T>& w,
+                     const PFState<T>& st, StepOut<T, KCAP>& out) {
+  typedef Layout<T> L;
+  const bool series = io.exo == nullptr;
+  out.write_state = out.write_obs = out.write_costs = out.write_soc = out.inc_reset = false;
+  out.terminated = -1;
+  out.timestep_op = 0;
+  out.n_iter = 0;
+  out.aux = ctx.aux;
+  out.reward = out.e_loss = out.penalty = 0.0;
+  if (ctx.absorbing) {  // absorbing terminal state (anm_env.py:365-367)
+    static_for<0, T::SDIM + KCAP>([&](auto Kc) { out.obs[Kc] = 0.0; });
+    out.write_obs = true;
+    return;
+  }
+  transition_end<T>(C, w, st, so.tol);
   out.n_iter = w.n_iter;
   out.write_soc = true;
   out.write_state = out.write_obs = true;
 
-  if (resetting) {
+  if (ctx.resetting) {
+    // tail of Simulator.reset / ANMEnv.reset for the drawn state: only its SoC and time index matter
+    double s0[T::SDIM + 1];
+    static_for<0, T::NDES>([&](auto I) { s0[2 * T::ND + I] = ctx.soc_req[I]; });
+    s0[T::SDIM] = double(ctx.aux);
     finish_reset<T, 1>(C, w, s0, 1, out.soc, out.state, out.obs);
     out.inc_reset = true;
     out.terminated = w.converged ? 0 : 1;  // not converged: try another draw at the next call
@@ -333,8 +363,8 @@ ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, co
     out.reward = -(el + pn);
     write_state_obs<T>(C, w, out.state, out.obs);
     if (series) {
-      out.state[T::SDIM] = double(aux);
-      out.obs[T::SDIM] = fmin(fmax(double(aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]);
+      out.state[T::SDIM] = double(ctx.aux);
+      out.obs[T::SDIM] = fmin(fmax(double(ctx.aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]);
     } else {
       static_for<0, KCAP>([&](auto Kc) {
         constexpr int k = Kc;
@@ -355,6 +385,16 @@ ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, co
     });
   }
   out.timestep_op = 2;
+}
+
+// one-shot composition
+template <class T, class JT, int KCAP>
+ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepIn<T>& in,
+                         StepOut<T, KCAP>& out, EnvWork<T>& w) {
+  StepCtx<T> ctx;
+  PFState<T> st;
+  step_begin<T, JT>(C, io, so, e, in, ctx, w, st, so.max_iter);
+  step_end<T, KCAP>(C, io, so, e, ctx, w, st, out);
 }
 
 // everything of StepOut except the state / obs rows
@@ -404,8 +444,72 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
   ANM_PHASE(6);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #if defined(__HIPCC__)
+// ---------------------------------------------------------------------------------------------
+// Straggler records (two-phase step).  A diverging Newton solve runs to the iteration cap while the
+// 63 other environments of its wave finished long ago.  The first launch therefore stops after
+// `iter_cap` iterations; every environment that is still iterating then writes its iterate to a
+// record (slot from an atomic counter) and a second launch continues those, densely packed, with the
+// same code, so the results are bit-identical to the one-launch path.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Rec {
+  static constexpr int E = 0, IT = 1, RESET = 2, AUX = 3, SOCREQ = 4, TH = SOCREQ + T::NDES, VM = TH + T::NB,
+                       CS = VM + T::NB, SN = CS + T::NB, BUSP = SN + T::NB, BUSQ = BUSP + T::NB, DEVP = BUSQ + T::NB,
+                       DEVQ = DEVP + T::ND, PPOT = DEVQ + T::ND, SOC = PPOT + T::NGEN, IN_SIZE = SOC + T::NDES,
+                       OUT_SIZE = 2 * (T::SDIM + 1) + T::NDES + 8,  // ResRec<T>::SIZE
+                       SIZE = IN_SIZE > OUT_SIZE ? IN_SIZE : OUT_SIZE;
+  static constexpr int HEADER = 8;  // doubles reserved at the start of the workspace (two int32 counters)
+};
+
+// layout of a record after the straggler launch (results; slot 0 still holds the environment index)
+template <class T>
+struct ResRec {
+  static constexpr int STATE = 1, OBS = STATE + T::SDIM + 1, SOC = OBS + T::SDIM + 1, REWARD = SOC + T::NDES,
+                       ELOSS = REWARD + 1, PENALTY = ELOSS + 1, NITER = PENALTY + 1, TERM = NITER + 1, TSOP = TERM + 1,
+                       FLAGS = TSOP + 1, SIZE = FLAGS + 1;
+};
+
+template <class T>
+__device__ void save_record(double* r, int64_t e, const StepCtx<T>& ctx, const EnvWork<T>& w, const PFState<T>& st) {
+  typedef Rec<T> R;
+  r[R::E] = double(e);
+  r[R::IT] = double(st.it);
+  r[R::RESET] = ctx.resetting ? 1.0 : 0.0;
+  r[R::AUX] = double(ctx.aux);
+  static_for<0, T::NDES>([&](auto I) { r[R::SOCREQ + I] = ctx.soc_req[I]; r[R::SOC + I] = w.soc[I]; });
+  static_for<0, T::NB>([&](auto I) {
+    r[R::TH + I] = w.th[I]; r[R::VM + I] = w.vm[I]; r[R::CS + I] = st.cs[I]; r[R::SN + I] = st.sn[I];
+    r[R::BUSP + I] = w.bus_p[I]; r[R::BUSQ + I] = w.bus_q[I];
+  });
+  static_for<0, T::ND>([&](auto I) { r[R::DEVP + I] = w.dev_p[I]; r[R::DEVQ + I] = w.dev_q[I]; });
+  static_for<0, T::NGEN>([&](auto I) { r[R::PPOT + I] = w.p_pot[I]; });
+}
+
+template <class T>
+__device__ int64_t load_record(const double* r, StepCtx<T>& ctx, EnvWork<T>& w, PFState<T>& st) {
+  typedef Rec<T> R;
+  st.it = int(r[R::IT]);
+  ctx.absorbing = false;
+  ctx.resetting = r[R::RESET] != 0.0;
+  ctx.aux = int(r[R::AUX]);
+  static_for<0, T::NDES>([&](auto I) { ctx.soc_req[I] = r[R::SOCREQ + I]; w.soc[I] = r[R::SOC + I]; });
+  static_for<0, T::NB>([&](auto I) {
+    w.th[I] = r[R::TH + I]; w.vm[I] = r[R::VM + I]; st.cs[I] = r[R::CS + I]; st.sn[I] = r[R::SN + I];
+    w.bus_p[I] = r[R::BUSP + I]; w.bus_q[I] = r[R::BUSQ + I];
+  });
+  static_for<0, T::ND>([&](auto I) { w.dev_p[I] = r[R::DEVP + I]; w.dev_q[I] = r[R::DEVQ + I]; });
+  static_for<0, T::NGEN>([&](auto I) { w.p_pot[I] = r[R::PPOT + I]; });
+  return int64_t(r[R::E]);
+}
+
+#define ANM_WAVE_SYNC()                                        \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
+
 // I/O layer 2 (GPU, series mode, K = 1): one wavefront = 64 consecutive environments whose action /
 // state / obs rows are contiguous in memory.  Rows travel through LDS so that every global access is
 // a fully coalesced 512-byte wave transaction (the plain layer issues 16-byte stores with a 144-byte
@@ -424,6 +528,8 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   const int rows = int((n - e0) < 64 ? (n - e0) : 64);
   StepIn<T> in;
   StepOut<T, 1> out;
+  StepCtx<T> ctx;
+  PFState<T> st;
   EnvWork<T> w;
   // ---- coalesced loads: 64 x ADIM doubles of actions
   {
@@ -433,31 +539,46 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
       const int idx = j * 64 + lane;
       if (idx < rows * D::ADIM) lds[(idx / D::ADIM) * AP + (idx % D::ADIM)] = g[idx];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ANM_WAVE_SYNC();
     const int lr = valid ? lane : rows - 1;
     static_for<0, D::ADIM>([&](auto I) { in.action[I] = lds[lr * AP + I]; });
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ANM_WAVE_SYNC();
   }
   in.was_term = io.terminated[ec] != 0;
   static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
   in.aux_prev = double(io.aux_index[ec]);
   in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
-  step_compute<T, JT, 1>(C, io, so, ec, in, out, w);
-  if (valid) {
+
+  const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
+  step_begin<T, JT>(C, io, so, ec, in, ctx, w, st, two_phase ? io.iter_cap : so.max_iter);
+  bool pending = false;
+  if (two_phase) {
+    // environments still iterating at the cap are handed to the straggler launch
+    int* cnt = reinterpret_cast<int*>(io.ws) + io.parity;
+    if (valid && st.active) {
+      const int slot = atomicAdd(cnt, 1);
+      if (slot < io.ws_cap) {
+        save_record<T>(io.ws + Rec<T>::HEADER + int64_t(slot) * Rec<T>::SIZE, e, ctx, w, st);
+        pending = true;
+      }
+    }
+    // record space exhausted (or a padding lane): finish here
+    const bool keep = st.active;
+    st.active = st.active && !pending;
+    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
+    (void)keep;
+  }
+  step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
+  const bool store = valid && !pending;
+  if (store) {
     store_step_scalars<T, 1>(io, e, out);
     if (out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
   }
   // ---- coalesced stores of the state and obs rows
   auto store_rows = [&](double* gbase, const double* row, bool wr) {
-    const unsigned long long mask = __ballot(wr && valid);
+    const unsigned long long mask = __ballot(wr && store);
     static_for<0, S>([&](auto K) { lds[lane * SP + K] = row[K]; });
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ANM_WAVE_SYNC();
     int l = lane / S, k = lane % S;  // element (row l, column k) of flat index j*64 + lane
     constexpr int dq = 64 / S, dr = 64 % S;
     for (int j = 0; j < S; ++j) {
@@ -466,15 +587,74 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
       k += dr;
       if (k >= S) { k -= S; ++l; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ANM_WAVE_SYNC();
   };
   store_rows(io.state + e0 * S, out.state, out.write_state);
   store_rows(io.obs + e0 * S, out.obs, out.write_obs);
   ANM_PHASE(6);
 }
-#endif
+
+// second launch of the two-phase step: continue the handed-over solves (grid-stride over records)
+template <class T, class JT>
+__device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so) {
+  constexpr int S = T::SDIM + 1;
+  int* cnt = reinterpret_cast<int*>(io.ws);
+  int n_rec = cnt[io.parity];
+  if (n_rec > io.ws_cap) n_rec = int(io.ws_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[io.parity ^ 1] = 0;  // counter of the next step
+  // Dense packing: 64 consecutive records per wavefront.  Measured alternatives (MI355X): dealing the
+  // records one per wavefront makes every iteration 2-3x slower once several sparse wavefronts share a
+  // CU (issue stalls, SQ_WAIT_INST_ANY 60 %), although each wave then only runs the sin/cos tier its
+  // own solve needs.  One record per thread, no loop: the Newton loop keeps every value in registers.
+  const int64_t j = int64_t(blockIdx.x) * 64 + threadIdx.x;
+  if (j >= n_rec) return;
+  StepCtx<T> ctx;
+  PFState<T> st;
+  EnvWork<T> w;
+  StepOut<T, 1> out;
+  double* r = io.ws + Rec<T>::HEADER + j * Rec<T>::SIZE;
+  const int64_t e = load_record<T>(r, ctx, w, st);
+  pf_resume<T>(C, w, st, so.tol, so.max_iter);
+  pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
+  step_end<T, 1>(C, io, so, e, ctx, w, st, out);
+  // The results go back into the record (r[0] keeps the environment index); the scatter launch
+  // writes them to the batch arrays.  Keeping the dozen output pointers out of this kernel keeps its
+  // Newton loop free of scalar-register spills.
+  typedef ResRec<T> Q;
+  static_for<0, S>([&](auto K) { r[Q::STATE + K] = out.state[K]; r[Q::OBS + K] = out.obs[K]; });
+  static_for<0, T::NDES>([&](auto I) { r[Q::SOC + I] = out.soc[I]; });
+  r[Q::REWARD] = out.reward; r[Q::ELOSS] = out.e_loss; r[Q::PENALTY] = out.penalty;
+  r[Q::NITER] = double(out.n_iter); r[Q::TERM] = double(out.terminated); r[Q::TSOP] = double(out.timestep_op);
+  r[Q::FLAGS] = double((out.write_state ? 1 : 0) | (out.write_obs ? 2 : 0) | (out.write_costs ? 4 : 0) |
+                       (out.write_soc ? 8 : 0) | (out.inc_reset ? 16 : 0));
+}
+
+// third launch: scatter the straggler results to the batch arrays
+template <class T>
+__device__ void op_step_scatter(const EnvIO& io) {
+  constexpr int S = T::SDIM + 1;
+  typedef ResRec<T> Q;
+  const int* cnt = reinterpret_cast<const int*>(io.ws);
+  int n_rec = cnt[io.parity];
+  if (n_rec > io.ws_cap) n_rec = int(io.ws_cap);
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n_rec) return;
+  const double* r = io.ws + Rec<T>::HEADER + j * Rec<T>::SIZE;
+  const int64_t e = int64_t(r[0]);
+  StepOut<T, 1> out;
+  const int flags = int(r[Q::FLAGS]);
+  out.write_state = flags & 1; out.write_obs = flags & 2; out.write_costs = flags & 4;
+  out.write_soc = flags & 8; out.inc_reset = flags & 16;
+  out.reward = r[Q::REWARD]; out.e_loss = r[Q::ELOSS]; out.penalty = r[Q::PENALTY];
+  out.n_iter = int(r[Q::NITER]); out.terminated = int(r[Q::TERM]); out.timestep_op = int(r[Q::TSOP]);
+  static_for<0, T::NDES>([&](auto I) { out.soc[I] = r[Q::SOC + I]; });
+  store_step_scalars<T, 1>(io, e, out);
+  if (out.write_state) {
+    io.aux_index[e] = int32_t(r[Q::STATE + T::SDIM]);
+    static_for<0, S>([&](auto K) { io.state[e * S + K] = r[Q::STATE + K]; });
+  }
+  if (out.write_obs) static_for<0, S>([&](auto K) { io.obs[e * S + K] = r[Q::OBS + K]; });
+}
 #endif
 
 }  // namespace anm

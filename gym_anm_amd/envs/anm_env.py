@@ -89,7 +89,7 @@ def check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, state_bound
 class BatchedANMEnv(GymEnv):
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
                  num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
-                 env_offset=0, impl=None, _backend=None):  # fmt: skip
+                 env_offset=0, impl=None, straggler_after="auto", _backend=None):  # fmt: skip
         GymEnv.reset(self, seed=seed)
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
         self.aux_bounds = aux_bounds
@@ -171,6 +171,20 @@ class BatchedANMEnv(GymEnv):
         if self._series is not None and K == 1 and sim.impl == "thread" and self._obs_is_state:
             self._aux_index = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._aux_index_ptr = None if self._aux_index is None else self._aux_index.data_ptr()
+        # two-phase step (see anm_step_ws in include/anm_mi355x.h): the first launch stops after
+        # `straggler_after` Newton iterations, a second launch continues the solves still running
+        self._ws = None
+        self._ws_ref = None
+        if straggler_after == "auto":
+            # measured on MI355X (scripts/two_phase_sweep.py): the hand-over pays once the batch is several
+            # times larger than the 65 536 lanes of the chip (2.1x at 1 M environments), and costs ~30 % below
+            straggler_after = 6 if self.num_envs >= 262144 else None
+        rec = sim.backend.lib.anm_step_ws_record_doubles()
+        if self._aux_index is not None and straggler_after and rec > 0 and int(straggler_after) < int(max_iter):
+            n_rec = min(self.num_envs, 1 << 18)
+            self._ws_buf = torch.zeros(8 + n_rec * rec, dtype=torch.float64, device=self.device)
+            self._ws = _lib.StepWs(self._ws_buf.data_ptr(), self._ws_buf.numel(), int(straggler_after), 0)
+            self._ws_ref = C.byref(self._ws)
         self._opts_ref = C.byref(sim.opts)
 
     # ---- hooks for task designers (anm_env.py:158-191) -----------------------------------------------
@@ -437,10 +451,14 @@ class BatchedANMEnv(GymEnv):
         if switch:
             with torch.cuda.device(dev):
                 rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
-                        self.rng_seed, self.env_offset, self._reset_count_ptr, self._aux_index_ptr, self._opts_ref, stream)  # fmt: skip
+                        self.rng_seed, self.env_offset, self._reset_count_ptr, self._aux_index_ptr, self._ws_ref, self._opts_ref,
+                        stream)  # fmt: skip
         else:
             rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
-                    self.rng_seed, self.env_offset, self._reset_count_ptr, self._aux_index_ptr, self._opts_ref, stream)  # fmt: skip
+                    self.rng_seed, self.env_offset, self._reset_count_ptr, self._aux_index_ptr, self._ws_ref, self._opts_ref,
+                        stream)  # fmt: skip
+        if self._ws is not None:
+            self._ws.parity ^= 1
         if rc != 0:
             sim.backend.check(rc, "anm_step_f64")
 

@@ -154,6 +154,21 @@ int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, cons
                   int32_t* timestep, int32_t* nr_iters, double* full, int32_t* aux_index,
                   const anm_solver_opts* opts, void* stream);
 
+/* Optional workspace of the two-phase step (thread-per-environment family, coalesced-row kernel).
+ * A diverging Newton solve runs to the iteration cap while the 63 other environments of its
+ * wavefront finished long ago.  With a workspace the step is two launches: the first stops after
+ * `iter_cap` iterations and hands the environments that are still iterating over (one record each),
+ * the second continues only those, densely packed, with the same code (bit-identical results).
+ * buf: device memory, zero-initialised once by the caller; n_doubles >= 8 + records * record size
+ * (anm_step_ws_record_doubles()); parity: 0, 1, 0, 1, ... on successive steps that use this buffer. */
+typedef struct anm_step_ws {
+  double* buf;
+  int64_t n_doubles;
+  int32_t iter_cap;
+  int32_t parity;
+} anm_step_ws;
+int anm_step_ws_record_doubles(void);
+
 /* ANMEnv.step for num_envs environments.
  *   in : action [E, action_dim];  exo [E, n_load+n_gen] MW and aux_next [E, K] (the output of
  *        next_vars), or both NULL in series mode (aux = (aux+1) mod period, table lookup)
@@ -175,7 +190,7 @@ int anm_step_f64(anm_model* m, int64_t num_envs, const double* action, const dou
                  const double* aux_next, double* soc, double* state, uint8_t* terminated,
                  int32_t* timestep, double* obs, double* reward, double* e_loss, double* penalty,
                  int32_t* nr_iters, double* full, int32_t autoreset, uint64_t rng_seed,
-                 uint64_t env_offset, int32_t* reset_count, int32_t* aux_index,
+                 uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_step_ws* ws,
                  const anm_solver_opts* opts, void* stream);
 
 /* obs[e, k] = clip(full[e, index[k]] * scale[k], low[k], high[k]) for k < n_obs: the list form of
@@ -196,13 +211,14 @@ typedef struct anm_full_layout {
 } anm_full_layout;
 int anm_model_full_layout(const anm_model* m, anm_full_layout* out);
 
-/* Timing helper for benchmarks: enqueue `n_launch` identical step launches bracketed by HIP
- * events on `stream` and return the average milliseconds per launch (synchronises). */
+/* Timing helper for benchmarks: enqueue `n_launch` identical steps bracketed by HIP events on
+ * `stream` and return the average milliseconds per step (synchronises).  With a workspace a step
+ * is two kernel launches and ws->parity is advanced. */
 int anm_time_step_launches(anm_model* m, int64_t num_envs, const double* action, double* soc,
                            double* state, uint8_t* terminated, int32_t* timestep, double* obs,
                            double* reward, double* e_loss, double* penalty, int32_t autoreset,
                            uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count,
-                           int32_t* aux_index, const anm_solver_opts* opts,
+                           int32_t* aux_index, anm_step_ws* ws, const anm_solver_opts* opts,
                            void* stream, int32_t n_launch, float* ms_per_launch);
 
 #ifdef __cplusplus

@@ -78,6 +78,7 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   m->env_set = true;
   return 0;
 }
+int anm_step_ws_record_doubles(void) { return 0; }
 int anm_model_set_impl(anm_model*, int32_t impl) {
   if (impl != ANM_IMPL_THREAD) return fail("hostsim: only the thread-per-environment templates have a host build");
   return 0;
@@ -125,7 +126,8 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
 int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
                  double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                  double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,
-                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_solver_opts* opts, void*) {
+                 uint64_t rng_seed, uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_step_ws*,
+                 const anm_solver_opts* opts, void*) {
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
   const bool series = exo == nullptr;
   if (series && m->period <= 0) return fail("anm_step_f64: no exo given and the model has no series (set_env)");
@@ -147,7 +149,8 @@ int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* ex
 }
 
 int anm_time_step_launches(anm_model*, int64_t, const double*, double*, double*, uint8_t*, int32_t*, double*,
-                           double*, double*, double*, int32_t, uint64_t, uint64_t, int32_t*, int32_t*, const anm_solver_opts*, void*,
+                           double*, double*, double*, int32_t, uint64_t, uint64_t, int32_t*, int32_t*, anm_step_ws*,
+                           const anm_solver_opts*, void*,
                            int32_t, float*) {
   return fail("hostsim: no device timing");
 }

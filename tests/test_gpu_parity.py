@@ -517,3 +517,33 @@ def test_device_sampler_reset(impl):
     low = torch.as_tensor(env.observation_space.low, device=DEV)
     high = torch.as_tensor(env.observation_space.high, device=DEV)
     assert bool(((o >= low) & (o <= high)).all())
+
+
+@pytest.mark.parametrize("cap_after", [1, 4, 8])
+def test_two_phase_step_is_bit_identical(cap_after):
+    """The two-launch step (first launch stops after `cap_after` Newton iterations, the solves still
+    running are continued by the straggler launch) returns bit-identical results to the one-launch
+    step, including in-kernel autoreset, on 65 536 environments."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 65536
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=9, autoreset=True, tol=1e-6, straggler_after=sa)
+            for sa in (None, cap_after)]  # fmt: skip
+    assert envs[0]._ws is None and envs[1]._ws is not None
+    for env in envs:
+        env.check_actions = False
+        env.reset(seed=9)
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    lo = torch.as_tensor(envs[0].action_space.low, device=DEV)
+    hi = torch.as_tensor(envs[0].action_space.high, device=DEV)
+    n_term = 0
+    for t in range(8):
+        a = lo + (hi - lo) * torch.rand((E_, 6), generator=gen, dtype=torch.float64, device=DEV)
+        (o0, r0, t0, _, _), (o1, r1, t1, _, _) = [env.step(a) for env in envs]
+        n_term += int(t0.sum())
+        for x0, x1 in ((o0, o1), (r0, r1), (t0, t1), (envs[0].state, envs[1].state), (envs[0].e_loss, envs[1].e_loss),
+                       (envs[0].penalty, envs[1].penalty), (envs[0].simulator.soc, envs[1].simulator.soc),
+                       (envs[0].simulator.nr_iters, envs[1].simulator.nr_iters), (envs[0].timestep, envs[1].timestep),
+                       (envs[0]._reset_count, envs[1]._reset_count), (envs[0]._aux_index, envs[1]._aux_index)):  # fmt: skip
+            assert torch.equal(x0, x1), t
+    assert n_term > 100  # the workload did produce diverging solves
