@@ -212,23 +212,44 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-gpu-rdc", "-Wno-unused-value", "-fno-slp-vectorize", "-ffp-contract=on"]  # fmt: skip
 
 
-def _sources_mtime():
-    return max(
-        os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip", ".h"))
-    )
+def _build_stamp(header_text, flags):
+    """Content hash of everything a library is built from (descriptor, kernel sources, C-ABI header,
+    compiler flags).  Freshness is decided by this stamp, not by mtimes: the built libraries travel
+    between machines with the tree and file times do not survive that reliably."""
+    h = hashlib.sha256()
+    h.update(header_text.encode())
+    h.update("\0".join(flags).encode())
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hpp", ".hip", ".h"))]
+    files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "anm_mi355x.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):
-    """Write the descriptor and compile ``libanm_<name>.so`` for gfx950 (no GPU needed to build)."""
+    """Write the descriptor and compile ``libanm_<name>.so`` for gfx950 (no GPU needed to build).
+
+    Safe to call from several processes at once (one rank per GPU): the compile is serialised by a
+    lock file and the library is put in place by an atomic rename."""
+    import fcntl
+
     name = name or topology_name(topo)
     os.makedirs(BUILD_DIR, exist_ok=True)
     hdr, lib = header_path(name), lib_path(name)
     text = emit_header(topo, name)
-    if not os.path.exists(hdr) or open(hdr).read() != text:
-        with open(hdr, "w") as f:
-            f.write(text)
-    fresh = os.path.exists(lib) and os.path.getmtime(lib) >= max(os.path.getmtime(hdr), _sources_mtime())
-    if fresh and not force:
+    extra_flags = list(extra_flags) + os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
+    stamp = _build_stamp(text, HIPCC_FLAGS + extra_flags)
+    stamp_path = lib + ".stamp"
+
+    def fresh():
+        try:
+            return os.path.exists(lib) and open(stamp_path).read().strip() == stamp
+        except OSError:
+            return False
+
+    if fresh() and not force:
         return lib
     hipcc = hipcc_path()
     if hipcc is None:
@@ -236,19 +257,38 @@ def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):
             "no prebuilt gfx950 library for topology '%s' (%s) and hipcc was not found to build it"
             % (name, topology_signature(topo))
         )
-    extra_flags = list(extra_flags) + os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + [
-        '-DANM_TOPO_HEADER="%s"' % hdr,
-        "-I", os.path.join(os.path.dirname(PKG_DIR), "include"),
-        os.path.join(CSRC, "anm_capi.hip"),
-        "-o", lib + ".tmp",
-    ]  # fmt: skip
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise E.HipExtensionError("hipcc failed for topology '%s':\n%s\n%s" % (name, res.stdout[-4000:], res.stderr[-8000:]))
-    os.replace(lib + ".tmp", lib)
+    with open(lib + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if fresh() and not force:  # another process built it while this one waited
+                return lib
+            if not os.path.exists(hdr) or open(hdr).read() != text:
+                tmp_hdr = "%s.%d.tmp" % (hdr, os.getpid())
+                with open(tmp_hdr, "w") as f:
+                    f.write(text)
+                os.replace(tmp_hdr, hdr)
+            tmp = "%s.%d.tmp" % (lib, os.getpid())
+            cmd = [hipcc] + HIPCC_FLAGS + extra_flags + [
+                '-DANM_TOPO_HEADER="%s"' % hdr,
+                "-I", os.path.join(os.path.dirname(PKG_DIR), "include"),
+                os.path.join(CSRC, "anm_capi.hip"),
+                "-o", tmp,
+            ]  # fmt: skip
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+                raise E.HipExtensionError(
+                    "hipcc failed for topology '%s':\n%s\n%s" % (name, res.stdout[-4000:], res.stderr[-8000:])
+                )
+            os.replace(tmp, lib)
+            with open(stamp_path + ".tmp", "w") as f:
+                f.write(stamp + "\n")
+            os.replace(stamp_path + ".tmp", stamp_path)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return lib
 
 
@@ -268,7 +308,10 @@ def stock_topologies():
 
 
 def build_stock(force=False, verbose=False):
-    out = {}
-    for nm, topo in stock_topologies().items():
-        out[nm] = build_library(topo, force=force, verbose=verbose)
-    return out
+    """Build the stock libraries (in parallel: each is one independent hipcc invocation)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    topos = stock_topologies()
+    with ThreadPoolExecutor(max_workers=len(topos)) as pool:
+        futs = {nm: pool.submit(build_library, topo, None, force, verbose) for nm, topo in topos.items()}
+        return {nm: f.result() for nm, f in futs.items()}

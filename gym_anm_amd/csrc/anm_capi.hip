@@ -36,6 +36,10 @@ int fail_hip(hipError_t e, const char* where) {
   return -2;
 }
 
+#ifndef ANM_ROWS_WAVES
+#define ANM_ROWS_WAVES 1  // min. waves per SIMD the step kernel is compiled for (register budget 512 / waves)
+#endif
+
 template <class JT>
 __global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C, TransitionIO io, SolverOpts so, int64_t n) {
   const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(cptr_t C, EnvIO io, SolverOpts s
 
 // coalesced-row variant of k_step (series mode, K = 1, no full dump): see op_step_rows
 template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_step_rows(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+__global__ __launch_bounds__(BLOCK, ANM_ROWS_WAVES) void k_step_rows(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
   __shared__ double lds[64 * (Topo::SDIM + 2)];
   op_step_rows<Topo, JT>(C, io, so, n, lds);
 }

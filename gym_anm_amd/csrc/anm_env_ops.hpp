@@ -269,8 +269,7 @@ ANM_HD void step_begin(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, cons
   ctx.resetting = in.was_term && io.autoreset && series;
   ctx.absorbing = in.was_term && !ctx.resetting;
   ctx.aux = 0;
-  st.active = false;
-  st.it = 0;
+  pf_idle<T>(st);
   ANM_PHASE(0);
   if (ctx.absorbing) return;
 
@@ -550,10 +549,16 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
 
   const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
-  step_begin<T, JT>(C, io, so, ec, in, ctx, w, st, two_phase ? io.iter_cap : so.max_iter);
+  step_begin<T, JT>(C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
   bool pending = false;
-  if (two_phase) {
-    // environments still iterating at the cap are handed to the straggler launch
+  int cap = two_phase ? io.iter_cap : so.max_iter;
+  // One copy of the Newton loop serves both passes (a second inlined copy costs registers and code):
+  // pass 0 iterates up to `cap`; in two-launch mode the environments still iterating are then handed
+  // to the straggler launch, and pass 1 only runs for those that found no record slot.
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, cap);
+    if (!two_phase || pass == 1) break;
     int* cnt = reinterpret_cast<int*>(io.ws) + io.parity;
     if (valid && st.active) {
       const int slot = atomicAdd(cnt, 1);
@@ -562,11 +567,9 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
         pending = true;
       }
     }
-    // record space exhausted (or a padding lane): finish here
-    const bool keep = st.active;
-    st.active = st.active && !pending;
-    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
-    (void)keep;
+    if (pending) st.diff = 0.0;  // handed over: this lane's own solve ends here (its outputs are not stored)
+    cap = so.max_iter;
+    if (!ANM_WAVE_ANY(st.active && !pending)) break;  // else: record space exhausted (or a padding lane)
   }
   step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
   const bool store = valid && !pending;
@@ -614,7 +617,7 @@ __device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so) {
   StepOut<T, 1> out;
   double* r = io.ws + Rec<T>::HEADER + j * Rec<T>::SIZE;
   const int64_t e = load_record<T>(r, ctx, w, st);
-  pf_resume<T>(C, w, st, so.tol, so.max_iter);
+  st.fresh = true;  // F and diff of the saved iterate are recomputed (same code, same inputs, same bits)
   pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
   step_end<T, 1>(C, io, so, e, ctx, w, st, out);
   // The results go back into the record (r[0] keeps the environment index); the scatter launch

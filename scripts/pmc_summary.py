@@ -5,7 +5,8 @@
 import collections, csv, glob, os, statistics, sys
 
 root = sys.argv[1]
-print("# rocprofv3 PMC summary of %s (kernel k_step, per launch, mean over launches)" % root)
+KERNEL = os.environ.get("ANM_PMC_KERNEL", "k_step")  # substring of the kernel name to summarise
+print("# rocprofv3 PMC summary of %s (kernel %s, per launch, mean over launches)" % (root, KERNEL))
 if len(sys.argv) > 2:
     print("# " + " ".join(sys.argv[2:]))
 vals = {}
@@ -17,10 +18,10 @@ for p in sorted(glob.glob(os.path.join(root, "p*"))):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "k_step" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     kt = glob.glob(os.path.join(p, "*", "*_kernel_trace.csv"))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt[0])) if "k_step" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt[0])) if KERNEL in r["Kernel_Name"]]
     print("pass %s: %d launches, avg kernel duration %.2f us" % (os.path.basename(p), len(d), statistics.mean(d)))
     for k, v in sorted(agg.items()):
         vals[k] = statistics.mean(v)
