@@ -238,7 +238,7 @@ struct IO {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
-enum { A_VR = 0, A_VI, A_ER, A_EI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N };  // LDS arrays
+enum { A_VR = 0, A_VI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N };  // LDS arrays
 
 #ifndef ANM_RADIAL_WAVES
 #define ANM_RADIAL_WAVES 1
@@ -398,28 +398,35 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   double diff = 0.0;
   bool active = true;
   const int pl = gb + (parent >= 0 ? parent : 0);
+  // Same formulation as the thread-per-environment kernels (PFState in anm_device.hpp): everything
+  // comes from W_ik = V_i conj(Y_ik V_k).  A lane owns W_bb, W_bp (its row, parent column) and W_pb
+  // (parent row, its column); S_b = W_bb + W_bp + sum over children c of W_pb(c), gathered through LDS.
+  double wpb_r = 0.0, wpb_i = 0.0;
   for (;;) {
-    // ---- V, E, contribution to the parent's current
+    // ---- V; the parent's V comes through LDS
     vr = vm * cs;
     vi = vm * sn;
-    const double sg = (vm > 0.0) ? 1.0 : ((vm < 0.0) ? -1.0 : NAN);
-    const double er = sg * cs, ei = sg * sn;
-    sh[A_VR][t] = vr; sh[A_VI][t] = vi; sh[A_ER][t] = er; sh[A_EI][t] = ei;
-    sh[A_UPR][t] = ypb_r * vr - ypb_i * vi;
-    sh[A_UPI][t] = ypb_r * vi + ypb_i * vr;
+    sh[A_VR][t] = vr; sh[A_VI][t] = vi;
     ANM_GROUP_SYNC();
-    double epr = 1.0, epi = 0.0;
     vpr = 1.0; vpi = 0.0;
-    if (parent >= 0) { vpr = sh[A_VR][pl]; vpi = sh[A_VI][pl]; epr = sh[A_ER][pl]; epi = sh[A_EI][pl]; }
-    ir = ybb_r * vr - ybb_i * vi + ybp_r * vpr - ybp_i * vpi;
-    ii = ybb_r * vi + ybb_i * vr + ybp_r * vpi + ybp_i * vpr;
+    if (parent >= 0) { vpr = sh[A_VR][pl]; vpi = sh[A_VI][pl]; }
+    // U = V_b conj(Y_bb), W_bb = U conj(V_b);  U = V_b conj(Y_bp), W_bp = U conj(V_p);  U = V_p conj(Y_pb), W_pb = U conj(V_b)
+    double ur = fma(vr, ybb_r, vi * ybb_i), ui = fma(vi, ybb_r, -(vr * ybb_i));
+    const double wbb_r = fma(ur, vr, ui * vi), wbb_i = fma(ui, vr, -(ur * vi));
+    ur = fma(vr, ybp_r, vi * ybp_i); ui = fma(vi, ybp_r, -(vr * ybp_i));
+    const double wbp_r = fma(ur, vpr, ui * vpi), wbp_i = fma(ui, vpr, -(ur * vpi));
+    ur = fma(vpr, ypb_r, vpi * ypb_i); ui = fma(vpi, ypb_r, -(vpr * ypb_i));
+    wpb_r = fma(ur, vr, ui * vi); wpb_i = fma(ui, vr, -(ur * vi));
+    sh[A_UPR][t] = wpb_r;
+    sh[A_UPI][t] = wpb_i;
+    ANM_GROUP_SYNC();
+    double sr = wbb_r + wbp_r, si = wbb_i + wbp_i;
     for (int k = ch_beg; k < ch_end; ++k) {
       const int c = gb + lists[k];
-      ir += sh[A_UPR][c];
-      ii += sh[A_UPI][c];
+      sr += sh[A_UPR][c];
+      si += sh[A_UPI][c];
     }
     // ---- mismatch and its inf-norm over the group
-    const double sr = vr * ir + vi * ii, si = vi * ir - vr * ii;
     const double fr = sr - bus_p, fi = si - bus_q;
     double a = isbus ? fmax(fabs(fr), fabs(fi)) : 0.0;
     double nanf = (isbus && (fr != fr || fi != fi)) ? 1.0 : 0.0;
@@ -433,26 +440,10 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     active = (diff > so.tol) && (it < so.max_iter);
     ANM_GROUP_SYNC();
     if (!__any(active && env_ok && !skip)) break;
-    // ---- Jacobian blocks: own diagonal, coupling with the parent (row b / col p and row p / col b)
-    Blk<JT> Dg, Jbp, Jpb;
-    {
-      // diagonal: U = V conj(Ybb); W = U conj(V); B = U conj(E)
-      const double ur = vr * ybb_r + vi * ybb_i, ui = vi * ybb_r - vr * ybb_i;
-      const double wr = ur * vr + ui * vi, wi = ui * vr - ur * vi;
-      const double br = ur * er + ui * ei, bi = ui * er - ur * ei;
-      const double dr = er * ir + ei * ii, di = ei * ir - er * ii;
-      Dg = Blk<JT>{JT(-(si - wi)), JT(dr + br), JT(sr - wr), JT(di + bi)};
-    }
-    {
-      const double ur = vr * ybp_r + vi * ybp_i, ui = vi * ybp_r - vr * ybp_i;       // V_b conj(Y_bp)
-      const double wr = ur * vpr + ui * vpi, wi = ui * vpr - ur * vpi;
-      const double br = ur * epr + ui * epi, bi = ui * epr - ur * epi;
-      Jbp = Blk<JT>{JT(wi), JT(br), JT(-wr), JT(bi)};
-      const double u2r = vpr * ypb_r + vpi * ypb_i, u2i = vpi * ypb_r - vpr * ypb_i;   // V_p conj(Y_pb)
-      const double w2r = u2r * vr + u2i * vi, w2i = u2i * vr - u2r * vi;
-      const double b2r = u2r * er + u2i * ei, b2i = u2i * er - u2r * ei;
-      Jpb = Blk<JT>{JT(w2i), JT(b2r), JT(-w2r), JT(b2i)};
-    }
+    // ---- Jacobian blocks (magnitude columns scaled by |V|): own diagonal, coupling with the parent
+    Blk<JT> Dg = Blk<JT>{JT(-(si - wbb_i)), JT(sr + wbb_r), JT(sr - wbb_r), JT(si + wbb_i)};
+    const Blk<JT> Jbp = Blk<JT>{JT(wbp_i), JT(wbp_r), JT(-wbp_r), JT(wbp_i)};
+    const Blk<JT> Jpb = Blk<JT>{JT(wpb_i), JT(wpb_r), JT(-wpb_r), JT(wpb_i)};
     JT r0 = JT(fr), r1 = JT(fi);
     // ---- elimination, deepest level first
     for (int lev = d.max_depth; lev >= 0; --lev) {
@@ -467,50 +458,62 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
           const Blk<JT> Lk = blk_mul(Jpb, Dg);
           const Blk<JT> Sc = blk_mul(Lk, Jbp);
           sh[A_S0][t] = double(Sc.a); sh[A_S1][t] = double(Sc.b); sh[A_S2][t] = double(Sc.c); sh[A_S3][t] = double(Sc.d);
-          sh[A_L0][t] = double(Lk.a * r0 + Lk.b * r1);
-          sh[A_L1][t] = double(Lk.c * r0 + Lk.d * r1);
+          sh[A_L0][t] = double(fm(Lk.a, r0, Lk.b * r1));
+          sh[A_L1][t] = double(fm(Lk.c, r0, Lk.d * r1));
         }
       }
       ANM_GROUP_SYNC();
     }
-    // ---- back substitution, roots first (dx published in A_L0/A_L1)
+    // ---- back substitution, roots first (dx published in A_UPR/A_UPI)
     JT d0 = JT(0), d1 = JT(0);
     for (int lev = 0; lev <= d.max_depth; ++lev) {
       if (isbus && depth == lev) {
         JT a0 = r0, a1 = r1;
         if (parent >= 0) {
           const JT p0 = JT(sh[A_UPR][pl]), p1 = JT(sh[A_UPI][pl]);
-          a0 -= Jbp.a * p0 + Jbp.b * p1;
-          a1 -= Jbp.c * p0 + Jbp.d * p1;
+          a0 = fm(-Jbp.b, p1, fm(-Jbp.a, p0, a0));
+          a1 = fm(-Jbp.d, p1, fm(-Jbp.c, p0, a1));
         }
-        d0 = Dg.a * a0 + Dg.b * a1;
-        d1 = Dg.c * a0 + Dg.d * a1;
+        d0 = fm(Dg.a, a0, Dg.b * a1);
+        d1 = fm(Dg.c, a0, Dg.d * a1);
         sh[A_UPR][t] = double(d0);
         sh[A_UPI][t] = double(d1);
       }
       ANM_GROUP_SYNC();
     }
-    // ---- update (group-uniform `active`)
-    const double am = (active && isbus) ? 1.0 : 0.0;
-    const double dth = double(d0) * am;
-    vm = fma(-double(d1), am, vm);
-    th -= dth;
-    if (fabs(dth) <= 0.78) {
-      double sd_, cd_;
-      sincos_kernel(dth, 0, sd_, cd_);
-      const double c0 = cs, s0v = sn;
-      cs = fma(c0, cd_, s0v * sd_);
-      sn = fma(s0v, cd_, -(c0 * sd_));
-    } else if (fabs(th) <= 1.0e5) {
-      sincos_small(th, sn, cs);
-    } else if (fabs(th) < 4.0e15) {
-      sincos_medium(th, sn, cs);
-    } else {
-      double sv, cv;
-      sincos(th, &sv, &cv);
-      sn = sv; cs = cv;
+    // ---- update (group-uniform `active`); d1 is the relative magnitude step
+    if (active && isbus) {
+      const double dth = double(d0);
+      vm = fma(-double(d1), fabs(vm), vm);
+      th -= dth;
+      if (fabs(dth) <= 0.78) {
+        double sd_, cd_;
+        sincos_kernel(dth, 0, sd_, cd_);
+        const double c0 = cs, s0v = sn;
+        cs = fma(c0, cd_, s0v * sd_);
+        sn = fma(s0v, cd_, -(c0 * sd_));
+      } else if (fabs(th) < 4.0e15) {
+        sincos_medium(th, sn, cs);
+      } else {
+        const SinCos r = sincos_huge(th);
+        sn = r.s; cs = r.c;
+      }
     }
     it = active ? it + 1 : it;
+  }
+  // bus currents I = Y V of the final iterate (solve_load_flow.py:52-60), once
+  {
+    sh[A_UPR][t] = fma(ypb_r, vr, -(ypb_i * vi));
+    sh[A_UPI][t] = fma(ypb_r, vi, ypb_i * vr);
+    ANM_GROUP_SYNC();
+    ir = fma(ybb_r, vr, -(ybb_i * vi)) + fma(ybp_r, vpr, -(ybp_i * vpi));
+    ii = fma(ybb_r, vi, ybb_i * vr) + fma(ybp_r, vpi, ybp_i * vpr);
+    for (int k = ch_beg; k < ch_end; ++k) {
+      const int c = gb + lists[k];
+      ir += sh[A_UPR][c];
+      ii += sh[A_UPI][c];
+    }
+    ANM_GROUP_SYNC();
   }
   const bool conv_nan = (diff != diff);
   const bool converged = !conv_nan && (diff <= so.tol);
