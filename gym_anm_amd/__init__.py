@@ -5,3 +5,19 @@ missing / unloadable extension raises (there is no CPU fallback in the product p
 """
 
 __version__ = "0.1.0"
+
+
+def _register():
+    """``gym.make("ANM6Easy-v0")`` like the reference (gym_anm/__init__.py:8-11), when gymnasium is
+    installed and the id is still free (gym-anm itself may be installed next to this package)."""
+    try:
+        from gymnasium.envs.registration import register, registry
+    except Exception:
+        return
+    if "ANM6Easy-v0" not in registry:
+        register(id="ANM6Easy-v0", entry_point="gym_anm_amd.envs:ANM6Easy")
+    if "ANM6EasyVec-v0" not in registry:
+        register(id="ANM6EasyVec-v0", entry_point="gym_anm_amd.envs:ANM6EasyVec")
+
+
+_register()

@@ -398,7 +398,8 @@ ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, co
 
 // everything of StepOut except the state / obs rows
 template <class T, int KCAP>
-ANM_HD void store_step_scalars(const EnvIO& io, int64_t e, const StepOut<T, KCAP>& o) {
+ANM_HD void store_step_scalars(const EnvIO& io, int64_t e, const StepOut<T, KCAP>& o, bool have_ts = false,
+                               int32_t ts_prev = 0) {  // have_ts: the caller already read timestep[e]
   if (o.write_soc) static_for<0, T::NDES>([&](auto I) { io.soc[e * T::NDES + I] = o.soc[I]; });
   if (o.terminated >= 0) io.terminated[e] = uint8_t(o.terminated);
   io.reward[e] = o.reward;
@@ -409,7 +410,7 @@ ANM_HD void store_step_scalars(const EnvIO& io, int64_t e, const StepOut<T, KCAP
   if (io.nr_iters) io.nr_iters[e] = o.n_iter;
   if (io.timestep) {
     if (o.timestep_op == 1) io.timestep[e] = 0;
-    else if (o.timestep_op == 2) io.timestep[e] += 1;
+    else if (o.timestep_op == 2) io.timestep[e] = (have_ts ? ts_prev : io.timestep[e]) + 1;
   }
   if (o.inc_reset) io.reset_count[e] += 1;
 }
@@ -525,6 +526,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   const bool valid = e < n;
   const int64_t ec = valid ? e : n - 1;
   const int rows = int((n - e0) < 64 ? (n - e0) : 64);
+  ANM_PHASE(7);  // kernel entry
   StepIn<T> in;
   StepOut<T, 1> out;
   StepCtx<T> ctx;
@@ -534,10 +536,18 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   {
     const double* g = io.action + e0 * D::ADIM;
     constexpr int AP = D::ADIM + 1;
-    for (int j = 0; j < D::ADIM; ++j) {
-      const int idx = j * 64 + lane;
-      if (idx < rows * D::ADIM) lds[(idx / D::ADIM) * AP + (idx % D::ADIM)] = g[idx];
-    }
+    // all loads are issued before the first use (one exposed memory latency, not ADIM of them):
+    // out-of-range lanes re-read the last element instead of branching around the load
+    const int last = rows * D::ADIM - 1;
+    double tmp[D::ADIM > 0 ? D::ADIM : 1];
+    static_for<0, D::ADIM>([&](auto J) {
+      const int idx = J * 64 + lane;
+      tmp[J] = g[idx < last ? idx : last];
+    });
+    static_for<0, D::ADIM>([&](auto J) {
+      const int idx = J * 64 + lane;
+      if (idx <= last) lds[(idx / D::ADIM) * AP + (idx % D::ADIM)] = tmp[J];
+    });
     ANM_WAVE_SYNC();
     const int lr = valid ? lane : rows - 1;
     static_for<0, D::ADIM>([&](auto I) { in.action[I] = lds[lr * AP + I]; });
@@ -547,6 +557,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
   in.aux_prev = double(io.aux_index[ec]);
   in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
+  const int32_t ts_prev = io.timestep ? io.timestep[ec] : 0;  // read now: the epilogue only stores
 
   const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
   step_begin<T, JT>(C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
@@ -574,7 +585,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
   const bool store = valid && !pending;
   if (store) {
-    store_step_scalars<T, 1>(io, e, out);
+    store_step_scalars<T, 1>(io, e, out, true, ts_prev);
     if (out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
   }
   // ---- coalesced stores of the state and obs rows
@@ -582,14 +593,18 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
     const unsigned long long mask = __ballot(wr && store);
     static_for<0, S>([&](auto K) { lds[lane * SP + K] = row[K]; });
     ANM_WAVE_SYNC();
-    int l = lane / S, k = lane % S;  // element (row l, column k) of flat index j*64 + lane
-    constexpr int dq = 64 / S, dr = 64 % S;
-    for (int j = 0; j < S; ++j) {
-      if ((mask >> l) & 1ull) gbase[j * 64 + lane] = lds[l * SP + k];
-      l += dq;
-      k += dr;
-      if (k >= S) { k -= S; ++l; }
-    }
+    // element j*64 + lane of the block is (row l, column k); all LDS reads first, then the stores
+    double v[S];
+    bool on[S];
+    static_for<0, S>([&](auto J) {
+      const int idx = J * 64 + lane;
+      const int l = idx / S, k = idx - l * S;
+      v[J] = lds[l * SP + k];
+      on[J] = ((mask >> l) & 1ull) != 0;
+    });
+    static_for<0, S>([&](auto J) {
+      if (on[J]) gbase[J * 64 + lane] = v[J];
+    });
     ANM_WAVE_SYNC();
   };
   store_rows(io.state + e0 * S, out.state, out.write_state);

@@ -544,9 +544,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     br_pf = vfr * br_ifr + vfi * br_ifi;
     br_qf = vfi * br_ifr - vfr * br_ifi;
     const double pt = vtr * itr + vti * iti, qt = vti * itr - vtr * iti;
-    const double sf = sqrt(br_pf * br_pf + br_qf * br_qf), st = sqrt(pt * pt + qt * qt);
+    const double sf2 = br_pf * br_pf + br_qf * br_qf, st2 = pt * pt + qt * qt;   // one root: see flows_and_reward
     const double sgn = (br_pf > 0.0) ? 1.0 : ((br_pf < 0.0) ? -1.0 : ((br_pf == 0.0) ? 0.0 : NAN));
-    const double smax = (sf != sf || st != st) ? NAN : fmax(sf, st);
+    const double smax = (sf2 != sf2 || st2 != st2) ? NAN : sqrt(fmax(sf2, st2));
     br_s = sgn * smax;
     const double over = fabs(br_s) - RD(DF_BRC + 8);
     pen += (over != over) ? NAN : fmax(0.0, over);

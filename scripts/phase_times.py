@@ -14,7 +14,7 @@ env.reset(seed=1)
 g = torch.Generator(device="cuda:0").manual_seed(0)
 lo = torch.as_tensor(env.action_space.low, device="cuda:0"); hi = torch.as_tensor(env.action_space.high, device="cuda:0")
 acc = None
-names = ["loads+inputs", "device maps+bus sums", "initial eval", "NR loop", "flows+reward", "finish+stores"]
+names = ["inputs -> exo/action", "device maps+bus sums", "Newton loop", "(loop exit)", "flows+reward", "finish+stores"]
 lib = env.simulator.backend.lib
 for it in range(12):
     a = lo + (hi - lo) * torch.rand((E, 6), generator=g, dtype=torch.float64, device="cuda:0")
@@ -26,9 +26,13 @@ for it in range(12):
     d = np.diff(buf[:7].astype(np.int64), axis=0)  # [6, waves]
     if it >= 2:
         acc = d if acc is None else acc + d
+        pre = (buf[0].astype(np.int64) - buf[7].astype(np.int64))
+        acc_pre = pre if it == 2 else acc_pre + pre
         n = it - 1
 tot = (buf[6].astype(np.int64) - buf[0].astype(np.int64))
 print("max_iter", mi, "clock ticks (s_memtime, 100 MHz?) per wave; mean / median / max over waves, averaged over steps")
+x = acc_pre / n
+print("%-22s mean %9.0f  median %9.0f  max %9.0f" % ("entry -> rows loaded", x.mean(), np.median(x), x.max()))
 for k, nm in enumerate(names):
     x = acc[k] / n
     print("%-22s mean %9.0f  median %9.0f  max %9.0f" % (nm, x.mean(), np.median(x), x.max()))
