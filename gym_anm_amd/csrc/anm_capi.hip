@@ -75,7 +75,11 @@ __global__ __launch_bounds__(BLOCK) void k_step_stragglers(cptr_t C, EnvIO io, S
 
 __global__ void k_step_scatter(EnvIO io) { op_step_scatter<Topo>(io); }
 
-__global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__ full, int n_obs,
+// obs[e, k] = clip(src(e, index[k]) * scale[k], low[k], high[k]); src is the `full` row for
+// index < full_dim and the aux tail of the state row beyond it; terminated environments observe 0
+// (anm_env.py:365-367, 442-446)
+__global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__ full, int state_dim, int K,
+                             const double* __restrict__ state, const uint8_t* __restrict__ terminated, int n_obs,
                              const int32_t* __restrict__ index, const double* __restrict__ scale,
                              const double* __restrict__ low, const double* __restrict__ high,
                              double* __restrict__ obs) {
@@ -83,8 +87,10 @@ __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__
   for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += int64_t(gridDim.x) * blockDim.x) {
     const int64_t e = t / n_obs;
     const int k = int(t - e * n_obs);
-    const double v = full[e * full_dim + index[k]] * scale[k];
-    obs[t] = fmin(fmax(v, low[k]), high[k]);
+    const int idx = index[k];
+    const double src = (idx < full_dim) ? full[e * full_dim + idx] : state[e * state_dim + (state_dim - K) + (idx - full_dim)];
+    const double v = fmin(fmax(src * scale[k], low[k]), high[k]);
+    obs[t] = (terminated && terminated[e]) ? 0.0 : v;
   }
 }
 
@@ -451,7 +457,8 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   return 0;
 }
 
-static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solver_opts* opts, hipStream_t s) {
+static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_solver_opts* opts, hipStream_t s) {
+  EnvIO io = io_in;
   int prec;
   SolverOpts so = solver(opts, prec);
   if (m->impl == ANM_IMPL_RADIAL) {
@@ -461,7 +468,8 @@ static int launch_step(anm_model* m, const EnvIO& io, int64_t n, const anm_solve
     return launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
-  if (io.aux_index && io.exo == nullptr && io.K == 1 && io.full == nullptr) {
+  if (io.aux_index && io.exo == nullptr && io.K == 1) {
+    if (io.full) io.ws = nullptr;  // the straggler launch has no `full` output: one launch then
     if (prec == ANM_SOLVE_F32)
       hipLaunchKernelGGL(k_step_rows<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
     else
@@ -541,14 +549,16 @@ int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double
   return 0;
 }
 
-int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t n_obs, const int32_t* index,
+int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t state_dim, int32_t K,
+                       const double* state, const uint8_t* terminated, int32_t n_obs, const int32_t* index,
                        const double* scale, const double* low, const double* high, double* obs, void* stream) {
-  if (n <= 0 || n_obs <= 0) return 0;
   if (!full || !index || !scale || !low || !high || !obs) return fail("anm_gather_obs_f64: null argument");
+  if (K > 0 && !state) return fail("anm_gather_obs_f64: aux variables need the state array");
+  if (n <= 0 || n_obs <= 0) return 0;
   const int64_t total = n * n_obs;
   unsigned grid = unsigned(std::min<int64_t>((total + 255) / 256, 2048));
   hipLaunchKernelGGL(k_gather_obs, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), n, full_dim, full,
-                     n_obs, index, scale, low, high, obs);
+                     state_dim, K, state, terminated, n_obs, index, scale, low, high, obs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_gather_obs");
   return 0;

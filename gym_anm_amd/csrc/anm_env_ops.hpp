@@ -587,6 +587,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   if (store) {
     store_step_scalars<T, 1>(io, e, out, true, ts_prev);
     if (out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
+    if (io.full && out.write_state) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
   }
   // ---- coalesced stores of the state and obs rows
   auto store_rows = [&](double* gbase, const double* row, bool wr) {

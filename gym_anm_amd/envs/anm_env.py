@@ -320,12 +320,10 @@ class BatchedANMEnv(GymEnv):
         n_obs = index.numel()
         if self._obs_buf is None:
             self._obs_buf = torch.zeros((self.num_envs, n_obs), dtype=torch.float64, device=self.device)
-        full = sim.full
-        if self.K > 0:
-            full = torch.cat([sim.full, self.state[:, self.state_N - self.K :]], dim=1).contiguous()
         with sim._device_ctx():
             rc = sim.backend.lib.anm_gather_obs_f64(
-                self.num_envs, full.shape[1], full.data_ptr(), n_obs, index.data_ptr(), scale.data_ptr(),
+                self.num_envs, sim.full.shape[1], sim.full.data_ptr(), self.state.shape[1], self.K,
+                self.state.data_ptr(), self._term_u8.data_ptr(), n_obs, index.data_ptr(), scale.data_ptr(),
                 low.data_ptr(), high.data_ptr(), self._obs_buf.data_ptr(), _stream_ptr(self.device),
             )  # fmt: skip
         sim.backend.check(rc, "anm_gather_obs_f64")
@@ -493,9 +491,7 @@ class BatchedANMEnv(GymEnv):
         if self._obs_is_state:
             obs = self._state_obs
         else:
-            obs = self.observation(self.state)
-            if self._gather is not None:
-                obs = torch.where(self._term_bool.unsqueeze(1), torch.zeros_like(obs), obs)
+            obs = self.observation(self.state)  # the gather kernel zeroes the rows of terminated environments
         return obs, self.reward, self._term_bool, self._truncated, {}
 
     def render(self, mode="human"):

@@ -193,11 +193,14 @@ int anm_step_f64(anm_model* m, int64_t num_envs, const double* action, const dou
                  uint64_t env_offset, int32_t* reset_count, int32_t* aux_index, const anm_step_ws* ws,
                  const anm_solver_opts* opts, void* stream);
 
-/* obs[e, k] = clip(full[e, index[k]] * scale[k], low[k], high[k]) for k < n_obs: the list form of
- * the observation space (anm_env.py:497-521,562-592).  index/scale/low/high are dev arrays. */
-int anm_gather_obs_f64(int64_t num_envs, int32_t full_dim, const double* full, int32_t n_obs,
-                       const int32_t* index, const double* scale, const double* low,
-                       const double* high, double* obs, void* stream);
+/* obs[e, k] = clip(src(e, index[k]) * scale[k], low[k], high[k]) for k < n_obs: the list form of
+ * the observation space (anm_env.py:497-521,562-592).  src(e, i) = full[e, i] for i < full_dim and
+ * the aux variable state[e, state_dim - K + (i - full_dim)] beyond it (state may be NULL if K = 0).
+ * With `terminated` non-NULL the rows of terminated environments are 0 (anm_env.py:365-367).
+ * index/scale/low/high are dev arrays of n_obs entries. */
+int anm_gather_obs_f64(int64_t num_envs, int32_t full_dim, const double* full, int32_t state_dim, int32_t K,
+                       const double* state, const uint8_t* terminated, int32_t n_obs, const int32_t* index,
+                       const double* scale, const double* low, const double* high, double* obs, void* stream);
 
 /* Offsets of each quantity inside one row of `full` (p.u. / rad), in the order of the reference's
  * STATE_VARIABLES (constants.py:31-48): bus_p, bus_q, bus_v_magn, bus_v_ang, bus_i_magn,

@@ -1,0 +1,41 @@
+"""Step time by observation mode: "state" (fused rows kernel) vs a list-form observation (plain step
+kernel with the full electrical-state dump + gather kernel).  ANM6Easy, random agent."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gym_anm_amd.envs import ANM6EasyVec
+
+import numpy as np
+from gym_anm_amd.envs.anm6 import ANM6Vec, anm6easy_series
+
+
+class ListObs(ANM6EasyVec):
+    """ANM6Easy with a list-form observation instead of "state"."""
+
+    def __init__(self, observation, num_envs=1, device="cuda", seed=None, **kw):
+        self.P_loads = anm6easy_series()[:3]
+        self.P_maxs = anm6easy_series()[3:]
+        ANM6Vec.__init__(self, observation, 1, 0.25, 0.995, 100, aux_bounds=np.array([[0, 95]]), costs_clipping=(1, 100),
+                         seed=seed, num_envs=num_envs, device=device, series=anm6easy_series(), **kw)
+
+dev = torch.device("cuda", 0)
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+for cap in (20, 100):
+    for mode in ("state", "list"):
+        kw = dict(num_envs=E, device=dev, seed=1, tol=1e-6, max_iter=cap, autoreset=True)
+        if mode == "list":
+            obs = [("bus_v_magn", "all", "pu"), ("branch_s", "all", "MVA"), ("des_soc", "all", "MWh"), ("aux", "all", None)]
+            env = ListObs(obs, **kw)
+        else:
+            env = ANM6EasyVec(**kw)
+        env.check_actions = False
+        env.reset(seed=1)
+        g = torch.Generator(device=dev).manual_seed(0)
+        lo = torch.as_tensor(env.action_space.low, device=dev); hi = torch.as_tensor(env.action_space.high, device=dev)
+        pool = [lo + (hi - lo) * torch.rand((E, 6), generator=g, dtype=torch.float64, device=dev) for _ in range(8)]
+        for i in range(10): env.step(pool[i % 8])
+        torch.cuda.synchronize()
+        t = time.perf_counter(); n = 100
+        for i in range(n): env.step(pool[i % 8])
+        torch.cuda.synchronize()
+        print("E=%d cap=%3d obs=%-5s %.1f us/step" % (E, cap, mode, (time.perf_counter() - t) / n * 1e6), flush=True)

@@ -155,12 +155,15 @@ int anm_time_step_launches(anm_model*, int64_t, const double*, double*, double*,
   return fail("hostsim: no device timing");
 }
 
-int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t n_obs, const int32_t* index,
-                       const double* scale, const double* low, const double* high, double* obs, void*) {
+int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t state_dim, int32_t K, const double* state,
+                       const uint8_t* terminated, int32_t n_obs, const int32_t* index, const double* scale,
+                       const double* low, const double* high, double* obs, void*) {
   for (int64_t e = 0; e < n; ++e)
     for (int k = 0; k < n_obs; ++k) {
-      const double v = full[e * full_dim + index[k]] * scale[k];
-      obs[e * n_obs + k] = std::fmin(std::fmax(v, low[k]), high[k]);
+      const int idx = index[k];
+      const double src = (idx < full_dim) ? full[e * full_dim + idx] : state[e * state_dim + (state_dim - K) + (idx - full_dim)];
+      const double v = std::fmin(std::fmax(src * scale[k], low[k]), high[k]);
+      obs[e * n_obs + k] = (terminated && terminated[e]) ? 0.0 : v;
     }
   return 0;
 }
