@@ -519,17 +519,22 @@ def test_device_sampler_reset(impl):
     assert bool(((o >= low) & (o <= high)).all())
 
 
+@pytest.mark.parametrize("small_workspace", [False, True])
 @pytest.mark.parametrize("cap_after", [1, 4, 8])
-def test_two_phase_step_is_bit_identical(cap_after):
+def test_two_phase_step_is_bit_identical(cap_after, small_workspace):
     """The two-launch step (first launch stops after `cap_after` Newton iterations, the solves still
     running are continued by the straggler launch) returns bit-identical results to the one-launch
-    step, including in-kernel autoreset, on 65 536 environments."""
+    step, including in-kernel autoreset, on 65 536 environments -- also when the record workspace is too
+    small for all the stragglers (the ones without a slot are finished by the first launch itself)."""
     from gym_anm_amd.envs import ANM6EasyVec
 
     E_ = 65536
     envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=9, autoreset=True, tol=1e-6, straggler_after=sa)
             for sa in (None, cap_after)]  # fmt: skip
     assert envs[0]._ws is None and envs[1]._ws is not None
+    if small_workspace:
+        rec = envs[1].simulator.backend.lib.anm_step_ws_record_doubles()
+        envs[1]._ws.n_doubles = 8 + 100 * rec  # room for 100 records; ~400 environments diverge per step
     for env in envs:
         env.check_actions = False
         env.reset(seed=9)
