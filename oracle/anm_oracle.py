@@ -416,6 +416,13 @@ class OracleEnv:
         self.last = out
         return np.clip(self.state, self.obs_low, self.obs_high), out["converged"]
 
+    def load_state(self, state, soc_pu):
+        """Continue from a given (non-terminal) state vector and storage SoC in p.u. (test helper: lets a
+        test replay a few steps of a long device run; the reference has no counterpart)."""
+        self.state = np.asarray(state, dtype=float).copy()
+        self.soc = np.atleast_1d(np.asarray(soc_pu, dtype=float)).copy()
+        self.terminated = False
+
     def step(self, action):
         """anm_env.py:333-453 with ANM6Easy.next_vars (anm6_easy.py:54-65)."""
         n = self.n

@@ -552,3 +552,57 @@ def test_two_phase_step_is_bit_identical(cap_after, small_workspace):
                        (envs[0]._reset_count, envs[1]._reset_count), (envs[0]._aux_index, envs[1]._aux_index)):  # fmt: skip
             assert torch.equal(x0, x1), t
     assert n_term > 100  # the workload did produce diverging solves
+
+
+def test_long_run_invariants():
+    """3 000 steps of 65 536 autoresetting environments under a random agent: observations stay finite
+    and inside the Box, rewards inside the clipping range, every environment keeps cycling through
+    collapse -> reset, and a sample of environments replayed by the oracle from a late snapshot still
+    agrees (no slow drift of the persistent state)."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    import anm_oracle as O
+
+    E_ = 65536
+    env = ANM6EasyVec(num_envs=E_, device=DEV, seed=3, autoreset=True, tol=1e-6)
+    env.check_actions = False
+    env.reset(seed=3)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    lo = torch.as_tensor(env.action_space.low, device=DEV)
+    hi = torch.as_tensor(env.action_space.high, device=DEV)
+    olo = torch.as_tensor(env.observation_space.low, device=DEV)
+    ohi = torch.as_tensor(env.observation_space.high, device=DEV)
+    r_min = -env.costs_clipping[1] / (1 - env.gamma)
+    n_term = torch.zeros((), dtype=torch.int64, device=DEV)
+    for t in range(3000):
+        a = lo + (hi - lo) * torch.rand((E_, 6), generator=gen, dtype=torch.float64, device=DEV)
+        obs, rew, term, _, _ = env.step(a)
+        n_term += term.sum()
+        if t % 500 == 499:
+            assert bool(torch.isfinite(obs).all()) and bool(((obs >= olo) & (obs <= ohi)).all())
+            assert bool(torch.isfinite(rew).all()) and bool((rew <= 1.0 + 1e-12).all()) and bool((rew >= r_min - 1e-9).all())
+    frac = float(n_term) / (3000 * E_)
+    assert 0.003 < frac < 0.01, frac  # ~0.6 % of the random-agent steps collapse
+    assert int(env._reset_count.min()) >= 1 and int(env.timestep.max()) < 3000
+    # replay 16 live environments for 5 more steps with the oracle, starting from the device state
+    idx = torch.nonzero(~env.terminated)[:16, 0]
+    oracles = []
+    for i in idx.tolist():
+        o = O.OracleEnv(networks.anm6_network(), sparse=False, tol=1e-6)
+        o.load_state(env.state[i].cpu().numpy(), float(env.simulator.soc[i, 0]))
+        o.done = False
+        oracles.append(o)
+    for _ in range(5):
+        a = lo + (hi - lo) * torch.rand((E_, 6), generator=gen, dtype=torch.float64, device=DEV)
+        obs, rew, term, _, _ = env.step(a)
+        for o, i in zip(oracles, idx.tolist()):
+            if o.done:
+                continue
+            oo, rr, tt = o.step(a[i].cpu().numpy())
+            assert bool(term[i]) == tt
+            if tt:
+                o.done = True
+                continue
+            np.testing.assert_allclose(obs[i].cpu().numpy(), oo, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(float(rew[i]), rr, rtol=1e-9, atol=1e-12)
