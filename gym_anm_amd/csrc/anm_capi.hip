@@ -62,10 +62,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(cptr_t C, EnvIO io, SolverOpts s
 }
 
 // coalesced-row variant of k_step (series mode, K = 1, no full dump): see op_step_rows
-template <class JT>
+template <class JT, bool FULL>
 __global__ __launch_bounds__(BLOCK, ANM_ROWS_WAVES) void k_step_rows(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
   __shared__ double lds[64 * (Topo::SDIM + 2)];
-  op_step_rows<Topo, JT>(C, io, so, n, lds);
+  op_step_rows<Topo, JT, FULL>(C, io, so, n, lds);
 }
 
 template <class JT>
@@ -470,10 +470,16 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
   cptr_t C = (cptr_t)m->d_const;
   if (io.aux_index && io.exo == nullptr && io.K == 1) {
     if (io.full) io.ws = nullptr;  // the straggler launch has no `full` output: one launch then
-    if (prec == ANM_SOLVE_F32)
-      hipLaunchKernelGGL(k_step_rows<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
-    else
-      hipLaunchKernelGGL(k_step_rows<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    if (io.full) {
+      if (prec == ANM_SOLVE_F32)
+        hipLaunchKernelGGL((k_step_rows<float, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+      else
+        hipLaunchKernelGGL((k_step_rows<double, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    } else if (prec == ANM_SOLVE_F32) {
+      hipLaunchKernelGGL((k_step_rows<float, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    } else {
+      hipLaunchKernelGGL((k_step_rows<double, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    }
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_rows");
     if (io.ws && io.iter_cap < so.max_iter) {

@@ -515,7 +515,9 @@ __device__ int64_t load_record(const double* r, StepCtx<T>& ctx, EnvWork<T>& w, 
 // a fully coalesced 512-byte wave transaction (the plain layer issues 16-byte stores with a 144-byte
 // lane stride: every store instruction touches 64 cache lines and partial lines are written twice).
 // The time index is kept in a compact int32 array instead of being re-read from the state rows.
-template <class T, class JT>
+// FULL: also write the `full` electrical-state dump (a separate instantiation: the dump costs the
+// default kernel its second wave per SIMD)
+template <class T, class JT, bool FULL>
 __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n, double* lds) {
   typedef Dims<T> D;
   constexpr int S = T::SDIM + 1;
@@ -587,7 +589,9 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   if (store) {
     store_step_scalars<T, 1>(io, e, out, true, ts_prev);
     if (out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
-    if (io.full && out.write_state) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+    if constexpr (FULL) {
+      if (io.full && out.write_state) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+    }
   }
   // ---- coalesced stores of the state and obs rows
   auto store_rows = [&](double* gbase, const double* row, bool wr) {
