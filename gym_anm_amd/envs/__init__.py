@@ -2,5 +2,6 @@
 
 from .anm_env import BatchedANMEnv
 from .anm6 import ANM6Vec, ANM6EasyVec, ANM6Easy
+from .vector import NumpyVectorEnv
 
 ANMEnv = BatchedANMEnv

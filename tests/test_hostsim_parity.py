@@ -67,3 +67,47 @@ def test_device_sampler_reset():
     s0 = rng.series_init_state(env.simulator.model, env._series, 21, 1000 + 3, 1)
     o_ref, _ = O.OracleEnv(networks.anm6_network(), sparse=False).reset_to(s0)
     npt.assert_allclose(obs2[3].numpy(), o_ref, rtol=0, atol=1e-9)
+
+
+def test_numpy_vector_env_adapter():
+    """NumpyVectorEnv: NumPy in / NumPy out around a batched environment with Gymnasium's next-step
+    autoreset convention; the step after a collapse returns the first observation of a new episode with
+    reward 0 and terminated False; an action outside the Box raises like the reference."""
+    import anm_oracle as O
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import NumpyVectorEnv
+
+    net = NETS["anm6"]
+    E_ = 32
+    venv = NumpyVectorEnv(ANM6EasyVec(num_envs=E_, device="cpu", seed=5, autoreset=True, _backend=_backend(net)))
+    assert venv.num_envs == E_ and venv.single_action_space.shape == (6,)
+    obs, info = venv.reset(seed=5)
+    assert isinstance(obs, np.ndarray) and obs.shape == (E_, 18) and obs.dtype == np.float64
+    orc = O.OracleEnv(networks.anm6_network(), sparse=False)
+    orc.load_state(venv.env.state[0].numpy(), float(venv.env.simulator.soc[0, 0]))
+    rng_ = np.random.default_rng(0)
+    lo, hi = venv.single_action_space.low, venv.single_action_space.high
+    was_term = np.zeros(E_, dtype=bool)
+    seen_reset = False
+    for t in range(60):
+        a = rng_.uniform(lo, hi, size=(E_, 6))
+        if t == 3:
+            a[:, 2] = 10 * hi[2]  # outside the action Box
+            with pytest.raises(AssertionError):
+                venv.step(a)
+            a[:, 2] = hi[2]
+        obs, rew, term, trunc, info = venv.step(a)
+        assert all(isinstance(x, np.ndarray) for x in (obs, rew, term, trunc)) and not trunc.any()
+        # environments that were terminated at the previous call have been re-initialised by this one
+        if was_term.any():
+            seen_reset = True
+            assert (rew[was_term] == 0).all() and not term[was_term].any()
+            assert (venv.env.timestep.numpy()[was_term] == 0).all()
+        if not orc.terminated:
+            o_ref, r_ref, t_ref = orc.step(a[0])
+            assert bool(term[0]) == t_ref
+            if not t_ref:
+                np.testing.assert_allclose(obs[0], o_ref, rtol=0, atol=1e-9)
+                np.testing.assert_allclose(rew[0], r_ref, rtol=1e-9)
+        was_term = term.copy()
+    assert seen_reset
