@@ -59,3 +59,31 @@ def test_wrong_topology_is_rejected():
     be = hostsim_backend(NetworkModel(networks.two_bus_network(), 0.25, 100).topology())
     with pytest.raises(errors.HipExtensionError, match="built for"):
         BatchedSimulator(networks.anm6_network(), 0.25, 100, num_envs=1, device="cpu", _backend=be)
+
+
+def test_build_is_keyed_by_content_not_by_file_times(tmp_path):
+    """A library is fresh iff its stamp (hash of descriptor + kernel sources + flags) matches: file
+    times do not matter (the built libraries travel to the GPU box with the tree), a stale stamp
+    triggers a rebuild, and two processes asking for the same library at once do not collide."""
+    import subprocess
+    import sys
+    import time
+
+    topo = NetworkModel(networks.two_bus_network(), 0.25, 100).topology()
+    lib = codegen.build_library(topo)
+    stamp = lib + ".stamp"
+    t_built = os.path.getmtime(lib)
+    os.utime(lib, (1, 1))  # an ancient library with a matching stamp is still fresh
+    assert codegen.build_library(topo) == lib and os.path.getmtime(lib) == 1
+    os.utime(lib, (t_built, t_built))
+    good = open(stamp).read()
+    open(stamp, "w").write("stale\n")
+    code = ("import sys; sys.path.insert(0, %r); from gym_anm_amd import codegen, networks; "
+            "from gym_anm_amd.model import NetworkModel; "
+            "print(codegen.build_library(NetworkModel(networks.two_bus_network(), 0.25, 100).topology()))" % ROOT)
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(3)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert open(stamp).read() == good and os.path.getmtime(lib) >= t0 - 1  # rebuilt once, stamp restored
+    assert not [f for f in os.listdir(os.path.dirname(lib)) if f.endswith(".tmp")]
