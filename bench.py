@@ -295,7 +295,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "k_step_rows<double>" if args.precision == "f64" else "k_step_rows<float>",
+                "kernel": "k_step_rows<double, false>" if args.precision == "f64" else "k_step_rows<float, false>",
                 "kernel_ms": kernel_s * 1e3, "launches_timed": args.steps,
                 "kernel_ms_back_to_back": ms.value, "launches_back_to_back": n_launch,
                 "algorithmic_bytes_per_env_step": bytes_per, "valu_fp64_issue": valu,
