@@ -410,13 +410,13 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     ANM_GROUP_SYNC();
     vpr = 1.0; vpi = 0.0;
     if (parent >= 0) { vpr = sh[A_VR][pl]; vpi = sh[A_VI][pl]; }
-    // U = V_b conj(Y_bb), W_bb = U conj(V_b);  U = V_b conj(Y_bp), W_bp = U conj(V_p);  U = V_p conj(Y_pb), W_pb = U conj(V_b)
-    double ur = fma(vr, ybb_r, vi * ybb_i), ui = fma(vi, ybb_r, -(vr * ybb_i));
-    const double wbb_r = fma(ur, vr, ui * vi), wbb_i = fma(ui, vr, -(ur * vi));
-    ur = fma(vr, ybp_r, vi * ybp_i); ui = fma(vi, ybp_r, -(vr * ybp_i));
-    const double wbp_r = fma(ur, vpr, ui * vpi), wbp_i = fma(ui, vpr, -(ur * vpi));
-    ur = fma(vpr, ypb_r, vpi * ypb_i); ui = fma(vpi, ypb_r, -(vpr * ypb_i));
-    wpb_r = fma(ur, vr, ui * vi); wpb_i = fma(ui, vr, -(ur * vi));
+    // W_bb = conj(Y_bb) vm^2;  P = V_b conj(V_p): W_bp = conj(Y_bp) P, W_pb = conj(Y_pb) conj(P)
+    const double m2 = vm * vm;
+    const double wbb_r = ybb_r * m2, wbb_i = -(ybb_i * m2);
+    const double pr = fma(vr, vpr, vi * vpi), pim = fma(vi, vpr, -(vr * vpi));
+    const double wbp_r = fma(ybp_r, pr, ybp_i * pim), wbp_i = fma(ybp_r, pim, -(ybp_i * pr));
+    wpb_r = fma(ypb_r, pr, -(ypb_i * pim));
+    wpb_i = -fma(ypb_r, pim, ypb_i * pr);
     sh[A_UPR][t] = wpb_r;
     sh[A_UPI][t] = wpb_i;
     ANM_GROUP_SYNC();
