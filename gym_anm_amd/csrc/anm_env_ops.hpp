@@ -454,7 +454,7 @@ ANM_HD void op_step(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
 // ---------------------------------------------------------------------------------------------
 template <class T>
 struct Rec {
-  static constexpr int E = 0, IT = 1, RESET = 2, AUX = 3, SOCREQ = 4, TH = SOCREQ + T::NDES, VM = TH + T::NB,
+  static constexpr int E = 0, IT = 1, RESET = 2, AUX = 3, SOCREQ = 4, VM = SOCREQ + T::NDES,
                        CS = VM + T::NB, SN = CS + T::NB, BUSP = SN + T::NB, BUSQ = BUSP + T::NB, DEVP = BUSQ + T::NB,
                        DEVQ = DEVP + T::ND, PPOT = DEVQ + T::ND, SOC = PPOT + T::NGEN, IN_SIZE = SOC + T::NDES,
                        OUT_SIZE = 2 * (T::SDIM + 1) + T::NDES + 8,  // ResRec<T>::SIZE
@@ -479,7 +479,7 @@ __device__ void save_record(double* r, int64_t e, const StepCtx<T>& ctx, const E
   r[R::AUX] = double(ctx.aux);
   static_for<0, T::NDES>([&](auto I) { r[R::SOCREQ + I] = ctx.soc_req[I]; r[R::SOC + I] = w.soc[I]; });
   static_for<0, T::NB>([&](auto I) {
-    r[R::TH + I] = w.th[I]; r[R::VM + I] = w.vm[I]; r[R::CS + I] = st.cs[I]; r[R::SN + I] = st.sn[I];
+    r[R::VM + I] = w.vm[I]; r[R::CS + I] = st.cs[I]; r[R::SN + I] = st.sn[I];
     r[R::BUSP + I] = w.bus_p[I]; r[R::BUSQ + I] = w.bus_q[I];
   });
   static_for<0, T::ND>([&](auto I) { r[R::DEVP + I] = w.dev_p[I]; r[R::DEVQ + I] = w.dev_q[I]; });
@@ -495,7 +495,7 @@ __device__ int64_t load_record(const double* r, StepCtx<T>& ctx, EnvWork<T>& w, 
   ctx.aux = int(r[R::AUX]);
   static_for<0, T::NDES>([&](auto I) { ctx.soc_req[I] = r[R::SOCREQ + I]; w.soc[I] = r[R::SOC + I]; });
   static_for<0, T::NB>([&](auto I) {
-    w.th[I] = r[R::TH + I]; w.vm[I] = r[R::VM + I]; st.cs[I] = r[R::CS + I]; st.sn[I] = r[R::SN + I];
+    w.vm[I] = r[R::VM + I]; st.cs[I] = r[R::CS + I]; st.sn[I] = r[R::SN + I];
     w.bus_p[I] = r[R::BUSP + I]; w.bus_q[I] = r[R::BUSQ + I];
   });
   static_for<0, T::ND>([&](auto I) { w.dev_p[I] = r[R::DEVP + I]; w.dev_q[I] = r[R::DEVQ + I]; });

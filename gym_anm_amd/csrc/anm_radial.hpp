@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   // ---------------- Newton-Raphson (lane = bus) ----------------------------------------------
   const double ybb_r = RD(DF_YBB_RE), ybb_i = RD(DF_YBB_IM), ybp_r = RD(DF_YBP_RE), ybp_i = RD(DF_YBP_IM);
   const double ypb_r = RD(DF_YPB_RE), ypb_i = RD(DF_YPB_IM);
-  double th = 0.0, vm = 1.0, cs = 1.0, sn = 0.0;
+  double vm = 1.0, cs = 1.0, sn = 0.0;
   double vr = 1.0, vi = 0.0, ir = 0.0, ii = 0.0, vpr = 1.0, vpi = 0.0;
   int it = 0;
   double diff = 0.0;
@@ -483,21 +483,21 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     }
     // ---- update (group-uniform `active`); d1 is the relative magnitude step
     if (active && isbus) {
+      // rotation of (cos, sin) by the angle step, see update_angles (anm_device.hpp)
       const double dth = double(d0);
       vm = fma(-double(d1), fabs(vm), vm);
-      th -= dth;
+      double sd_, cd_;
       if (fabs(dth) <= 0.78) {
-        double sd_, cd_;
         sincos_kernel(dth, 0, sd_, cd_);
-        const double c0 = cs, s0v = sn;
-        cs = fma(c0, cd_, s0v * sd_);
-        sn = fma(s0v, cd_, -(c0 * sd_));
-      } else if (fabs(th) < 4.0e15) {
-        sincos_medium(th, sn, cs);
+      } else if (fabs(dth) < 4.0e15) {
+        sincos_medium(dth, sd_, cd_);
       } else {
-        const SinCos r = sincos_huge(th);
-        sn = r.s; cs = r.c;
+        const SinCos r = sincos_huge(dth);
+        sd_ = r.s; cd_ = r.c;
       }
+      const double c0 = cs, s0v = sn;
+      cs = fma(c0, cd_, s0v * sd_);
+      sn = fma(s0v, cd_, -(c0 * sd_));
     }
     it = active ? it + 1 : it;
   }
