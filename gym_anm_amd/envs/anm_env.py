@@ -30,7 +30,7 @@ import torch
 
 from .. import _lib
 from .. import errors as E
-from ..model import CLASSICAL, RENEWABLE, STORAGE, STATE_VARIABLES
+from ..model import STATE_VARIABLES
 from ..simulator import BatchedSimulator, _stream_ptr
 from ..spaces import Box, GymEnv
 

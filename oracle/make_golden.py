@@ -39,7 +39,7 @@ ref_harness.load_reference()
 
 from gym_anm.simulator import Simulator  # noqa: E402
 from gym_anm.simulator import solve_load_flow as slf  # noqa: E402
-from gym_anm.simulator.components import Load, Generator, StorageUnit, RenewableGen  # noqa: E402
+from gym_anm.simulator.components import Load, Generator, StorageUnit  # noqa: E402
 from gym_anm.envs import ANM6Easy  # noqa: E402
 
 from gym_anm_amd import networks  # noqa: E402  (network *data* only)

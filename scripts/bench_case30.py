@@ -2,7 +2,7 @@
 launch per step, both kernel families; also ANM6 through the lane-group family for comparison."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from gym_anm_amd import networks
 from gym_anm_amd.simulator import BatchedSimulator
 DEV = "cuda:0"
