@@ -261,8 +261,8 @@ struct StepCtx {
 };
 
 // first half of a step: inputs -> device maps, bus sums, up to `iter_cap` Newton iterations
-template <class T, class JT>
-ANM_HD void step_begin(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepIn<T>& in, StepCtx<T>& ctx,
+template <class T, class JT, class CD>
+ANM_HD void step_begin(cptr_t C, CD Cd, const EnvIO& io, SolverOpts so, int64_t e, const StepIn<T>& in, StepCtx<T>& ctx,
                        EnvWork<T>& w, PFState<T>& st, int iter_cap) {
   typedef Layout<T> L;
   const bool series = io.exo == nullptr;
@@ -308,7 +308,7 @@ ANM_HD void step_begin(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, cons
   ctx.aux = aux;
   // 3. one simulator transition, shared by the step and the autoreset path
   ANM_PHASE(1);
-  transition_begin<T, JT>(C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, iter_cap);
+  transition_begin<T, JT>(C, Cd, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, iter_cap);
   (void)L::TOTAL;
 }
 
@@ -392,7 +392,7 @@ ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, co
                          StepOut<T, KCAP>& out, EnvWork<T>& w) {
   StepCtx<T> ctx;
   PFState<T> st;
-  step_begin<T, JT>(C, io, so, e, in, ctx, w, st, so.max_iter);
+  step_begin<T, JT>(C, C, io, so, e, in, ctx, w, st, so.max_iter);
   step_end<T, KCAP>(C, io, so, e, ctx, w, st, out);
 }
 
@@ -562,7 +562,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   const int32_t ts_prev = io.timestep ? io.timestep[ec] : 0;  // read now: the epilogue only stores
 
   const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
-  step_begin<T, JT>(C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
+  step_begin<T, JT>(C, C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
   bool pending = false;
   int cap = two_phase ? io.iter_cap : so.max_iter;
   // One copy of the Newton loop serves both passes (a second inlined copy costs registers and code):
