@@ -51,7 +51,7 @@ def cpu_baseline(budget_s=12.0, all_cores=True):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cpu_bench
 
-    n, dt = cpu_bench.run(budget_s, seed=0)
+    n, dt, _ = cpu_bench.run(budget_s, seed=0)
     out = {
         "value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": "%d sequential ANM6Easy env-steps (%.1f s) of oracle/anm_oracle.py, scipy.sparse Jacobian + spsolve "
@@ -68,6 +68,17 @@ def cpu_baseline(budget_s=12.0, all_cores=True):
                                           "the processes received / wall" % (tot, n_proc, slow, wall)}  # fmt: skip
         except Exception as ex:  # the 1-core figure is the contract; never lose the line over this
             out["all_cores"] = {"error": str(ex)[:200]}
+        # upper bound for a compiled CPU port: the kernel templates built for the host (g++ -O2), SURVEY 8(d)
+        try:
+            n2, dt2, _ = cpu_bench.run_cpp(3.0)
+            tot, slow, n_proc, wall, eff = cpu_bench.run_all_cores(4.0, impl="cpp")
+            out["cpp_port"] = {"value": n2 / dt2, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                               "all_cores": {"value": tot / slow, "cores": n_proc, "effective_cores": round(eff, 1)},
+                               "sample": "tests/hostsim (the HIP kernel templates compiled with g++ -O2), 2048 "
+                                         "environments per step, %d env-steps in %.1f s on one core; then one process "
+                                         "per usable core for 4 s" % (n2, dt2)}  # fmt: skip
+        except Exception as ex:
+            out["cpp_port"] = {"error": str(ex)[:200]}
     return out
 
 

@@ -48,13 +48,41 @@ def run(budget_s, seed=0):
         env.reset_to(s0)
 
     reset()
-    n, t0 = 0, time.perf_counter()
+    n, t0, c0 = 0, time.perf_counter(), time.process_time()
     while time.perf_counter() - t0 < budget_s:
         _, _, term = env.step(rng.uniform(lo, hi))
         n += 1
         if term:
             reset()
-    return n, time.perf_counter() - t0
+    return n, time.perf_counter() - t0, time.process_time() - c0
+
+
+def run_cpp(budget_s, seed=0, num_envs=2048):
+    """Second CPU figure: the kernel templates themselves compiled for the host with g++ -O2
+    (tests/hostsim, the test double of the CPU tier), single-threaded loop over `num_envs` environments
+    per step, random agent with in-"kernel" autoreset -- an upper bound for a compiled CPU port."""
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from hostsim_backend import hostsim_backend
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import ANM6EasyVec
+    from gym_anm_amd.model import NetworkModel
+
+    torch.set_num_threads(1)
+    be = hostsim_backend(NetworkModel(networks.anm6_network(), 0.25, 100).topology())
+    env = ANM6EasyVec(num_envs=num_envs, device="cpu", seed=seed, autoreset=True, tol=1e-5, _backend=be)
+    env.check_actions = False
+    env.reset(seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = torch.as_tensor(env.action_space.low), torch.as_tensor(env.action_space.high)
+    pool = [lo + (hi - lo) * torch.rand((num_envs, 6), generator=g, dtype=torch.float64) for _ in range(4)]
+    env.step(pool[0])
+    n, t0, c0 = 0, time.perf_counter(), time.process_time()
+    while time.perf_counter() - t0 < budget_s:
+        env.step(pool[n % 4])
+        n += 1
+    return n * num_envs, time.perf_counter() - t0, time.process_time() - c0
 
 
 def usable_cores():
@@ -80,13 +108,13 @@ def usable_cores():
     return n
 
 
-def run_all_cores(budget_s, n_proc=None):
-    """One independent process per usable host core, each stepping its own environment for `budget_s`."""
+def run_all_cores(budget_s, n_proc=None, impl="numpy"):
+    """One independent process per usable host core, each stepping its own environment(s) for `budget_s`."""
     import subprocess
 
     n_proc = n_proc or usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--seconds", str(budget_s)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--seconds", str(budget_s), "--impl", impl]
     t0 = time.perf_counter()
     procs = [subprocess.Popen(cmd + ["--seed", str(100 + i)], stdout=subprocess.PIPE, env=env) for i in range(n_proc)]
     total, slowest, cpu = 0, 0.0, 0.0
@@ -104,7 +132,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--impl", choices=["numpy", "cpp"], default="numpy")
     a = ap.parse_args()
-    c0 = time.process_time()
-    n, dt = run(a.seconds, a.seed)
-    print(json.dumps({"steps": n, "seconds": dt, "cpu_seconds": time.process_time() - c0}))
+    n, dt, cpu = (run if a.impl == "numpy" else run_cpp)(a.seconds, a.seed)
+    print(json.dumps({"steps": n, "seconds": dt, "cpu_seconds": cpu}))
