@@ -48,11 +48,11 @@ class EnvConfig(C.Structure):
 
 
 class StepWs(C.Structure):
-    _fields_ = [("buf", C.c_void_p), ("n_doubles", C.c_int64), ("iter_cap", C.c_int32), ("parity", C.c_int32)]
+    _fields_ = [("buf", C.c_void_p), ("n_doubles", C.c_int64), ("iter_cap", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SolverOpts(C.Structure):
-    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32)]
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32), ("handoff_after", C.c_int32)]
 
 
 FULL_FIELDS = ["bus_p", "bus_q", "bus_v_magn", "bus_v_ang", "bus_i_magn", "bus_i_ang", "dev_p", "dev_q", "des_soc",
@@ -65,6 +65,7 @@ class FullLayout(C.Structure):
 
 SOLVE_F64, SOLVE_F32 = 0, 1
 IMPL_THREAD, IMPL_RADIAL = 0, 1
+HANDOFF_NEVER, HANDOFF_AUTO = -1, -2
 
 _P = C.c_void_p  # raw device (or, for the test double, host) pointers are passed as integers
 
@@ -160,14 +161,18 @@ def load_for_topology(topo, impl=None) -> Backend:
         for cand in sorted(os.listdir(codegen.BUILD_DIR)) if os.path.isdir(codegen.BUILD_DIR) else []:
             if cand.startswith("libanm_") and cand.endswith(".so") and cand.count(".") == 1:
                 gpath = os.path.join(codegen.BUILD_DIR, cand)
+                if not codegen.library_is_fresh(gpath):  # built from other sources / another ABI revision
+                    continue
                 try:
                     be = Backend(C.CDLL(gpath), "cuda", gpath)
                 except OSError:
                     continue
                 be.generic = True
                 return be
-    if not os.path.exists(path):
-        path = codegen.build_library(topo)  # raises HipExtensionError when hipcc is unavailable
+    # build_library returns at once when the library's content stamp matches this tree's sources; a
+    # stale library (edited kernels, changed C ABI) is rebuilt, or refused when hipcc is unavailable:
+    # calling an old binary through the new ctypes signatures would be silent garbage
+    path = codegen.build_library(topo)
     try:
         cdll = C.CDLL(path)
     except OSError as ex:

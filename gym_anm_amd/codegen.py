@@ -103,6 +103,56 @@ def symbolic_block_lu(n_bus, branches):
                 useg=useg, b_j=b_j, b_blk=b_blk, bseg=bseg)  # fmt: skip
 
 
+def tree_tables(n_bus, branches, ypat):
+    """Rooted-tree view of a radial network for the lane-group Newton continuation (csrc/anm_group.hpp):
+    lane l of a group plays bus l + 1.  Returns None when the network is not a tree (or too large for one
+    wavefront).  parent 0 = the slack bus; height 0 = leaf (elimination goes by height: every bus of height h
+    folds the Schur complements of its children, which are all lower); depth 0 = attached to the slack
+    (back substitution goes by depth)."""
+    if len(branches) != n_bus - 1 or n_bus < 2 or n_bus - 1 > 64:
+        return None
+    adj = {i: [] for i in range(n_bus)}
+    for f, t in branches:
+        adj[f].append(t)
+        adj[t].append(f)
+    parent, depth, order = {0: -1}, {0: -1}, [0]
+    for u in order:
+        for v in sorted(adj[u]):
+            if v not in parent:
+                parent[v] = u
+                depth[v] = depth[u] + 1
+                order.append(v)
+    if len(order) != n_bus:
+        return None
+    children = {b: sorted(c for c in range(1, n_bus) if parent[c] == b) for b in range(n_bus)}
+    height = {}
+    for b in reversed(order):
+        height[b] = 0 if (b == 0 or not children[b]) else 1 + max(height[c] for c in children[b])
+    if n_bus > 1:
+        height[0] = 1 + max(height[c] for c in children[0])
+    maxch = max([len(children[b]) for b in range(1, n_bus)] + [1])
+    maxh = max(height[b] for b in range(1, n_bus))
+    maxd = max(depth[b] for b in range(1, n_bus))
+    ch = []
+    for b in range(n_bus):
+        cs = children[b] if b != 0 else []
+        ch += cs + [-1] * (maxch - len(cs))
+    nch_h = [max([len(children[b]) for b in range(1, n_bus) if height[b] == h] + [0]) for h in range(maxh + 1)]
+    pos = {ij: z for z, ij in enumerate(ypat)}
+    grp = 8
+    while grp < n_bus - 1:
+        grp *= 2
+    return dict(
+        GRP=grp, MAXCH=maxch, MAXH=maxh, MAXD=maxd,
+        PARENT=[-1] + [parent[b] for b in range(1, n_bus)],
+        HEIGHT=[height[b] for b in range(n_bus)], DEPTH=[-1] + [depth[b] for b in range(1, n_bus)],
+        NCH=[0] + [len(children[b]) for b in range(1, n_bus)], CH=ch, NCH_H=nch_h,
+        ZBB=[-1] + [pos[(b, b)] for b in range(1, n_bus)],
+        ZBP=[-1] + [pos[(b, parent[b])] for b in range(1, n_bus)],
+        ZPB=[-1] + [pos[(parent[b], b)] for b in range(1, n_bus)],
+    )  # fmt: skip
+
+
 def _arr(name, values, typ="int"):
     vals = list(values)
     body = ", ".join(str(int(v)) for v in vals) if vals else "0"
@@ -170,6 +220,20 @@ def emit_header(topo, name=None) -> str:
         _arr("B_J", sym["b_j"]),
         _arr("B_BLK", sym["b_blk"]),
         _arr("BSEG", sym["bseg"]),
+    ]
+    tt = tree_tables(n_bus, branches, ypat)
+    if tt is None:
+        lines += ["  static constexpr int TREE = 0, GRP = 64;"]
+    else:
+        lines += [
+            "  // rooted-tree view (lane-group Newton continuation, csrc/anm_group.hpp): lane l <-> bus l + 1",
+            "  static constexpr int TREE = 1, GRP = %d, T_MAXCH = %d, T_MAXH = %d, T_MAXD = %d;"
+            % (tt["GRP"], tt["MAXCH"], tt["MAXH"], tt["MAXD"]),
+            _arr("T_PARENT", tt["PARENT"]), _arr("T_HEIGHT", tt["HEIGHT"]), _arr("T_DEPTH", tt["DEPTH"]),
+            _arr("T_NCH", tt["NCH"]), _arr("T_CH", tt["CH"]), _arr("T_NCH_H", tt["NCH_H"]),
+            _arr("T_ZBB", tt["ZBB"]), _arr("T_ZBP", tt["ZBP"]), _arr("T_ZPB", tt["ZPB"]),
+        ]  # fmt: skip
+    lines += [
         "};",
         "}  // namespace",
         "",
@@ -226,6 +290,23 @@ def _build_stamp(header_text, flags):
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def library_is_fresh(lib: str) -> bool:
+    """True when ``lib`` was built from the kernel sources, C-ABI header and flags of this tree (its
+    ``.stamp`` equals the content hash recomputed from its own descriptor header).  Used before a
+    dlopen that does not go through build_library (generic mode picks any built library)."""
+    base = os.path.basename(lib)
+    if not (base.startswith("libanm_") and base.endswith(".so")):
+        return False
+    name = base[len("libanm_"):-len(".so")].split(".")[0]
+    try:
+        text = open(header_path(name)).read()
+        stamp = open(lib + ".stamp").read().strip()
+    except OSError:
+        return False
+    extra = os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
+    return stamp == _build_stamp(text, HIPCC_FLAGS + extra)
 
 
 def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):

@@ -36,6 +36,9 @@ int fail_hip(hipError_t e, const char* where) {
   return -2;
 }
 
+#ifndef ANM_HANDOFF_DEFAULT
+#define ANM_HANDOFF_DEFAULT 8
+#endif
 #ifndef ANM_ROWS_WAVES
 #define ANM_ROWS_WAVES 1  // min. waves per SIMD the step kernel is compiled for (register budget 512 / waves)
 #endif
@@ -140,13 +143,17 @@ int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const r
 }
 
 SolverOpts solver(const anm_solver_opts* o, int& precision) {
-  SolverOpts s{1e-5, 100};
+  SolverOpts s{1e-5, 100, ANM_HANDOFF_AUTO};
   precision = ANM_SOLVE_F64;
   if (o) {
     s.tol = o->tol;
     s.max_iter = o->max_iter;
     precision = o->precision;
+    s.handoff = o->handoff_after;
   }
+  // default hand-over point: every converging solve seen so far needs <= 9 iterations at tol 1e-6, so after
+  // ANM_HANDOFF_DEFAULT trips the lanes still iterating are (almost only) diverging solves
+  if (s.handoff == ANM_HANDOFF_AUTO) s.handoff = Topo::TREE ? ANM_HANDOFF_DEFAULT : ANM_HANDOFF_NEVER;
   return s;
 }
 
@@ -452,7 +459,6 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
     io.ws = ws->buf;
     io.ws_cap = cap;
     io.iter_cap = ws->iter_cap;
-    io.parity = ws->parity & 1;
   }
   return 0;
 }
@@ -538,10 +544,6 @@ int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double
   hipEventRecord(t0, s);
   for (int k = 0; k < n_launch && rc == 0; ++k) {
     rc = launch_step(m, io, n, opts, s);
-    if (io.ws) {
-      io.parity ^= 1;
-      ws->parity ^= 1;
-    }
   }
   hipEventRecord(t1, s);
   e = hipEventSynchronize(t1);

@@ -7,12 +7,14 @@
 #pragma once
 
 #include "anm_device.hpp"
+#include "anm_group.hpp"
 
 namespace anm {
 
 struct SolverOpts {
   double tol;
   int max_iter;
+  int handoff;  // >= 0: Newton iterations in thread mode before a running solve moves to a lane group; < 0: never
 };
 
 template <class T>
@@ -105,7 +107,6 @@ struct EnvIO {
   double* ws;               // two-phase step: workspace (counters + straggler records) or null
   int64_t ws_cap;           // number of straggler records the workspace can hold
   int iter_cap;             // two-phase step: Newton iterations done by the first launch
-  int parity;               // two-phase step: which of the two counters this step uses
 };
 
 // Split an init_state row (anm_env.py / simulator.py:248-268) into transition inputs.
@@ -342,6 +343,12 @@ ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const 
     finish_reset<T, 1>(C, w, s0, 1, out.soc, out.state, out.obs);
     out.inc_reset = true;
     out.terminated = w.converged ? 0 : 1;  // not converged: try another draw at the next call
+    if (!w.converged) {  // ... and look exactly like the absorbing terminal state until then
+      static_for<0, T::SDIM + 1>([&](auto Kc) {
+        out.state[Kc] = 0.0;
+        out.obs[Kc] = 0.0;
+      });
+    }
     out.timestep_op = 1;
     out.write_costs = true;  // reward = e_loss = penalty = 0
     return;
@@ -503,13 +510,6 @@ __device__ int64_t load_record(const double* r, StepCtx<T>& ctx, EnvWork<T>& w, 
   return int64_t(r[R::E]);
 }
 
-#define ANM_WAVE_SYNC()                                        \
-  do {                                                         \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
-    __builtin_amdgcn_wave_barrier();                           \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
-  } while (0)
-
 // I/O layer 2 (GPU, series mode, K = 1): one wavefront = 64 consecutive environments whose action /
 // state / obs rows are contiguous in memory.  Rows travel through LDS so that every global access is
 // a fully coalesced 512-byte wave transaction (the plain layer issues 16-byte stores with a 144-byte
@@ -564,7 +564,10 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
   step_begin<T, JT>(C, C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
   bool pending = false;
-  int cap = two_phase ? io.iter_cap : so.max_iter;
+  // in-wave straggler hand-over (anm_group.hpp): tree topologies, not combined with the two-launch mode
+  constexpr bool CAN_GROUP = T::TREE != 0 && group::Shape<T>::NG * group::Slot<T>::SIZE <= 64 * (T::SDIM + 2);
+  const int handoff = (CAN_GROUP && !two_phase && so.handoff >= 0 && so.handoff < so.max_iter) ? so.handoff : -1;
+  int cap = two_phase ? io.iter_cap : (handoff >= 0 ? handoff : so.max_iter);
   // One copy of the Newton loop serves both passes (a second inlined copy costs registers and code):
   // pass 0 iterates up to `cap`; in two-launch mode the environments still iterating are then handed
   // to the straggler launch, and pass 1 only runs for those that found no record slot.
@@ -572,7 +575,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   for (int pass = 0; pass < 2; ++pass) {
     pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, cap);
     if (!two_phase || pass == 1) break;
-    int* cnt = reinterpret_cast<int*>(io.ws) + io.parity;
+    int* cnt = reinterpret_cast<int*>(io.ws);  // cnt[0]: records of this step (zeroed by the scatter launch)
     if (valid && st.active) {
       const int slot = atomicAdd(cnt, 1);
       if (slot < io.ws_cap) {
@@ -583,6 +586,10 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
     if (pending) st.diff = 0.0;  // handed over: this lane's own solve ends here (its outputs are not stored)
     cap = so.max_iter;
     if (!ANM_WAVE_ANY(st.active && !pending)) break;  // else: record space exhausted (or a padding lane)
+  }
+  if constexpr (CAN_GROUP) {
+    if (handoff >= 0 && ANM_WAVE_ANY(st.active && valid))
+      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
   }
   step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
   const bool store = valid && !pending;
@@ -622,9 +629,12 @@ template <class T, class JT>
 __device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so) {
   constexpr int S = T::SDIM + 1;
   int* cnt = reinterpret_cast<int*>(io.ws);
-  int n_rec = cnt[io.parity];
+  int n_rec = cnt[0];
   if (n_rec > io.ws_cap) n_rec = int(io.ws_cap);
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[io.parity ^ 1] = 0;  // counter of the next step
+  // The count is handed to the scatter launch in cnt[1] so that the scatter launch can zero cnt[0] for the
+  // next step: every step leaves the counters as it found them (no host-side parity, no memset), which is
+  // what makes one captured step replayable from a HIP graph any number of times.
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[1] = n_rec;
   // Dense packing: 64 consecutive records per wavefront.  Measured alternatives (MI355X): dealing the
   // records one per wavefront makes every iteration 2-3x slower once several sparse wavefronts share a
   // CU (issue stalls, SQ_WAIT_INST_ANY 60 %), although each wave then only runs the sin/cos tier its
@@ -657,9 +667,9 @@ template <class T>
 __device__ void op_step_scatter(const EnvIO& io) {
   constexpr int S = T::SDIM + 1;
   typedef ResRec<T> Q;
-  const int* cnt = reinterpret_cast<const int*>(io.ws);
-  int n_rec = cnt[io.parity];
-  if (n_rec > io.ws_cap) n_rec = int(io.ws_cap);
+  int* cnt = reinterpret_cast<int*>(io.ws);
+  const int n_rec = cnt[1];  // written by the straggler launch (already clamped to the workspace)
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[0] = 0;  // nobody reads cnt[0] in this launch
   const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (j >= n_rec) return;
   const double* r = io.ws + Rec<T>::HEADER + j * Rec<T>::SIZE;

@@ -626,9 +626,15 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       soc = soc_req / base;  // simulator.py:284-288
       io.e.soc[e * d.NDES + slot] = soc;
     }
-    if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
-    if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
-    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) put(2 * d.ND + d.NDES + slot, p_pot * base);
+    if (mode == 2 && !converged) {
+      // a redraw whose first power flow does not converge looks like the absorbing terminal state
+      // until the next call draws again
+      for (int k = l; k < S; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+    } else {
+      if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
+      if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
+      if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) put(2 * d.ND + d.NDES + slot, p_pot * base);
+    }
     if (mode == 1) {
       if (sampled) {
         if (l == 0) { put(d.SDIM, double(aux)); io.e.reset_count[e] += 1; }
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
     } else {
       if (l == 0) {
-        put(d.SDIM, double(aux));
+        if (converged) put(d.SDIM, double(aux));
         io.e.reset_count[e] += 1;
         io.e.terminated[e] = converged ? 0 : 1;
         if (io.e.timestep) io.e.timestep[e] = 0;

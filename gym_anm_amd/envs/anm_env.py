@@ -89,7 +89,7 @@ def check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, state_bound
 class BatchedANMEnv(GymEnv):
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
                  num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
-                 env_offset=0, impl=None, straggler_after="auto", _backend=None):  # fmt: skip
+                 env_offset=0, impl=None, straggler_after="auto", handoff_after="auto", _backend=None):  # fmt: skip
         GymEnv.reset(self, seed=seed)
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
         self.aux_bounds = aux_bounds
@@ -104,7 +104,8 @@ class BatchedANMEnv(GymEnv):
         self.env_offset = int(env_offset)  # global index of environment 0 (sharded batches)
 
         self.simulator = BatchedSimulator(network, delta_t, lamb, num_envs=num_envs, device=device, tol=tol,
-                                          max_iter=max_iter, precision=precision, impl=impl, _backend=_backend)  # fmt: skip
+                                          max_iter=max_iter, precision=precision, impl=impl,
+                                          handoff_after=handoff_after, _backend=_backend)  # fmt: skip
         sim = self.simulator
         self.device = sim.device
         check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, sim.state_bounds)
@@ -138,7 +139,11 @@ class BatchedANMEnv(GymEnv):
         self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
         self._reset_count = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._truncated = torch.zeros(E_, dtype=torch.bool, device=self.device)
-        self.rng_seed = 0 if seed is None else int(seed)
+        # key of the device-side sampler (reset(options={"sampler": "device"}), autoreset).  Unseeded
+        # environments draw it from np_random (entropy-seeded in that case), so that two unseeded
+        # environments -- e.g. the ranks of a sharded batch -- are not correlated; explicit seeds stay
+        # deterministic.
+        self.rng_seed = int(self.np_random.integers(2**62)) if seed is None else int(seed)
         self._act_low = torch.as_tensor(lo, **f64)
         self._act_high = torch.as_tensor(hi, **f64)
         self.check_actions = True
@@ -458,8 +463,6 @@ class BatchedANMEnv(GymEnv):
             rc = fn(sim._handle, self.num_envs, action_ptr, exo_ptr, aux_ptr, *args, 1 if self.autoreset else 0,
                     self.rng_seed, self.env_offset, self._reset_count_ptr, self._aux_index_ptr, self._ws_ref, self._opts_ref,
                         stream)  # fmt: skip
-        if self._ws is not None:
-            self._ws.parity ^= 1
         if rc != 0:
             sim.backend.check(rc, "anm_step_f64")
 

@@ -73,7 +73,7 @@ class StateView:
 
 class BatchedSimulator:
     def __init__(self, network, delta_t, lamb, num_envs=1, device="cuda", tol=1e-5, max_iter=100,
-                 precision="f64", impl=None, _backend=None):  # fmt: skip
+                 precision="f64", impl=None, handoff_after="auto", _backend=None):  # fmt: skip
         self.model = NetworkModel(network, delta_t, lamb)
         m = self.model
         self.baseMVA, self.delta_t, self.lamb = m.baseMVA, delta_t, lamb
@@ -100,7 +100,12 @@ class BatchedSimulator:
         elif self.device.type != self.backend.device_type:
             raise E.HipExtensionError("backend runs on %s tensors" % self.backend.device_type)
 
-        self.opts = _lib.SolverOpts(float(tol), int(max_iter), _lib.SOLVE_F32 if precision == "f32" else _lib.SOLVE_F64)
+        # handoff_after: Newton iterations a solve spends in its own lane before a still-running (diverging)
+        # one continues on a lane group, see anm_solver_opts in include/anm_mi355x.h; None = never
+        ho = _lib.HANDOFF_AUTO if handoff_after == "auto" else (_lib.HANDOFF_NEVER if handoff_after is None
+                                                                else int(handoff_after))  # fmt: skip
+        self.opts = _lib.SolverOpts(float(tol), int(max_iter), _lib.SOLVE_F32 if precision == "f32" else _lib.SOLVE_F64,
+                                    ho)  # fmt: skip
         self._handle = C.c_void_p()
         desc, self._keep = _lib.network_desc(m)
         with self._device_ctx():

@@ -129,7 +129,16 @@ typedef struct anm_solver_opts {
   double tol;       /* stop when ||F||inf <= tol  (reference: 1e-5, simulator.py:529) */
   int32_t max_iter; /* iteration cap               (reference: 100, solve_load_flow.py:176) */
   int32_t precision;/* ANM_SOLVE_F64 | ANM_SOLVE_F32 */
+  /* Straggler hand-over inside a wavefront (thread-per-environment family, tree topologies, coalesced-row
+   * step kernel): after `handoff_after` Newton iterations the solves that are still running -- in practice
+   * the diverging ones, which go on to the iteration cap -- leave their lane and continue spread over a
+   * group of lanes, one lane per bus (csrc/anm_group.hpp), so that the wavefront's remaining trips are
+   * short.  >= 0: hand over after that many iterations; ANM_HANDOFF_NEVER: stay in the lane;
+   * ANM_HANDOFF_AUTO: the library's default for the topology. */
+  int32_t handoff_after;
 } anm_solver_opts;
+#define ANM_HANDOFF_NEVER (-1)
+#define ANM_HANDOFF_AUTO (-2)
 
 /* Simulator.transition for num_envs environments.  All pointers dev.
  *   in : p_load [E, n_load], p_pot [E, n_gen], p_set/q_set [E, n_gen+n_des] (set-point devices by
@@ -160,12 +169,14 @@ int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, cons
  * `iter_cap` iterations and hands the environments that are still iterating over (one record each),
  * the second continues only those, densely packed, with the same code (bit-identical results).
  * buf: device memory, zero-initialised once by the caller; n_doubles >= 8 + records * record size
- * (anm_step_ws_record_doubles()); parity: 0, 1, 0, 1, ... on successive steps that use this buffer. */
+ * (anm_step_ws_record_doubles()).  Every step leaves the record counters at the head of the buffer as
+ * it found them (the last launch of a step zeroes the count), so a captured step can be replayed from
+ * a HIP graph any number of times; one workspace serves one stream at a time. */
 typedef struct anm_step_ws {
   double* buf;
   int64_t n_doubles;
   int32_t iter_cap;
-  int32_t parity;
+  int32_t reserved;
 } anm_step_ws;
 int anm_step_ws_record_doubles(void);
 
@@ -216,7 +227,7 @@ int anm_model_full_layout(const anm_model* m, anm_full_layout* out);
 
 /* Timing helper for benchmarks: enqueue `n_launch` identical steps bracketed by HIP events on
  * `stream` and return the average milliseconds per step (synchronises).  With a workspace a step
- * is two kernel launches and ws->parity is advanced. */
+ * is three kernel launches. */
 int anm_time_step_launches(anm_model* m, int64_t num_envs, const double* action, double* soc,
                            double* state, uint8_t* terminated, int32_t* timestep, double* obs,
                            double* reward, double* e_loss, double* penalty, int32_t autoreset,

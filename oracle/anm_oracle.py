@@ -267,6 +267,25 @@ def newton_raphson(p, q, Y, tol=1e-5, max_iter=100, sparse=True):
 # ======================================================================================
 # Simulator.transition / reset  (simulator.py:225-293, 464-683)
 # ======================================================================================
+def compute_reward(n: Net, dev_p, p_pot, v_magn, br_s):
+    """``Simulator._compute_reward`` (simulator.py:638-683): (e_loss, penalty) in p.u. energy.
+    ``dev_p`` per device, ``p_pot`` per non-slack generator, ``v_magn`` per bus, ``br_s`` per branch."""
+    e_loss = 0.0
+    for k in range(n.D):
+        if n.dev_type[k] in (LOAD, SLACK, CLASSICAL, RENEWABLE):
+            e_loss += dev_p[k]
+        if n.dev_type[k] == RENEWABLE:
+            e_loss += np.maximum(0, p_pot[n.gens.index(k)] - dev_p[k])
+    e_loss *= n.delta_t
+    pen = 0.0
+    for i in range(n.N):
+        pen += np.maximum(0, v_magn[i] - n.v_max[i]) + np.maximum(0, n.v_min[i] - v_magn[i])
+    for b in range(n.B):
+        pen += np.maximum(0, np.abs(br_s[b]) - n.rate[b])
+    pen *= n.delta_t * n.lamb
+    return e_loss, pen
+
+
 def transition(n: Net, P_load, P_pot, P_set, Q_set, soc, tol=1e-5, max_iter=100, sparse=True):
     """One ``Simulator.transition``.  Inputs in MW/MVAr ordered like n.loads / n.gens / n.setp,
     ``soc`` (p.u., ordered like n.des) is the SoC before the step.  Returns a dict of p.u. outputs."""
@@ -320,21 +339,7 @@ def transition(n: Net, P_load, P_pot, P_set, Q_set, soc, tol=1e-5, max_iter=100,
         s_from = vf * np.conj(i_from)
         s_to = vt * np.conj(i_to)
         br_s = np.sign(s_from.real) * np.maximum(np.abs(s_from), np.abs(s_to))
-        # simulator.py:638-683
-        e_loss = 0.0
-        for k in range(n.D):
-            if n.dev_type[k] in (LOAD, SLACK, CLASSICAL, RENEWABLE):
-                e_loss += dev_p[k]
-            if n.dev_type[k] == RENEWABLE:
-                e_loss += np.maximum(0, p_pot[n.gens.index(k)] - dev_p[k])
-        e_loss *= n.delta_t
-        pen = 0.0
-        for i in range(n.N):
-            vm = np.abs(V[i])
-            pen += np.maximum(0, vm - n.v_max[i]) + np.maximum(0, n.v_min[i] - vm)
-        for b in range(n.B):
-            pen += np.maximum(0, np.abs(br_s[b]) - n.rate[b])
-        pen *= n.delta_t * n.lamb
+        e_loss, pen = compute_reward(n, dev_p, p_pot, np.abs(V), br_s)
     return dict(
         dev_p=dev_p, dev_q=dev_q, soc_after=soc_new, p_pot=p_pot, bus_p=bus_p, bus_q=bus_q, V=V, I=I,
         n_iter=it, diff=diff, converged=stable, br_p_from=s_from.real, br_q_from=s_from.imag,
@@ -387,7 +392,11 @@ class OracleEnv:
     """
 
     def __init__(self, network, delta_t=0.25, gamma=0.995, lamb=100, costs_clipping=(1, 100),
-                 aux_bounds=((0, 95),), tables=None, sparse=True, tol=1e-5, max_iter=100):  # fmt: skip
+                 aux_bounds=((0, 95),), tables=None, sparse=True, tol=1e-5, max_iter=100, next_vars=None):  # fmt: skip
+        # next_vars: the task hook of anm_env.py:176-191, state -> [P_load (MW).., P_pot (MW).., aux (K)..];
+        # default: ANM6Easy's table lookup (anm6_easy.py:54-65), K = 1
+        self.next_vars = next_vars
+        self.K = len(aux_bounds)
         self.n = parse_network(network, delta_t, lamb)
         self.gamma, self.c1, self.c2 = gamma, costs_clipping[0], costs_clipping[1]
         self.tables = anm6easy_tables() if tables is None else tables
@@ -405,14 +414,14 @@ class OracleEnv:
 
     def _state_vec(self, out, aux):
         b = self.n.baseMVA
-        return np.concatenate((out["dev_p"] * b, out["dev_q"] * b, self.soc * b, out["p_pot"] * b, [aux]))
+        return np.concatenate((out["dev_p"] * b, out["dev_q"] * b, self.soc * b, out["p_pot"] * b, np.atleast_1d(aux)))
 
     def reset_to(self, init_state):
         """anm_env.py:266-311 for one given init_state draw; returns (obs, converged)."""
         out = sim_reset(self.n, np.asarray(init_state, dtype=float), **self.kw)
         self.soc = out["soc_after"]
         self.terminated = False
-        self.state = self._state_vec(out, init_state[-1])
+        self.state = self._state_vec(out, init_state[len(init_state) - self.K :])
         self.last = out
         return np.clip(self.state, self.obs_low, self.obs_high), out["converged"]
 
@@ -428,9 +437,14 @@ class OracleEnv:
         n = self.n
         if self.terminated:
             return np.zeros_like(self.state), 0.0, True
-        aux = int((self.state[-1] + 1) % self.T)
         nl, ng = len(n.loads), len(n.gens)
-        P_load, P_pot = self.tables[:nl, aux], self.tables[nl : nl + ng, aux]
+        if self.next_vars is None:
+            aux = int((self.state[-1] + 1) % self.T)
+            P_load, P_pot = self.tables[:nl, aux], self.tables[nl : nl + ng, aux]
+        else:
+            v = np.asarray(self.next_vars(self.state), dtype=float)
+            assert v.size == nl + ng + self.K  # anm_env.py:372-374
+            P_load, P_pot, aux = v[:nl], v[nl : nl + ng], v[nl + ng :]
         gen_ids, des_ids = n.gens, n.des
         P_set, Q_set = {}, {}
         for a, k in zip(action[:ng], gen_ids):

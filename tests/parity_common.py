@@ -122,3 +122,213 @@ def run_episodes(env_factory, n_steps=150):
                 npt.assert_allclose(obs[e].cpu().numpy(), g["reset_obs"][reset_off[e] + j], rtol=0, atol=1e-8)
     npt.assert_array_equal(env.timestep.cpu().numpy() > 0, np.ones(n_ep, bool))
     return env
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: bodies shared by the GPU tier (tests/test_gpu_headline.py) and the host test double
+# (tests/test_hostsim_parity.py).  `kw(net)` returns the backend keywords (device=, _backend=).
+# ---------------------------------------------------------------------------------------------------
+def uniform_actions(env, gen):
+    dev = env.device
+    lo = torch.as_tensor(env.action_space.low, device=dev)
+    hi = torch.as_tensor(env.action_space.high, device=dev)
+    return lo + (hi - lo) * torch.rand((env.num_envs, lo.numel()), generator=gen, dtype=torch.float64, device=dev)
+
+
+def headline_replay(kw, E_, T, n_random, n_collapsed, **env_kw):
+    """ANM6EasyVec(tol=1e-6, autoreset) for T steps; a seeded sample plus environments that collapsed early
+    are replayed by OracleEnv(tol=1e-6), autoreset draws included: observation <= 1e-9, reward rtol 1e-9,
+    terminated and Newton iteration counts exact."""
+    import anm_oracle as O
+    from gym_anm_amd import rng
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    net = networks.anm6_network()
+    env = ANM6EasyVec(num_envs=E_, seed=1234, tol=1e-6, autoreset=True, **kw(net), **env_kw)
+    dev = env.device
+    env.check_actions = False
+    env.reset(seed=1234)
+    state0, soc0 = env.state.clone(), env.simulator.soc.clone()
+    gen = torch.Generator(device=dev).manual_seed(99)
+    rec = {k: [] for k in ("a", "obs", "r", "term", "it", "rc", "el", "pen")}
+    for t in range(T):
+        a = uniform_actions(env, gen)
+        rec["rc"].append(env._reset_count.clone())
+        obs, r, term, _, _ = env.step(a)
+        for k, v in zip(("a", "obs", "r", "term", "it", "el", "pen"),
+                        (a, obs, r, term, env.simulator.nr_iters, env.e_loss, env.penalty)):  # fmt: skip
+            rec[k].append(v.clone())
+    collapsed = torch.nonzero(torch.stack(rec["term"])[: T - 2].any(dim=0))[:, 0].cpu().numpy()
+    sample = np.unique(np.concatenate((np.random.default_rng(0).choice(E_, n_random, replace=False),
+                                       collapsed[:n_collapsed])))  # fmt: skip
+    idx = torch.as_tensor(sample, device=dev)
+    R = {k: torch.stack([x[idx] for x in v]).cpu().numpy() for k, v in rec.items()}
+    s0, c0 = state0[idx].cpu().numpy(), soc0[idx].cpu().numpy()
+    n_reset = n_term = 0
+    for j, e in enumerate(sample):
+        orc = O.OracleEnv(net, sparse=False, tol=1e-6)
+        orc.load_state(s0[j], c0[j])
+        for t in range(T):
+            if orc.terminated:  # Gymnasium next-step autoreset: this call returns the first observation
+                s_init = rng.series_init_state(env.simulator.model, env._series, 1234, int(e), int(R["rc"][t][j]))
+                o, conv = orc.reset_to(s_init)
+                assert conv and not R["term"][t][j]
+                assert R["r"][t][j] == 0.0 and R["el"][t][j] == 0.0 and R["pen"][t][j] == 0.0
+                n_reset += 1
+            else:
+                o, r, term = orc.step(R["a"][t][j])
+                assert term == bool(R["term"][t][j]), (e, t)
+                npt.assert_allclose(R["r"][t][j], r, rtol=1e-9, atol=1e-12)
+                if term:
+                    n_term += 1
+                    assert not R["obs"][t][j].any()
+                    continue
+                npt.assert_allclose(R["el"][t][j], orc.e_loss, rtol=1e-9, atol=1e-12)
+                npt.assert_allclose(R["pen"][t][j], orc.penalty, rtol=1e-9, atol=1e-10)
+            npt.assert_allclose(R["obs"][t][j], o, rtol=0, atol=1e-9, err_msg="env %d step %d" % (e, t))
+            assert int(R["it"][t][j]) == orc.last["n_iter"], (e, t)
+    return len(sample), n_term, n_reset
+
+
+def _check_reset_outputs(sim, g, conv):
+    ok = g["converged"].astype(bool)
+    npt.assert_array_equal(conv, ok)  # flags exact, the non-converged ones included
+    assert (~ok).any()
+    full = sim.full.cpu().numpy()
+    sl = full_slices(sim)
+    slack = sim.model.slack_dev
+    keep = [k for k in range(sim.N_device) if k != slack]
+    npt.assert_allclose(full[:, sl["dev_p"]][:, keep], g["dev_p"][:, keep], rtol=0, atol=1e-12)
+    npt.assert_allclose(full[:, sl["dev_q"]][:, keep], g["dev_q"][:, keep], rtol=0, atol=1e-12)
+    npt.assert_allclose(sim.soc.cpu().numpy(), g["soc_after"], rtol=0, atol=1e-13)
+    npt.assert_array_equal(sim.nr_iters.cpu().numpy()[ok], g["n_iter"][ok])
+    for key, ref in (("dev_p", g["dev_p"]), ("dev_q", g["dev_q"]), ("bus_v_magn", np.abs(g["V"])),
+                     ("bus_v_ang", np.angle(g["V"])), ("branch_s", g["br_s"]), ("branch_p", g["br_p_from"]),
+                     ("bus_i_magn", np.abs(g["I"]))):  # fmt: skip
+        npt.assert_allclose(full[:, sl[key]][ok], ref[ok], rtol=0, atol=1e-9, err_msg=key)
+
+
+def reset_golden(name, kw, impl=None):
+    """tests/golden/reset_<name>.npz (recorded from the reference's Simulator.reset, simulator.py:225-293)
+    through BatchedSimulator.reset and through ANMEnv.reset -> anm_reset_f64 (anm_env.py:266-311 tail)."""
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    net = networks.anm6_network() if name == "anm6" else networks.three_bus_loop_network(base_mva=10, gen_max=100.0)
+    g = np.load(os.path.join(GOLDEN, "reset_%s.npz" % name))
+    M = len(g["n_iter"])
+    extra = {} if impl is None else {"impl": impl}
+    sim = BatchedSimulator(net, float(g["delta_t"]), float(g["lamb"]), num_envs=M, **kw(net), **extra)
+    if impl is not None:
+        assert sim.impl == impl
+    conv = sim.reset(g["init_state"])
+    _check_reset_outputs(sim, g, conv.cpu().numpy())
+
+    class Env(BatchedANMEnv):
+        def __init__(self, **k):
+            super().__init__(net, "state", 1, float(g["delta_t"]), 0.995, float(g["lamb"]), **k)
+
+    env = Env(num_envs=M, **kw(net), **extra)
+    env._need_full = True  # ask the reset kernel for the electrical-state dump as well
+    obs, _ = env.reset(options={"init_state": g["init_state"]})
+    _check_reset_outputs(env.simulator, g, env.pfe_converged.cpu().numpy())
+    ok = g["converged"].astype(bool)
+    npt.assert_array_equal(env.terminated.cpu().numpy(), ~ok)  # explicit non-converging state: terminated
+    b = env.simulator.baseMVA
+    st = np.concatenate((g["dev_p"] * b, g["dev_q"] * b, g["soc_after"] * b, g["p_pot"] * b, g["init_state"][:, -1:]), 1)
+    npt.assert_allclose(env.state.cpu().numpy()[ok], st[ok], rtol=0, atol=1e-7)
+    lo, hi = env.observation_space.low, env.observation_space.high
+    npt.assert_allclose(obs.cpu().numpy()[ok], np.clip(st, lo, hi)[ok], rtol=0, atol=1e-7)
+    assert bool((env.timestep == 0).all())
+    return env
+
+
+def sharded_equal_unsharded(kw, E_, T, **env_kw):
+    """BASELINE.json config 5's partition rule: environments [0, E/2) and [E/2, E) stepped as two batches with
+    env_offset 0 | E/2 give bit-identical outputs to the batch of E, autoreset (device RNG keyed by the
+    global environment index) included."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    net = networks.anm6_network()
+    H = E_ // 2
+    mk = lambda n, off: ANM6EasyVec(num_envs=n, seed=7, tol=1e-6, autoreset=True, env_offset=off, **kw(net), **env_kw)
+    whole, parts = mk(E_, 0), [mk(H, 0), mk(H, H)]
+    for env in [whole] + parts:
+        env.check_actions = False
+        env.reset(seed=7, options={"sampler": "device"})
+    gen = torch.Generator(device=whole.device).manual_seed(8)
+    fields = lambda env, out: (out[0], out[1], out[2], env.state, env.simulator.soc, env.simulator.nr_iters,
+                               env.timestep, env._reset_count, env.e_loss, env.penalty)  # fmt: skip
+    n_term = 0
+    for t in range(T):
+        a = uniform_actions(whole, gen)
+        ref = fields(whole, whole.step(a))
+        n_term += int(ref[2].sum())
+        for k, env in enumerate(parts):
+            cur = fields(env, env.step(a[k * H : (k + 1) * H].contiguous()))
+            for x, y in zip(cur, ref):
+                assert torch.equal(x, y[k * H : (k + 1) * H]), (t, k)
+    return n_term, int(whole._reset_count.max())
+
+
+def callable_observation_and_two_aux(kw, E_=96, T=24):
+    """A task with K = 2 auxiliary variables, a host next_vars() hook and a callable observation
+    (anm_env.py:176-191, 372-374, 511-514) against the oracle."""
+    import anm_oracle as O
+    from gym_anm_amd.envs.anm6 import anm6easy_series
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    net = networks.anm6_network()
+    tab = anm6easy_series()
+
+    def next_vars_np(s):  # aux0: time index; aux1: a counter that modulates the generation potential
+        t = int((s[-2] + 1) % 96)
+        w = 0.5 + 0.5 * np.cos(0.3 * (s[-1] + 1.0))
+        return np.concatenate((tab[:3, t], tab[3:, t] * w, [t, s[-1] + 1.0]))
+
+    class Task(BatchedANMEnv):
+        def __init__(self, **k):
+            obs = lambda s: torch.stack((s[:, 0] + s[:, 2], s[:, 14] * 0.01, s[:, -1], s[:, 7:14].sum(dim=1)), dim=1)
+            super().__init__(net, obs, 2, 0.25, 0.995, 100, aux_bounds=np.array([[0, 95], [0, 1e6]]),
+                             costs_clipping=(1, 100), **k)  # fmt: skip
+
+        def next_vars(self, s_t):
+            t = torch.remainder(s_t[:, -2] + 1, 96).long()
+            w = 0.5 + 0.5 * torch.cos(0.3 * (s_t[:, -1] + 1.0))
+            T_ = torch.as_tensor(tab, device=s_t.device)
+            return torch.cat((T_[:3, t].T, T_[3:, t].T * w[:, None], t[:, None].double(), (s_t[:, -1] + 1.0)[:, None]), 1)
+
+    env = Task(num_envs=E_, seed=5, **kw(net))
+    dev = env.device
+    assert env.observation_space is None  # unknown until the first reset (anm_env.py:303-309)
+    rng_ = np.random.default_rng(12)
+    s0 = np.zeros((E_, env.state_N))
+    t0 = rng_.integers(0, 96, E_)
+    s0[:, [1, 3, 5]] = tab[:3, t0].T
+    s0[:, [2, 4]] = tab[3:, t0].T
+    s0[:, 15:17] = tab[3:, t0].T
+    s0[:, 14] = rng_.uniform(0, 100, E_)
+    s0[:, 17], s0[:, 18] = t0, rng_.integers(0, 50, E_)
+    obs, _ = env.reset(options={"init_state": s0})
+    assert obs.shape == (E_, 4) and env.observation_space.shape == (4,) and np.isinf(env.observation_space.high).all()
+    oracles = []
+    for e in range(E_):
+        o = O.OracleEnv(net, sparse=False, aux_bounds=((0, 95), (0, 1e6)), next_vars=next_vars_np)
+        _, conv = o.reset_to(s0[e])
+        assert conv == (not bool(env.terminated[e]))
+        oracles.append(o)
+    f = lambda s: np.array([s[0] + s[2], s[14] * 0.01, s[-1], s[7:14].sum()])
+    npt.assert_allclose(obs.cpu().numpy(), np.stack([f(o.state) for o in oracles]), rtol=0, atol=1e-8)
+    lo, hi = env.action_space.low, env.action_space.high
+    n_term = 0
+    for t in range(T):
+        a = rng_.uniform(lo, hi, (E_, len(lo)))
+        obs, r, term, _, _ = env.step(torch.as_tensor(a, device=dev))
+        for e, o in enumerate(oracles):
+            oo, rr, tt = o.step(a[e])
+            assert tt == bool(term[e]), (t, e)
+            npt.assert_allclose(float(r[e]), rr, rtol=1e-9, atol=1e-10)
+            npt.assert_allclose(env.state[e].cpu().numpy(), o.state, rtol=0, atol=1e-8)
+            npt.assert_allclose(obs[e].cpu().numpy(), 0.0 if tt else f(o.state), rtol=0, atol=1e-8)
+        n_term += int(term.sum())
+    assert n_term < E_  # most environments survive the random steps
+    return env

@@ -1,0 +1,141 @@
+"""GPU tier, round 2: parity exactly where the headline number is taken, and on the entry points the
+round-1 suite only reached indirectly.
+
+* the benchmarked configuration (65 536 autoresetting ANM6Easy environments, Newton tolerance 1e-6,
+  reference iteration cap) replayed by the oracle for hundreds of environments, autoreset draws included,
+  with exact Newton iteration counts;
+* the reference's ``Simulator.reset`` golden vectors (``tests/golden/reset_*.npz``, 350 cases incl.
+  non-converged ones) through ``anm_reset_f64`` and ``BatchedSimulator.reset`` on both kernel families
+  (simulator.py:225-293, anm_env.py:266-311);
+* BASELINE.json config 5's partition rule on one GPU: two half batches keyed by ``env_offset`` are
+  bit-identical to the unsharded batch;
+* a callable observation and a K = 2 task with a host ``next_vars`` hook against the oracle
+  (anm_env.py:176-191, 511-514);
+* one captured step of the two-launch mode replayed from a HIP graph is bit-identical to eager steps.
+"""
+import os
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+import torch
+
+import parity_common as pc
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+KW = lambda net: {"device": DEV}
+_uniform_actions = pc.uniform_actions
+
+
+@pytest.mark.parametrize("handoff", ["auto", 0, 2])
+def test_headline_config_oracle_replay(handoff):
+    """bench.py's configuration (65 536 environments, tol 1e-6, autoreset, reference cap) for 10 steps; 256+
+    environments replayed by the oracle.  handoff=0 forces every solve through the lane-group continuation
+    from its first iteration, 2 most of them; "auto" is the shipped policy."""
+    n, n_term, n_reset = pc.headline_replay(KW, 65536, 10, 224, 64, handoff_after=handoff)
+    assert n >= 256 and n_term >= 32 and n_reset >= 32
+
+
+@pytest.mark.parametrize("name,impl", [("anm6", "thread"), ("anm6", "radial"), ("3bus", "thread")])
+def test_reset_golden_simulator_and_env(name, impl):
+    env = pc.reset_golden(name, KW, impl)
+    assert env.simulator.backend.path.endswith(".so") and "gym_anm_amd/_build/libanm_" in env.simulator.backend.path
+
+
+def test_sharded_batches_equal_the_unsharded_batch():
+    n_term, max_resets = pc.sharded_equal_unsharded(KW, 16384, 40)
+    assert n_term > 50 and max_resets >= 2
+
+
+def test_two_devices_shard_like_one():
+    """The same partition rule across two real devices (skipped on a single-GPU box)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 8192
+    H = E_ // 2
+    whole = ANM6EasyVec(num_envs=E_, device="cuda:0", seed=7, tol=1e-6, autoreset=True)
+    parts = [ANM6EasyVec(num_envs=H, device="cuda:%d" % k, seed=7, tol=1e-6, autoreset=True, env_offset=k * H)
+             for k in range(2)]  # fmt: skip
+    for env in [whole] + parts:
+        env.check_actions = False
+        env.reset(seed=7, options={"sampler": "device"})
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    for t in range(20):
+        a = _uniform_actions(whole, gen)
+        o, r, term, _, _ = whole.step(a)
+        for k, env in enumerate(parts):
+            ok, rk, tk, _, _ = env.step(a[k * H : (k + 1) * H].to(env.device))
+            assert torch.equal(ok.cpu(), o[k * H : (k + 1) * H].cpu()) and torch.equal(rk.cpu(), r[k * H : (k + 1) * H].cpu())
+            assert torch.equal(tk.cpu(), term[k * H : (k + 1) * H].cpu())
+
+
+def test_callable_observation_and_two_aux_variables():
+    pc.callable_observation_and_two_aux(KW)
+
+
+def test_next_vars_of_the_wrong_size_is_refused():
+    from gym_anm_amd import errors, networks
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    class Bad(BatchedANMEnv):
+        def __init__(self, **kw):
+            super().__init__(networks.anm6_network(), "state", 1, 0.25, 0.995, 100, **kw)
+
+        def next_vars(self, s_t):
+            return torch.zeros((self.num_envs, 5), dtype=torch.float64, device=s_t.device)
+
+    env = Bad(num_envs=4, device=DEV)
+    env.reset(options={"init_state": np.zeros(env.state_N)})
+    with pytest.raises(errors.EnvNextVarsError):
+        env.step(torch.zeros((4, 6), dtype=torch.float64, device=DEV))
+
+
+@pytest.mark.parametrize("n_capture", [1, 3])
+def test_captured_two_launch_step_replays_bit_identically(n_capture):
+    """One (or an odd number of) two-launch steps captured in a HIP graph and replayed: the record
+    counters are handled entirely on the device, so every replay equals the eager step bit for bit."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 65536
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=9, autoreset=True, tol=1e-6, straggler_after=4, handoff_after=-1)
+            for _ in range(2)]  # fmt: skip
+    for env in envs:
+        assert env._ws is not None
+        env.check_actions = False
+        env.reset(seed=9)
+    eager, graphed = envs
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    static_a = _uniform_actions(graphed, gen)
+    stream = torch.cuda.Stream(device=DEV)
+    stream.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(stream):
+        for _ in range(2):  # warm-up on the side stream, mirrored on the eager environment
+            graphed.step(static_a)
+    torch.cuda.current_stream(DEV).wait_stream(stream)
+    for _ in range(2):
+        eager.step(static_a)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        for _ in range(n_capture):
+            graphed.step(static_a)
+    # capture does not execute: the eager environment is not advanced here
+    n_term = 0
+    for rep in range(6):
+        a = _uniform_actions(eager, gen)
+        static_a.copy_(a)
+        graph.replay()
+        for _ in range(n_capture):
+            o, r, term, _, _ = eager.step(a)
+        torch.cuda.synchronize()
+        n_term += int(term.sum())
+        for x, y in ((graphed._state_obs, o), (graphed.reward, r), (graphed.terminated, term), (graphed.state, eager.state),
+                     (graphed.simulator.soc, eager.simulator.soc), (graphed.simulator.nr_iters, eager.simulator.nr_iters),
+                     (graphed._reset_count, eager._reset_count), (graphed.timestep, eager.timestep)):  # fmt: skip
+            assert torch.equal(x, y), rep
+    assert n_term > 100

@@ -180,3 +180,28 @@ def test_random_meshed_networks_against_oracle(n_bus, seed, n_chords):
         np.testing.assert_allclose(float(sim.reward[e]), ref["reward"], rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(sim.soc[e].numpy(), ref["soc_after"], rtol=0, atol=1e-12)
     assert n_conv >= M // 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: the bodies of tests/test_gpu_headline.py on the host test double (host layer + kernel logic)
+# ---------------------------------------------------------------------------------------------------
+_KW = lambda net: {"device": "cpu", "_backend": _backend(net)}
+
+
+def test_headline_config_oracle_replay_small():
+    n, n_term, n_reset = pc.headline_replay(_KW, 4096, 10, 24, 24)
+    assert n >= 32 and n_term >= 8 and n_reset >= 8
+
+
+@pytest.mark.parametrize("name", ["anm6", "3bus"])
+def test_reset_golden_simulator_and_env(name):
+    pc.reset_golden(name, _KW)
+
+
+def test_sharded_batches_equal_the_unsharded_batch():
+    n_term, max_resets = pc.sharded_equal_unsharded(_KW, 2048, 30)
+    assert n_term > 20 and max_resets >= 1
+
+
+def test_callable_observation_and_two_aux_variables():
+    pc.callable_observation_and_two_aux(_KW, E_=24, T=12)

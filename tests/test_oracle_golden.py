@@ -227,10 +227,31 @@ def test_known_soc_update():  # test_devices.py:456-492
     assert O.update_soc(n, 1, 9.9, -1.0) == 10.0 and O.update_soc(n, 1, 1.1, 1.0) == 1.0
 
 
-def test_known_reward():  # test_simulator_basics.py:247-293 restated on the oracle's reward formula
+def test_known_reward():
+    """The reference's two reward known answers (tests/simulator/test_simulator_basics.py:247-293),
+    network fixture of :10-33 restated as data, through the oracle's compute_reward."""
+    N_ = None
+    net = {
+        "baseMVA": 10,
+        "bus": np.array([[0, 1, 50, 1.1, 0.9], [2, 1, 50, 1.1, 0.9], [1, 0, 100, 1.0, 1.0]]),
+        "branch": np.array([[0, 1, 0.1, 0.2, 0.3, 20, 1, 90], [1, 2, 0.4, 0.5, 0.6, 20, 2, 0]]),
+        "device": np.array([
+            [1, 0, -1, 0.2, 0, -10, N_, N_, N_, N_, N_, N_, N_, N_, N_],
+            [0, 1, 0, N_, 200, -200, 200, -200, N_, N_, N_, N_, N_, N_, N_],
+            [2, 2, 2, N_, 30, 0, 30, -30, N_, N_, N_, N_, N_, N_, N_],
+            [3, 2, 3, N_, 50, -50, 50, -50, N_, N_, N_, N_, 100, 0, 0.9],
+        ]),
+    }  # fmt: skip
     base, lamb, dt = 10.0, 100, 0.5
-    p_dev = np.array([20, -5, 20, -30]) / base
-    e_loss = (p_dev[0] + p_dev[1] + p_dev[2] + max(0, 25 / base - p_dev[2])) * dt
-    npt.assert_allclose(e_loss, 40 * dt / base)
-    pen = lamb * dt * (0.1 + 0.1 + (3 - 2) + (4 - 2))
-    npt.assert_allclose(pen, lamb * dt * (0.2 + 30 / base))
+    n = O.parse_network(net, dt, lamb)
+    assert [int(t) for t in n.dev_type] == [O.SLACK, O.LOAD, O.RENEWABLE, O.STORAGE]  # sorted by device id
+    # the reference sets devices[i].p by device id: ids 0..3 -> p = [20, -5, 20, -30] MW
+    dev_p = np.array([20, -5, 20, -30]) / base
+    p_pot = np.array([25 / base])
+    # buses sorted by id: the test assigns v to buses[0], buses[1], buses[2]
+    e, pen = O.compute_reward(n, dev_p, p_pot, np.array([1.0, 1.0, 1.0]), np.array([10, 10]) / base)
+    npt.assert_allclose(e, 40 * dt / base, rtol=1e-12)
+    assert pen == 0
+    e, pen = O.compute_reward(n, dev_p, p_pot, np.array([1.2, 1.0, 0.8]), np.array([30, 40]) / base)
+    npt.assert_allclose(e, 40 * dt / base, rtol=1e-12)
+    npt.assert_allclose(pen, lamb * dt * (0.2 + 30 / base), rtol=1e-12)
