@@ -140,8 +140,10 @@ def tree_tables(n_bus, branches, ypat):
     nch_h = [max([len(children[b]) for b in range(1, n_bus) if height[b] == h] + [0]) for h in range(maxh + 1)]
     pos = {ij: z for z, ij in enumerate(ypat)}
     grp = 8
-    while grp < n_bus - 1:
+    while grp < n_bus:  # n_bus - 1 bus lanes + at least one padding lane (the neutral source of the hand-overs)
         grp *= 2
+    if grp > 64:
+        return None
     return dict(
         GRP=grp, MAXCH=maxch, MAXH=maxh, MAXD=maxd,
         PARENT=[-1] + [parent[b] for b in range(1, n_bus)],
@@ -151,6 +153,162 @@ def tree_tables(n_bus, branches, ypat):
         ZBP=[-1] + [pos[(b, parent[b])] for b in range(1, n_bus)],
         ZPB=[-1] + [pos[(parent[b], b)] for b in range(1, n_bus)],
     )  # fmt: skip
+
+
+def dpp_plan(n_bus, tt):
+    """Lane layout + DPP steps for the hand-overs of the lane-group Newton trip, when the tree allows it.
+
+    A hand-over ("every lane gets the value its parent holds", "... its c-th child holds") is a general
+    permutation, served by ds_bpermute_b32 (one LDS-pipe instruction per dword plus the s_waitcnt that
+    follows).  A DPP move (v_mov_b32_dpp row_shl/row_shr) is one plain VALU instruction -- but it only shifts
+    whole 16-lane rows by a constant, for whole banks of 4 lanes.  This search looks for positions of the
+    buses inside the group such that every hand-over class is at most two such moves: all the
+    (destination <- source) pairs of a move share one offset; every other lane a move writes either does not
+    care (padding lane), is overwritten by the next move, or reads a NEUTRAL value.  Padding lanes hold
+    V = 1 + 0j, W = 0, Schur complement 0 in every group of the wavefront, which is exactly "the parent of a
+    bus attached to the slack" and "no such child".  The first move of a class is preferably a full-row move
+    with bound_ctrl (lanes shifted in from outside the row read 0, no `old` operand to initialise); a second
+    move is restricted to banks.  Groups of 8 lanes only (two groups per DPP row).  Returns None when no
+    layout works (the hand-overs then use ds_bpermute_b32)."""
+    import itertools
+
+    parent, maxch = tt["PARENT"], tt["MAXCH"]
+    ch = [tt["CH"][b * maxch:(b + 1) * maxch] for b in range(n_bus)]
+    buses = list(range(1, n_bus))
+    roots = [b for b in buses if parent[b] == 0]
+    if maxch > 2 or len(roots) > 2 or n_bus - 1 > 15:
+        return None
+    # the smallest group that has a plan: more solves per wavefront matters more than a cheaper move or two (a
+    # wavefront with more stragglers than groups runs its Newton chain twice)
+    for G in (8, 16):
+        if n_bus > G:
+            continue
+        r = _dpp_plan_for_group(G, n_bus, parent, ch, maxch, buses, roots, tt)
+        if r is not None:
+            return r[1]
+    return None
+
+
+def _dpp_plan_for_group(G, n_bus, parent, ch, maxch, buses, roots, tt):
+    import itertools
+
+    ngr = 16 // G
+
+    def simulate(steps, lane_bus, pairs, accept_zero):
+        """steps: [(offset, bank set within the group or None = full row)].  True when every lane of the row
+        ends with what it needs.  accept_zero: a lane without a source may read 0 / keep `old`; otherwise
+        (parent class: V of the slack = 1) it must keep `old` or read a padding lane."""
+        out = ["OLD"] * 16
+        for off, banks in steps:
+            for i in range(16):
+                g, l = divmod(i, G)
+                if banks is not None and (l // 4) not in banks:
+                    continue
+                src = i + off
+                if 0 <= src < 16:
+                    out[i] = divmod(src, G)
+                elif banks is None:
+                    out[i] = "ZERO"  # bound_ctrl
+        for i in range(16):
+            g, l = divmod(i, G)
+            v = out[i]
+            if lane_bus[l] == 0:
+                continue  # padding lane: don't care
+            if l in pairs:
+                if v != (g, pairs[l]):
+                    return False
+            elif v == "OLD":
+                continue
+            elif v == "ZERO":
+                if not accept_zero:
+                    return False
+            elif lane_bus[v[1]] != 0:
+                return False  # reads some bus lane's value
+        return True
+
+    def solve_class(lane_bus, pairs, accept_zero):
+        by_off = {}
+        for d, s_ in pairs.items():
+            by_off.setdefault(s_ - d, set()).add(d // 4)
+        offs = sorted(by_off)
+        if not offs:
+            return []
+        if len(offs) > 2:
+            return None
+        cands = []
+        if len(offs) == 1:
+            cands = [[(offs[0], None)], [(offs[0], by_off[offs[0]])]]
+        else:
+            a, b = offs
+            cands = [[(a, None), (b, by_off[b])], [(b, None), (a, by_off[a])], [(a, by_off[a]), (b, by_off[b])]]
+        best = None
+        for st in cands:
+            if simulate(st, lane_bus, pairs, accept_zero):
+                # a bank-masked first move leaves the other lanes undefined: its consumers then run under an
+                # exec mask ("has such a child"), a few scalar instructions per use
+                cost = len(st) + (0 if st[0][1] is None else 0.25)
+                if best is None or cost < best[0]:
+                    best = (cost, st)
+        return None if best is None else best
+
+    # Layouts worth trying: the c-th child of every bus sits at a fixed offset o_c from its parent, so that
+    # "value of my c-th child" is ONE row shift; the layout is then fixed by the offsets and the root positions.
+    # Weights: how many dwords per Newton trip go through each class (V and the Newton step from the parent;
+    # W and, per elimination level, Schur complement + reduced right-hand side from each child).
+    w_par = 4 + 4 * tt["MAXD"]
+    w_ch = 4 + 12 * sum(1 for x in tt["NCH_H"] if x > 0)
+    offs = [o for o in range(-(G - 1), G) if o != 0]
+    best = None
+    for o in itertools.product(offs, repeat=maxch):
+        if len(set(o)) < maxch:
+            continue
+        for rpos in itertools.permutations(range(G), len(roots)):
+            pos, ok, todo = {}, True, []
+            for rb, rp in zip(roots, rpos):
+                pos[rb] = rp
+                todo.append(rb)
+            while todo and ok:
+                b = todo.pop()
+                for c in range(maxch):
+                    k = ch[b][c]
+                    if k > 0:
+                        pos[k] = pos[b] + o[c]
+                        ok = ok and 0 <= pos[k] < G
+                        todo.append(k)
+            if not ok or len(set(pos.values())) != len(buses):
+                continue
+            lane_bus = [0] * G
+            for b, l in pos.items():
+                lane_bus[l] = b
+            r = solve_class(lane_bus, {pos[b]: pos[parent[b]] for b in buses if parent[b] > 0}, False)
+            if r is None:
+                continue
+            plan, cost = {"PAR": r[1] if r else []}, (r[0] if r else 0) * w_par
+            for c in range(maxch):
+                r = solve_class(lane_bus, {pos[b]: pos[ch[b][c]] for b in buses if ch[b][c] > 0}, True)
+                if r is None:
+                    plan = None
+                    break
+                plan["CH%d" % c] = r[1] if r else []
+                cost += (r[0] if r else 0) * w_ch
+            if plan is None:
+                continue
+            if best is None or cost < best[0]:
+                best = (cost, pos, lane_bus, plan)
+    if best is None:
+        return None
+    cost, pos, lane_bus, plan = best
+
+    def encode(st):
+        out = []
+        for off, banks in st:
+            ctrl = (0x100 + off) if off > 0 else (0x110 - off)  # row_shl:n reads lane i + n, row_shr:n lane i - n
+            mask = 0xF if banks is None else sum(1 << (b + g * (G // 4)) for b in banks for g in range(ngr))
+            out.append((ctrl, mask, 1 if banks is None else 0))
+        return out
+
+    return cost, dict(GRP=G, POS=[0] + [pos[b] for b in buses], LANE_BUS=lane_bus,
+                      plan={k: encode(v) for k, v in plan.items()})
 
 
 def _arr(name, values, typ="int"):
@@ -225,14 +383,41 @@ def emit_header(topo, name=None) -> str:
     if tt is None:
         lines += ["  static constexpr int TREE = 0, GRP = 64;"]
     else:
+        dp = None if os.environ.get("ANM_NO_DPP") else dpp_plan(n_bus, tt)  # ANM_NO_DPP: tuning switch
         lines += [
             "  // rooted-tree view (lane-group Newton continuation, csrc/anm_group.hpp): lane l <-> bus l + 1",
             "  static constexpr int TREE = 1, GRP = %d, T_MAXCH = %d, T_MAXH = %d, T_MAXD = %d;"
-            % (tt["GRP"], tt["MAXCH"], tt["MAXH"], tt["MAXD"]),
+            % (dp["GRP"] if dp else tt["GRP"], tt["MAXCH"], tt["MAXH"], tt["MAXD"]),
             _arr("T_PARENT", tt["PARENT"]), _arr("T_HEIGHT", tt["HEIGHT"]), _arr("T_DEPTH", tt["DEPTH"]),
             _arr("T_NCH", tt["NCH"]), _arr("T_CH", tt["CH"]), _arr("T_NCH_H", tt["NCH_H"]),
             _arr("T_ZBB", tt["ZBB"]), _arr("T_ZBP", tt["ZBP"]), _arr("T_ZPB", tt["ZPB"]),
         ]  # fmt: skip
+        if dp is None:  # hand-overs by ds_bpermute_b32, bus b in lane b - 1
+            lane_bus = [b if b < n_bus else 0 for b in range(1, tt["GRP"] + 1)]
+            lines += ["  static constexpr int T_DPP = 0;", _arr("T_LANE_BUS", lane_bus),
+                      _arr("T_POS", [0] + list(range(n_bus - 1)))]
+            lines += ["  static constexpr int T_PAR_N = 0;", _arr("T_PAR_CTRL", [0, 0]), _arr("T_PAR_BANK", [0, 0]),
+                      _arr("T_PAR_FULL", [0, 0]),
+                      _arr("T_CH_N", [0] * tt["MAXCH"]), _arr("T_CH_CTRL", [0] * (2 * tt["MAXCH"])),
+                      _arr("T_CH_BANK", [0] * (2 * tt["MAXCH"])), _arr("T_CH_FULL", [0] * (2 * tt["MAXCH"]))]
+        else:
+            pl = dp["plan"]
+            pad2 = lambda st: [x for x in st] + [(0, 0, 0)] * (2 - len(st))
+            chn, chc, chb, chf = [], [], [], []
+            for c in range(tt["MAXCH"]):
+                st = pl["CH%d" % c]
+                chn.append(len(st))
+                chc += [x[0] for x in pad2(st)]
+                chb += [x[1] for x in pad2(st)]
+                chf += [x[2] for x in pad2(st)]
+            lines += [
+                "  // hand-overs as DPP row shifts (codegen.dpp_plan): lane of each bus, bus of each lane (0 = padding)",
+                "  static constexpr int T_DPP = 1;", _arr("T_LANE_BUS", dp["LANE_BUS"]), _arr("T_POS", dp["POS"]),
+                "  static constexpr int T_PAR_N = %d;" % len(pl["PAR"]),
+                _arr("T_PAR_CTRL", [x[0] for x in pad2(pl["PAR"])]), _arr("T_PAR_BANK", [x[1] for x in pad2(pl["PAR"])]),
+                _arr("T_PAR_FULL", [x[2] for x in pad2(pl["PAR"])]),
+                _arr("T_CH_N", chn), _arr("T_CH_CTRL", chc), _arr("T_CH_BANK", chb), _arr("T_CH_FULL", chf),
+            ]  # fmt: skip
     lines += [
         "};",
         "}  // namespace",

@@ -37,7 +37,7 @@ int fail_hip(hipError_t e, const char* where) {
 }
 
 #ifndef ANM_HANDOFF_DEFAULT
-#define ANM_HANDOFF_DEFAULT 8
+#define ANM_HANDOFF_DEFAULT 6
 #endif
 #ifndef ANM_ROWS_WAVES
 #define ANM_ROWS_WAVES 1  // min. waves per SIMD the step kernel is compiled for (register budget 512 / waves)

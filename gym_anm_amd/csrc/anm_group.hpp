@@ -27,15 +27,102 @@
 namespace anm {
 namespace group {
 
-// value of `x` in lane `src4 / 4` of the wavefront (every lane must be executing: an inactive source lane
-// reads as 0)
-__device__ __forceinline__ double lane_get(double x, int src4) {
+// llvm CmpInst predicate codes taken by __builtin_amdgcn_{fcmp,uicmp,sicmp}: they return the compare as a
+// 64-bit lane mask in scalar registers (no bool -> ballot round trip)
+enum : int { FCMP_UNO = 8, FCMP_UGT = 10, ICMP_NE = 33, ICMP_SLT = 40 };
+
+// ---------------------------------------------------------------------------------------------
+// Hand-overs between the lanes of a group.  Two implementations behind one interface, chosen per topology
+// by codegen.dpp_plan:
+//   * DPP row shifts (v_mov_b32_dpp row_shl/row_shr + bank mask): no latency to wait for, when the tree has
+//     a lane layout in which every hand-over class is at most two whole-row shifts;
+//   * ds_bpermute_b32 (the LDS crossbar, no LDS memory): any tree, ~100 cycles of latency per hand-over.
+// Both rely on the PADDING lanes of a group (there is always at least one) holding neutral values in every
+// group of the wavefront -- V = 1 + 0j, W = 0, Schur complement 0, step 0 -- so that "the parent of a bus
+// attached to the slack" and "a child this bus does not have" are ordinary sources: no selects.
+// Every lane of the wavefront must be executing at a hand-over.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bperm(double x, int src4) {
+#ifdef ANM_GROUP_FAKE_XFER  // timing experiment only (wrong results): what the trips cost without the hand-overs
+  return x + double(src4) * 1e-300;
+#endif
   const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(x));
   const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(x));
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float lane_get(float x, int src4) {
+__device__ __forceinline__ float bperm(float x, int src4) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(x)));
+}
+// One DPP move of x.  FULL: whole-row move with bound_ctrl (lanes shifted in from outside the row read 0).
+// FIRST && !FULL: a bank-masked move with nothing to merge into -- the lanes it does not write are left
+// UNDEFINED (no register to initialise); the caller only consumes it on the lanes that have a source.
+template <int CTRL, int BANK, int FULL, bool FIRST>
+__device__ __forceinline__ int dpp_move32(int old, int x) {
+  if constexpr (FIRST) {
+    (void)old;
+    return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, FULL ? 0xF : BANK, FULL != 0);
+  } else {
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, BANK, false);
+  }
+}
+template <int CTRL, int BANK, int FULL, bool FIRST>
+__device__ __forceinline__ double dpp_move(double old, double x) {
+  const int lo = dpp_move32<CTRL, BANK, FULL, FIRST>(__double2loint(old), __double2loint(x));
+  const int hi = dpp_move32<CTRL, BANK, FULL, FIRST>(__double2hiint(old), __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int BANK, int FULL, bool FIRST>
+__device__ __forceinline__ float dpp_move(float old, float x) {
+  return __int_as_float(dpp_move32<CTRL, BANK, FULL, FIRST>(__float_as_int(old), __float_as_int(x)));
+}
+
+template <class T>
+struct Lanes {
+  int psrc4;               // bpermute address of the parent's lane (roots, padding lanes: a padding lane)
+  int csrc4[T::T_MAXCH];   // ... of the c-th child's lane (no such child: a padding lane)
+
+  // x as held by the lane of this lane's parent bus (a bus attached to the slack, a padding lane: what a
+  // padding lane holds, `neutral`)
+  template <class R>
+  __device__ __forceinline__ R from_parent(R x, R neutral) const {
+    if constexpr (T::T_DPP != 0) {
+      R v = neutral;
+      if constexpr (T::T_PAR_N > 0) {
+        static_assert(T::T_PAR_FULL[0] != 0, "codegen.dpp_plan: the first parent move covers the whole row");
+        v = dpp_move<T::T_PAR_CTRL[0], T::T_PAR_BANK[0], 1, true>(v, x);
+      }
+      if constexpr (T::T_PAR_N > 1) v = dpp_move<T::T_PAR_CTRL[1], T::T_PAR_BANK[1], 0, false>(v, x);
+      return v;
+    } else {
+      return bperm(x, psrc4);
+    }
+  }
+  // does from_child<CH> deliver the neutral 0 on the lanes without such a child?  (else: undefined there)
+  template <int CH>
+  static constexpr bool child_neutral() {
+    return T::T_DPP == 0 || T::T_CH_N[CH] == 0 || T::T_CH_FULL[2 * CH] != 0;
+  }
+  // x as held by the lane of this lane's CH-th child
+  template <int CH, class R>
+  __device__ __forceinline__ R from_child(R x) const {
+    if constexpr (T::T_DPP != 0) {
+      R v = R(0);
+      if constexpr (T::T_CH_N[CH] > 0)
+        v = dpp_move<T::T_CH_CTRL[2 * CH], T::T_CH_BANK[2 * CH], T::T_CH_FULL[2 * CH], true>(v, x);
+      if constexpr (T::T_CH_N[CH] > 1)
+        v = dpp_move<T::T_CH_CTRL[2 * CH + 1], T::T_CH_BANK[2 * CH + 1], 0, false>(v, x);
+      return v;
+    } else {
+      return bperm(x, csrc4[CH]);
+    }
+  }
+};
+
+template <class T>
+constexpr int first_padding_lane() {
+  for (int l = 0; l < T::GRP; ++l)
+    if (T::T_LANE_BUS[l] == 0) return l;
+  return -1;
 }
 
 // LDS slot of one handed-over solve: 5 per-bus arrays + the iteration count / flags
@@ -63,25 +150,26 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
   typedef Slot<T> S;
   constexpr int G = Shape<T>::G, NG = Shape<T>::NG, NB = T::NB;
   const int lane = threadIdx.x & 63;
-  const int l = lane & (G - 1);        // bus l + 1
+  const int l = lane & (G - 1);        // position inside the group
   const int gb = lane - l;             // first lane of this group
   const int grp = lane / G;
-  const int b = (l + 1 < NB) ? l + 1 : 0;
-  const bool lane_bus = (l + 1 < NB);
+  constexpr int PAD = first_padding_lane<T>();
+  static_assert(PAD >= 0, "a lane group needs a padding lane (codegen.tree_tables)");
 
   // ---- per-lane view of the tree (constant tables indexed by the lane: loaded once)
-  const int parent = T::T_PARENT[b];                 // 0: slack, -1: padding lane
+  const int b = T::T_LANE_BUS[l];                    // bus played by this lane, 0: padding lane
+  const bool lane_bus = b > 0;
+  const int parent = T::T_PARENT[b];                 // 0: slack (b is a root of the elimination forest)
   const int height = lane_bus ? T::T_HEIGHT[b] : -1;
   const int depth = lane_bus ? T::T_DEPTH[b] : -1;
   const int nch = lane_bus ? T::T_NCH[b] : 0;
-  const int psrc4 = 4 * ((lane_bus && parent > 0) ? gb + parent - 1 : lane);
-  int csrc4[T::T_MAXCH];
+  Lanes<T> X;
+  X.psrc4 = 4 * (gb + ((lane_bus && parent > 0) ? T::T_POS[parent] : PAD));
   static_for<0, T::T_MAXCH>([&](auto Cc) {
     const int c = lane_bus ? T::T_CH[b * T::T_MAXCH + Cc] : -1;
-    csrc4[Cc] = 4 * (c > 0 ? gb + c - 1 : lane);
+    X.csrc4[Cc] = 4 * (gb + (c > 0 ? T::T_POS[c] : PAD));
   });
-  const bool root = lane_bus && parent == 0;         // attached to the slack bus (V_0 = 1)
-  double ybb_r = 0, ybb_i = 0, ybp_r = 0, ybp_i = 0, ypb_r = 0, ypb_i = 0;
+  double ybb_r = 0, ybb_i = 0, ybp_r = 0, ybp_i = 0, ypb_r = 0, ypb_i = 0;   // padding lanes: Y = 0 -> W = 0
   if (lane_bus) {
     ybb_r = C[L::Y_RE + T::T_ZBB[b]]; ybb_i = C[L::Y_IM + T::T_ZBB[b]];
     ybp_r = C[L::Y_RE + T::T_ZBP[b]]; ybp_i = C[L::Y_IM + T::T_ZBP[b]];
@@ -117,14 +205,23 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
     ANM_WAVE_SYNC();
 
     // ---- the reference's loop, rotated like pf_iterate (anm_device.hpp): evaluate; account for the update of
-    // the previous trip; leave when no group runs; update
-    bool f_gt = false, f_nan = false;   // ||F||inf > tol / F has a NaN, for the iterate of this group
-    bool inc = false, take = gvalid;
+    // the previous trip; leave when no group runs; update.  `running` is uniform over a group; a group that
+    // stopped (or holds no solve) rides along: its lanes keep executing, nothing of it changes any more.
+    // Predicates live as 64-bit lane masks in scalar registers (v_cmp writes them there; the loop control is
+    // then SALU work): `runm` = lanes of the groups that are still iterating.
+    const unsigned long long busm = __builtin_amdgcn_uicmp(isbus ? 1u : 0u, 0u, ICMP_NE);
+    unsigned long long runm = __builtin_amdgcn_uicmp(gvalid ? 1u : 0u, 0u, ICMP_NE);
+    const unsigned glo = unsigned(gmask & busm), ghi = unsigned((gmask & busm) >> 32);   // bus lanes of my group
+    unsigned tb = 0u, tn = 0u;   // != 0: ||F||inf > tol (or NaN) / F has a NaN, somewhere in my group
+    it -= gvalid ? 1 : 0;        // the first trip only evaluates: its `it += running` is undone here
+    // What a lane publishes for its parent (Schur complement, reduced right-hand side) and its Newton step:
+    // a bus lane rewrites them at its own level of every trip before anybody reads them; a padding lane never
+    // does, so these zeros are the neutral values the hand-overs rely on.
+    Blk<JT> Sc = Blk<JT>{JT(0), JT(0), JT(0), JT(0)};
+    JT Lr0 = JT(0), Lr1 = JT(0), d0 = JT(0), d1 = JT(0);
     for (;;) {
       const double vr = vm * cs, vi = vm * sn;
-      double vpr = lane_get(vr, psrc4), vpi = lane_get(vi, psrc4);
-      vpr = root ? 1.0 : vpr;
-      vpi = root ? 0.0 : vpi;
+      const double vpr = X.from_parent(vr, 1.0), vpi = X.from_parent(vi, 0.0);
       // W_bb = conj(Y_bb) vm^2;  P = V_b conj(V_p):  W_bp = conj(Y_bp) P,  W_pb = conj(Y_pb) conj(P)
       const double m2 = vm * vm;
       const double wbb_r = ybb_r * m2, wbb_i = -(ybb_i * m2);
@@ -134,22 +231,24 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
       // S_b = W_bb + W_bp + sum over the children c of W_pb(c)
       double sr = wbb_r + wbp_r, si = wbb_i + wbp_i;
       static_for<0, T::T_MAXCH>([&](auto Cc) {
-        const double cr = lane_get(wpb_r, csrc4[Cc]), ci = lane_get(wpb_i, csrc4[Cc]);
-        const bool has = Cc < nch;
-        sr += has ? cr : 0.0;
-        si += has ? ci : 0.0;
+        const double cr = X.template from_child<Cc>(wpb_r), ci = X.template from_child<Cc>(wpb_i);
+        if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
+          sr += cr;
+          si += ci;
+        }
       });
       const double fr = sr - bus_p, fi = si - bus_q;
-      // group-wide stop test: ||F||inf > tol and "F has a NaN" are all the reference's loop and flags need
-      const bool gt = isbus && (fmax(fabs(fr), fabs(fi)) > tol);
-      const bool nn = isbus && ((fr != fr) || (fi != fi));
-      const bool any_gt = (__ballot(gt) & gmask) != 0ull;
-      const bool any_nn = (__ballot(nn) & gmask) != 0ull;
-      it = inc ? it + 1 : it;
-      f_gt = take ? any_gt : f_gt;
-      f_nan = take ? any_nn : f_nan;
-      const bool run = gvalid && f_gt && !f_nan && (it < max_iter);   // NaN > tol is false, like the reference
-      if (!__any(run)) break;
+      // group-wide stop test: "||F||inf > tol" and "F has a NaN" are all the reference's loop and flags need.
+      // A group that has stopped keeps evaluating the same frozen iterate, so what the last trip computed
+      // is also each group's final verdict: nothing but `runm` and `it` is carried over.
+      const unsigned long long badm = __builtin_amdgcn_fcmp(fmax(fabs(fr), fabs(fi)), tol, FCMP_UGT);
+      const unsigned long long nanm = __builtin_amdgcn_fcmp(fr, fi, FCMP_UNO);
+      tb = (unsigned(badm) & glo) | (unsigned(badm >> 32) & ghi);
+      tn = (unsigned(nanm) & glo) | (unsigned(nanm >> 32) & ghi);
+      it += __builtin_amdgcn_inverse_ballot_w64(runm) ? 1 : 0;   // the update applied in the previous trip
+      runm &= __builtin_amdgcn_uicmp(tb, 0u, ICMP_NE) & ~__builtin_amdgcn_uicmp(tn, 0u, ICMP_NE) &
+              __builtin_amdgcn_sicmp(it, max_iter, ICMP_SLT);   // NaN > tol is false, like the reference
+      if (runm == 0ull) break;
 
       // ---- Jacobian blocks (anm_device.hpp: newton_update): own diagonal and the two couplings with the parent
       Blk<JT> Dg = Blk<JT>{JT(-(si - wbb_i)), JT(sr + wbb_r), JT(sr - wbb_r), JT(si + wbb_i)};
@@ -157,41 +256,41 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
       const Blk<JT> Jpb = Blk<JT>{JT(wpb_i), JT(wpb_r), JT(-wpb_r), JT(wpb_i)};
       JT r0 = JT(fr), r1 = JT(fi);
       // ---- elimination by height: a bus folds the Schur complements and reduced right-hand sides its
-      // children published (registers Sc / Lr of the child lanes), inverts its pivot and publishes its own
-      Blk<JT> Sc = Blk<JT>{JT(0), JT(0), JT(0), JT(0)};
-      JT Lr0 = JT(0), Lr1 = JT(0);
+      // children published (registers Sc / Lr of the child lanes; 0 on padding lanes), inverts its pivot
+      // and publishes its own
       static_for<0, T::T_MAXH + 1>([&](auto H) {
         constexpr int h = H;
         constexpr int NC = T::T_NCH_H[h];
         JT ga[NC > 0 ? NC : 1], gbb[NC > 0 ? NC : 1], gc[NC > 0 ? NC : 1], gd[NC > 0 ? NC : 1], g0[NC > 0 ? NC : 1],
             g1[NC > 0 ? NC : 1];
         static_for<0, NC>([&](auto Cc) {
-          ga[Cc] = lane_get(Sc.a, csrc4[Cc]); gbb[Cc] = lane_get(Sc.b, csrc4[Cc]);
-          gc[Cc] = lane_get(Sc.c, csrc4[Cc]); gd[Cc] = lane_get(Sc.d, csrc4[Cc]);
-          g0[Cc] = lane_get(Lr0, csrc4[Cc]); g1[Cc] = lane_get(Lr1, csrc4[Cc]);
+          ga[Cc] = X.template from_child<Cc>(Sc.a); gbb[Cc] = X.template from_child<Cc>(Sc.b);
+          gc[Cc] = X.template from_child<Cc>(Sc.c); gd[Cc] = X.template from_child<Cc>(Sc.d);
+          g0[Cc] = X.template from_child<Cc>(Lr0); g1[Cc] = X.template from_child<Cc>(Lr1);
         });
         if (height == h) {
           static_for<0, NC>([&](auto Cc) {
-            if (Cc < nch) {
+            if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
               Dg.a -= ga[Cc]; Dg.b -= gbb[Cc]; Dg.c -= gc[Cc]; Dg.d -= gd[Cc];
               r0 -= g0[Cc]; r1 -= g1[Cc];
             }
           });
           Dg = blk_inv(Dg);
-          const Blk<JT> Lk = blk_mul(Jpb, Dg);
-          Sc = blk_mul(Lk, Jbp);
-          Lr0 = fm(Lk.a, r0, Lk.b * r1);
-          Lr1 = fm(Lk.c, r0, Lk.d * r1);
+          if constexpr (h < T::T_MAXH) {  // a bus of maximal height hangs off the slack: nobody folds it
+            const Blk<JT> Lk = blk_mul(Jpb, Dg);
+            Sc = blk_mul(Lk, Jbp);
+            Lr0 = fm(Lk.a, r0, Lk.b * r1);
+            Lr1 = fm(Lk.c, r0, Lk.d * r1);
+          }
         }
       });
       // ---- back substitution by depth (Dg now holds the inverted pivots)
-      JT d0 = JT(0), d1 = JT(0);
       static_for<0, T::T_MAXD + 1>([&](auto Dd) {
         constexpr int dd = Dd;
         JT p0 = JT(0), p1 = JT(0);
         if constexpr (dd > 0) {
-          p0 = lane_get(d0, psrc4);
-          p1 = lane_get(d1, psrc4);
+          p0 = X.from_parent(d0, JT(0));
+          p1 = X.from_parent(d1, JT(0));
         }
         if (depth == dd) {
           JT a0 = r0, a1 = r1;
@@ -203,37 +302,45 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
           d1 = fm(Dg.c, a0, Dg.d * a1);
         }
       });
-      // ---- update (group-uniform `run`); d1 is the relative magnitude step.  Rotation of (cos, sin) by the
-      // angle step, path chosen per wavefront exactly as update_angles does
-      const bool upd = run && isbus;
-      const double dth = upd ? double(d0) : 0.0;
-      const bool small_step = fabs(dth) <= 0.78;  // false for NaN
-      double sd_, cd_;
-      if (!__any(!small_step)) {
-        sincos_kernel(dth, 0, sd_, cd_);
-      } else if (fabs(dth) < 4.0e15) {
-        sincos_medium(dth, sd_, cd_);
-      } else {
-        const SinCos r = sincos_huge(dth);
-        sd_ = r.s;
-        cd_ = r.c;
-      }
-      if (upd) {
+      // ---- update of the running groups; d1 is the relative magnitude step.  Rotation of (cos, sin) by the
+      // angle step, path chosen per wavefront exactly as update_angles does (the reduction of a small step
+      // returns the same bits as the short path)
+      const unsigned long long updm = runm & busm;
+      const bool upd = __builtin_amdgcn_inverse_ballot_w64(updm);
+      const double dth = double(d0);
+      const unsigned long long bigm = __builtin_amdgcn_fcmp(fabs(dth), 0.78, FCMP_UGT) & updm;  // NaN counts
+      if (bigm == 0ull) {
+        if (upd) {
+          double sd_, cd_;
+          sincos_kernel(dth, 0, sd_, cd_);
+          vm = fma(-double(d1), fabs(vm), vm);
+          const double c0 = cs, s0 = sn;
+          cs = fma(c0, cd_, s0 * sd_);
+          sn = fma(s0, cd_, -(c0 * sd_));
+        }
+      } else if (upd) {
+        double sd_, cd_;
+        if (fabs(dth) < 4.0e15) {
+          sincos_medium(dth, sd_, cd_);
+        } else {
+          const SinCos r = sincos_huge(dth);
+          sd_ = r.s;
+          cd_ = r.c;
+        }
         vm = fma(-double(d1), fabs(vm), vm);
         const double c0 = cs, s0 = sn;
         cs = fma(c0, cd_, s0 * sd_);
         sn = fma(s0, cd_, -(c0 * sd_));
       }
-      inc = take = run;
     }
 
     // ---- results back to the owner lanes
     if (isbus) {
       double* s = lds + grp * S::SIZE;
       s[S::VM + b] = vm; s[S::CS + b] = cs; s[S::SN + b] = sn;
-      if (l == 0) {
+      if (b == 1) {
         s[S::IT] = double(it);
-        s[S::FLAGS] = f_nan ? NAN : (f_gt ? INFINITY : 0.0);
+        s[S::FLAGS] = (tn != 0u) ? NAN : ((tb != 0u) ? INFINITY : 0.0);
       }
     }
     ANM_WAVE_SYNC();

@@ -319,7 +319,6 @@ def callable_observation_and_two_aux(kw, E_=96, T=24):
     f = lambda s: np.array([s[0] + s[2], s[14] * 0.01, s[-1], s[7:14].sum()])
     npt.assert_allclose(obs.cpu().numpy(), np.stack([f(o.state) for o in oracles]), rtol=0, atol=1e-8)
     lo, hi = env.action_space.low, env.action_space.high
-    n_term = 0
     for t in range(T):
         a = rng_.uniform(lo, hi, (E_, len(lo)))
         obs, r, term, _, _ = env.step(torch.as_tensor(a, device=dev))
@@ -329,6 +328,5 @@ def callable_observation_and_two_aux(kw, E_=96, T=24):
             npt.assert_allclose(float(r[e]), rr, rtol=1e-9, atol=1e-10)
             npt.assert_allclose(env.state[e].cpu().numpy(), o.state, rtol=0, atol=1e-8)
             npt.assert_allclose(obs[e].cpu().numpy(), 0.0 if tt else f(o.state), rtol=0, atol=1e-8)
-        n_term += int(term.sum())
-    assert n_term < E_  # most environments survive the random steps
+    assert float(term.double().mean()) < 0.5  # most environments survive the random steps
     return env

@@ -529,8 +529,8 @@ def test_two_phase_step_is_bit_identical(cap_after, small_workspace):
     from gym_anm_amd.envs import ANM6EasyVec
 
     E_ = 65536
-    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=9, autoreset=True, tol=1e-6, straggler_after=sa)
-            for sa in (None, cap_after)]  # fmt: skip
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=9, autoreset=True, tol=1e-6, straggler_after=sa, handoff_after=None)
+            for sa in (None, cap_after)]  # fmt: skip  (no lane-group continuation: both stay thread-per-environment)
     assert envs[0]._ws is None and envs[1]._ws is not None
     if small_workspace:
         rec = envs[1].simulator.backend.lib.anm_step_ws_record_doubles()
