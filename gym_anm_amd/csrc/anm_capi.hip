@@ -57,18 +57,18 @@ __global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C, EnvIO io, SolverOpts 
   op_reset<Topo, JT>(C, io, so, e);
 }
 
-template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_step(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
-  const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
-  if (e >= n) return;
-  op_step<Topo, JT>(C, io, so, e);
-}
-
-// coalesced-row variant of k_step (series mode, K = 1, no full dump): see op_step_rows
+// fast path of the step (series mode, K = 1, "state" observation): see op_step_rows
 template <class JT, bool FULL>
 __global__ __launch_bounds__(BLOCK, ANM_ROWS_WAVES) void k_step_rows(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
   __shared__ double lds[64 * (Topo::SDIM + 2)];
   op_step_rows<Topo, JT, FULL>(C, io, so, n, lds);
+}
+
+// general step (host next_vars, K != 1, list-form observations, `full` dump): see op_step_general
+template <class JT>
+__global__ __launch_bounds__(BLOCK) void k_step_general(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+  extern __shared__ double lds_dyn[];
+  op_step_general<Topo, JT>(C, io, so, n, lds_dyn);
 }
 
 template <class JT>
@@ -111,6 +111,13 @@ struct anm_model {
   int period = 0;
   int K = 0;
   bool env_set = false;
+  // list-form observation (anm_model_set_obs)
+  int n_obs = 0;
+  unsigned obs_need = 0;
+  int obs_row_stride = 0, obs_aux_off = 0;   // compact row layout (only the classes the list reads)
+  short obs_cls_off[FC_COUNT] = {0};
+  int32_t* d_obs_index = nullptr;            // [2][n_obs]: compact-layout indices, identity-layout indices
+  double* d_obs_tab = nullptr;               // [3][n_obs]: scale, low, high
   std::vector<double> h_const;
   std::vector<cplx> ybus;
 };
@@ -236,6 +243,8 @@ void anm_model_destroy(anm_model* m) {
   if (m->d_series) hipFree(m->d_series);
   if (m->d_ri) hipFree(m->d_ri);
   if (m->d_rd) hipFree(m->d_rd);
+  if (m->d_obs_index) hipFree(m->d_obs_index);
+  if (m->d_obs_tab) hipFree(m->d_obs_tab);
   delete m;
 }
 
@@ -319,6 +328,69 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
 }
 
 int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
+
+static unsigned magic_div(int d) { return d > 0 ? unsigned((0x100000000ull + uint64_t(d) - 1) / uint64_t(d)) : 0u; }
+
+int anm_model_obs_fusable(const anm_model* m) {
+  return (m && m->tpe_ok && GenLds<Topo>::FULL_OK) ? 1 : 0;
+}
+
+int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const double* scale, const double* low,
+                      const double* high) {
+  if (!m) return fail("anm_model_set_obs: null model");
+  if (m->d_obs_index) { hipFree(m->d_obs_index); m->d_obs_index = nullptr; }
+  if (m->d_obs_tab) { hipFree(m->d_obs_tab); m->d_obs_tab = nullptr; }
+  m->n_obs = 0;
+  if (n_obs <= 0) return 0;   // back to the "state" observation
+  if (!anm_model_obs_fusable(m))
+    return fail("anm_model_set_obs: this model cannot gather inside the step kernel (use anm_gather_obs_f64)");
+  if (!index || !scale || !low || !high) return fail("anm_model_set_obs: null argument");
+  if (n_obs > 4096) return fail("anm_model_set_obs: more than 4096 observation entries");
+  typedef FullState<Topo> F;
+  const int FS = F::SIZE;
+  int cls_size[FC_COUNT];
+  for (unsigned c = 0; c < FC_COUNT; ++c)
+    cls_size[c] = (c + 1 < FC_COUNT ? full_class_base<Topo>(c + 1) : FS) - full_class_base<Topo>(c);
+  unsigned need = 0;
+  for (int k = 0; k < n_obs; ++k) {
+    const int i = index[k];
+    if (i < 0 || i >= FS + Layout<Topo>::KMAX) return fail("anm_model_set_obs: index out of range");
+    if (i < FS) {
+      unsigned c = 0;
+      while (c + 1 < FC_COUNT && full_class_base<Topo>(c + 1) <= i) ++c;
+      need |= 1u << c;
+    }
+  }
+  int off = 0;
+  for (unsigned c = 0; c < FC_COUNT; ++c) {
+    m->obs_cls_off[c] = short(off);
+    if ((need >> c) & 1u) off += cls_size[c];
+  }
+  m->obs_need = need;
+  m->obs_aux_off = off;
+  m->obs_row_stride = (off + Layout<Topo>::KMAX) | 1;
+  std::vector<int32_t> idx(2 * size_t(n_obs));
+  for (int k = 0; k < n_obs; ++k) {
+    const int i = index[k];
+    idx[n_obs + k] = i;  // identity layout: FullState offsets, aux behind them
+    if (i >= FS) {
+      idx[k] = m->obs_aux_off + (i - FS);
+    } else {
+      unsigned c = 0;
+      while (c + 1 < FC_COUNT && full_class_base<Topo>(c + 1) <= i) ++c;
+      idx[k] = m->obs_cls_off[c] + (i - full_class_base<Topo>(c));
+    }
+  }
+  std::vector<double> tab(3 * size_t(n_obs));
+  for (int k = 0; k < n_obs; ++k) { tab[k] = scale[k]; tab[n_obs + k] = low[k]; tab[2 * n_obs + k] = high[k]; }
+  hipError_t e = hipMalloc(&m->d_obs_index, idx.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_obs_tab, tab.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(m->d_obs_index, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->d_obs_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail_hip(e, "anm_model_set_obs");
+  m->n_obs = n_obs;
+  return 0;
+}
 
 int anm_model_set_impl(anm_model* m, int32_t impl) {
   if (!m) return fail("anm_model_set_impl: null model");
@@ -452,6 +524,26 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   io.env_offset = env_offset;
   io.reset_count = reset_count;
   io.aux_index = aux_index;
+  io.n_obs = 0;
+  io.state_magic = magic_div((m->tpe_ok ? Topo::SDIM : m->plan.d.SDIM) + m->K);
+  if (m->tpe_ok && (m->n_obs > 0 || full)) {
+    // rows of the electrical state in LDS: identity layout when the dump is asked for, else only the classes
+    // the observation list reads
+    const bool ident = full != nullptr;
+    io.n_obs = m->n_obs;
+    io.obs_magic = magic_div(m->n_obs);
+    io.obs_need = ident ? ~0u : m->obs_need;
+    io.row_stride = ident ? GenLds<Topo>::FSP : m->obs_row_stride;
+    io.aux_off = ident ? FullState<Topo>::SIZE : m->obs_aux_off;
+    for (unsigned cc = 0; cc < FC_COUNT; ++cc)
+      io.cls_off[cc] = ident ? short(full_class_base<Topo>(cc)) : m->obs_cls_off[cc];
+    if (m->n_obs > 0) {
+      io.obs_index = m->d_obs_index + (ident ? m->n_obs : 0);
+      io.obs_scale = m->d_obs_tab;
+      io.obs_lo = m->d_obs_tab + m->n_obs;
+      io.obs_hi = m->d_obs_tab + 2 * m->n_obs;
+    }
+  }
   io.ws = nullptr;
   if (ws && ws->buf && m->tpe_ok) {
     const int64_t cap = (ws->n_doubles - Rec<Topo>::HEADER) / Rec<Topo>::SIZE;
@@ -474,18 +566,12 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
     return launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
-  if (io.aux_index && io.exo == nullptr && io.K == 1) {
-    if (io.full) io.ws = nullptr;  // the straggler launch has no `full` output: one launch then
-    if (io.full) {
-      if (prec == ANM_SOLVE_F32)
-        hipLaunchKernelGGL((k_step_rows<float, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
-      else
-        hipLaunchKernelGGL((k_step_rows<double, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
-    } else if (prec == ANM_SOLVE_F32) {
+  if (io.aux_index && io.exo == nullptr && io.K == 1 && !io.full && io.n_obs == 0) {
+    // fast path: series mode, "state" observation, nothing but the batch tensors
+    if (prec == ANM_SOLVE_F32)
       hipLaunchKernelGGL((k_step_rows<float, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
-    } else {
+    else
       hipLaunchKernelGGL((k_step_rows<double, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
-    }
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_rows");
     if (io.ws && io.iter_cap < so.max_iter) {
@@ -504,12 +590,23 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
     }
     return 0;
   }
+  io.ws = nullptr;
+  if (io.full && !GenLds<Topo>::FULL_OK) {  // rows too wide for LDS: plain per-lane dump, no fused list
+    io.n_obs = 0;
+  }
+  // dynamic LDS: the widest of the buffers op_step_general overlays
+  const int S = Topo::SDIM + io.K;
+  size_t doubles = size_t(GenLds<Topo>::G_MIN);
+  doubles = std::max(doubles, size_t(64) * size_t(Dims<Topo>::ADIM + 1));
+  doubles = std::max(doubles, size_t(64) * size_t(S | 1));
+  if (GenLds<Topo>::FULL_OK && (io.n_obs > 0 || io.full)) doubles = std::max(doubles, size_t(64) * size_t(io.row_stride));
+  const size_t lds_bytes = doubles * sizeof(double);
   if (prec == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(k_step<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    hipLaunchKernelGGL(k_step_general<float>, dim3(grid_for(n)), dim3(BLOCK), lds_bytes, s, C, io, so, n);
   else
-    hipLaunchKernelGGL(k_step<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    hipLaunchKernelGGL(k_step_general<double>, dim3(grid_for(n)), dim3(BLOCK), lds_bytes, s, C, io, so, n);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail_hip(e, "launch k_step");
+  if (e != hipSuccess) return fail_hip(e, "launch k_step_general");
   return 0;
 }
 

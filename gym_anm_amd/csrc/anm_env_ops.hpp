@@ -104,6 +104,19 @@ struct EnvIO {
   uint64_t env_offset;      // global index of environment 0 of this batch (RNG key)
   int32_t* reset_count;     // [E] (autoreset)
   int32_t* aux_index;       // [E] series mode: compact copy of the time index (optional)
+  // list-form observation produced inside the step kernel (anm_model_set_obs): obs[e, k] =
+  // clip(src(e, obs_index[k]) * obs_scale[k], obs_lo[k], obs_hi[k]); n_obs == 0: obs = clip(state)
+  int n_obs;
+  unsigned obs_magic;       // ceil(2^32 / n_obs): idx / n_obs by multiply-high
+  unsigned state_magic;     // ceil(2^32 / (SDIM + K))
+  unsigned obs_need;        // FullClass bits the list reads
+  int row_stride;           // doubles per LDS row of the electrical state (odd)
+  int aux_off;              // where the aux variables sit in such a row
+  short cls_off[FC_COUNT];  // where each class sits in such a row (compact: only the classes the list reads)
+  const int32_t* obs_index; // indices into such a row
+  const double* obs_scale;
+  const double* obs_lo;
+  const double* obs_hi;
   double* ws;               // two-phase step: workspace (counters + straggler records) or null
   int64_t ws_cap;           // number of straggler records the workspace can hold
   int iter_cap;             // two-phase step: Newton iterations done by the first launch
@@ -314,7 +327,9 @@ ANM_HD void step_begin(cptr_t C, CD Cd, const EnvIO& io, SolverOpts so, int64_t 
 }
 
 // second half: solution -> flows, reward, clipping, terminal handling, state and observation rows
-template <class T, int KCAP>
+// DO_TRANSITION_END = false: the caller has already run transition_end (it reads the electrical state in
+// between, see op_step_general)
+template <class T, int KCAP, bool DO_TRANSITION_END = true>
 ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepCtx<T>& ctx, EnvWork<T>& w,
                      const PFState<T>& st, StepOut<T, KCAP>& out) {
   typedef Layout<T> L;
@@ -330,7 +345,7 @@ ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const 
     out.write_obs = true;
     return;
   }
-  transition_end<T>(C, w, st, so.tol);
+  if (DO_TRANSITION_END) transition_end<T>(C, w, st, so.tol);
   out.n_iter = w.n_iter;
   out.write_soc = true;
   out.write_state = out.write_obs = true;
@@ -622,6 +637,170 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   store_rows(io.state + e0 * S, out.state, out.write_state);
   store_rows(io.obs + e0 * S, out.obs, out.write_obs);
   ANM_PHASE(6);
+}
+
+// ---------------------------------------------------------------------------------------------
+// I/O layer 3 (GPU): the general step -- everything the fast path above leaves out:
+//   * tasks whose next_vars() runs on the host (exo / aux_next given, K = 0..KMAX auxiliary variables),
+//   * list-form observations (anm_env.py:497-521, 562-592): gathered, scaled and clipped inside this kernel
+//     from the electrical state of the step, only the quantity classes the list names being computed,
+//   * the optional `full` dump of the electrical state (Simulator.state).
+// Same wave-per-64-environments shape and the same coalesced row traffic as op_step_rows; the electrical
+// state of the 64 environments is staged in LDS (one row per lane, odd stride), read back transposed for the
+// observation gather and for the dump.  Networks whose rows do not fit (FULL_OK false) keep the rows in
+// registers: no fused list, plain per-lane dump.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct GenLds {
+  static constexpr int KM = Layout<T>::KMAX;
+  // identity layout of the rows (full dump): FullState + aux; fused paths need it to fit in LDS
+  static constexpr int FSP = (FullState<T>::SIZE + KM) | 1;
+  static constexpr bool FULL_OK = 64 * FSP * 8 <= 60 * 1024;
+  static constexpr int SP = (T::SDIM + KM) | 1;
+  static constexpr int B_MIN = 64 * (Dims<T>::ADIM + 1) > 64 * SP ? 64 * (Dims<T>::ADIM + 1) : 64 * SP;
+  static constexpr int G_MIN = T::TREE != 0 ? group::Shape<T>::NG * group::Slot<T>::SIZE : 0;
+  static constexpr int B_DOUBLES = B_MIN > G_MIN ? B_MIN : G_MIN;  // action / state / obs rows, hand-over slots
+};
+
+template <class T, class JT>
+__device__ void op_step_general(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n, double* lds) {
+  typedef Dims<T> D;
+  typedef GenLds<T> G;
+  typedef Layout<T> L;
+  constexpr int KM = G::KM;
+  const int K = io.K;
+  const int S = T::SDIM + K;
+  const int lane = threadIdx.x;
+  const int64_t e0 = int64_t(blockIdx.x) * 64;
+  const int64_t e = e0 + lane;
+  const bool valid = e < n;
+  const int64_t ec = valid ? e : n - 1;
+  const int rows = int((n - e0) < 64 ? (n - e0) : 64);
+  // One LDS buffer (dynamic, sized by the launch), used in turn for: the action transposes, the hand-over
+  // slots of the lane groups, the electrical-state rows [64][row_stride], the state / obs rows [64][SP]
+  double* ldsA = lds;
+  double* ldsB = lds;
+  const int RS = io.row_stride;
+  const bool series = io.exo == nullptr;
+  StepIn<T> in;
+  StepCtx<T> ctx;
+  PFState<T> st;
+  EnvWork<T> w;
+  // ---- coalesced loads of the action rows (as op_step_rows)
+  {
+    const double* g = io.action + e0 * D::ADIM;
+    constexpr int AP = D::ADIM + 1;
+    const int last = rows * D::ADIM - 1;
+    double tmp[D::ADIM > 0 ? D::ADIM : 1];
+    static_for<0, D::ADIM>([&](auto J) {
+      const int idx = J * 64 + lane;
+      tmp[J] = g[idx < last ? idx : last];
+    });
+    static_for<0, D::ADIM>([&](auto J) {
+      const int idx = J * 64 + lane;
+      if (idx <= last) ldsB[(idx / D::ADIM) * AP + (idx % D::ADIM)] = tmp[J];
+    });
+    ANM_WAVE_SYNC();
+    const int lr = valid ? lane : rows - 1;
+    static_for<0, D::ADIM>([&](auto I) { in.action[I] = ldsB[lr * AP + I]; });
+    ANM_WAVE_SYNC();
+  }
+  in.was_term = io.terminated[ec] != 0;
+  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
+  if (!series) static_for<0, D::NEXO>([&](auto I) { in.exo[I] = io.exo[ec * D::NEXO + I]; });
+  in.aux_prev = series ? (io.aux_index ? double(io.aux_index[ec]) : io.state[ec * S + T::SDIM]) : 0.0;
+  in.reset_count = (io.autoreset && io.reset_count) ? io.reset_count[ec] : 0;
+  const int32_t ts_prev = io.timestep ? io.timestep[ec] : 0;
+
+  step_begin<T, JT>(C, C, io, so, ec, in, ctx, w, st, -1);
+  constexpr bool CAN_GROUP = T::TREE != 0;
+  const int handoff = (CAN_GROUP && so.handoff >= 0 && so.handoff < so.max_iter) ? so.handoff : -1;
+  pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, handoff >= 0 ? handoff : so.max_iter);
+  if constexpr (CAN_GROUP) {
+    if (handoff >= 0 && ANM_WAVE_ANY(st.active && valid))
+      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, ldsB);
+  }
+  if (!ctx.absorbing) transition_end<T>(C, w, st, so.tol);
+
+  // ---- electrical state of this environment -> its LDS row (before the state / observation rows are built:
+  // the voltages, currents and flows die here)
+  const bool list = io.n_obs > 0;
+  bool dumped = false;
+  if constexpr (G::FULL_OK) {
+    if (list || io.full) {
+      const unsigned need = io.obs_need;
+      double* row = ldsA + lane * RS;
+      if (!ctx.absorbing) {
+        emit_full_state<T>(w, need, [&](unsigned c, int i, double v) { row[io.cls_off[c] + i] = v; });
+        if (ctx.resetting && ((need >> FC_DES_SOC) & 1u)) {
+          // Simulator.reset overwrites the SoC with the requested one (simulator.py:284-288)
+          const double base = C[L::SCALARS + SC_BASE];
+          static_for<0, T::NDES>([&](auto I) { row[io.cls_off[FC_DES_SOC] + I] = ctx.soc_req[I] / base; });
+        }
+      }
+      dumped = true;
+    }
+  }
+  StepOut<T, KM> out;
+  step_end<T, KM, false>(C, io, so, ec, ctx, w, st, out);
+  const bool store = valid;
+  if (store) {
+    store_step_scalars<T, KM>(io, e, out, true, ts_prev);
+    if (io.aux_index && out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
+  }
+  const bool zero_obs = ctx.absorbing || out.terminated == 1;   // anm_env.py:365-367, 442-446
+  const unsigned long long zero_rows = __ballot(zero_obs);
+  const unsigned long long state_rows = __ballot(out.write_state && store);
+  const unsigned long long obs_rows = __ballot(out.write_obs && store);
+
+  if constexpr (G::FULL_OK) {
+    if (dumped) {
+      double* row = ldsA + lane * RS;
+      static_for<0, KM>([&](auto Kc) {   // the aux variables sit behind the electrical state
+        if (Kc < K) row[io.aux_off + Kc] = out.state[T::SDIM + Kc];
+      });
+      ANM_WAVE_SYNC();
+      if (list) {  // obs[e0 + r, k] for flat index idx = r * n_obs + k: coalesced stores, LDS gathers
+        const int total = rows * io.n_obs;
+        double* gobs = io.obs + e0 * io.n_obs;
+        for (int idx = lane; idx < total; idx += 64) {
+          const int r = int(__umulhi(unsigned(idx), io.obs_magic));
+          const int k = idx - r * io.n_obs;
+          const double v = ldsA[r * RS + io.obs_index[k]] * io.obs_scale[k];
+          const double c = fmin(fmax(v, io.obs_lo[k]), io.obs_hi[k]);
+          if ((obs_rows >> r) & 1ull) gobs[idx] = ((zero_rows >> r) & 1ull) ? 0.0 : c;
+        }
+      }
+      if (io.full) {
+        constexpr int FS = FullState<T>::SIZE;
+        const int total = rows * FS;
+        double* gfull = io.full + e0 * FS;
+        for (int idx = lane; idx < total; idx += 64) {
+          const int r = idx / FS, k = idx - r * FS;
+          if ((state_rows >> r) & 1ull) gfull[idx] = ldsA[r * RS + k];   // identity layout when dumping
+        }
+      }
+    }
+  } else {
+    if (io.full && out.write_state && store) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+  }
+  // ---- state rows, then (state observation) obs rows: through LDS region B, coalesced
+  const int SPr = S | 1;
+  auto store_rows = [&](double* gbase, const double* vals, unsigned long long mask) {
+    ANM_WAVE_SYNC();
+    static_for<0, T::SDIM + KM>([&](auto Kc) {
+      if (Kc < S) ldsB[lane * SPr + Kc] = vals[Kc];
+    });
+    ANM_WAVE_SYNC();
+    const int total = rows * S;
+    for (int idx = lane; idx < total; idx += 64) {
+      const int r = int(__umulhi(unsigned(idx), io.state_magic));
+      const int k = idx - r * S;
+      if ((mask >> r) & 1ull) gbase[idx] = ldsB[r * SPr + k];
+    }
+  };
+  store_rows(io.state + e0 * S, out.state, state_rows);
+  if (!list) store_rows(io.obs + e0 * S, out.obs, obs_rows);
 }
 
 // second launch of the two-phase step: continue the handed-over solves (grid-stride over records)

@@ -31,7 +31,7 @@ import torch
 from .. import _lib
 from .. import errors as E
 from ..model import STATE_VARIABLES
-from ..simulator import BatchedSimulator, _stream_ptr
+from ..simulator import BatchedSimulator, StateView, _stream_ptr
 from ..spaces import Box, GymEnv
 
 
@@ -89,7 +89,8 @@ def check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, state_bound
 class BatchedANMEnv(GymEnv):
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
                  num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
-                 env_offset=0, impl=None, straggler_after="auto", handoff_after="auto", _backend=None):  # fmt: skip
+                 env_offset=0, impl=None, straggler_after="auto", handoff_after="auto", track_full=False,
+                 fuse_observation=True, _backend=None):  # fmt: skip
         GymEnv.reset(self, seed=seed)
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
         self.aux_bounds = aux_bounds
@@ -163,17 +164,34 @@ class BatchedANMEnv(GymEnv):
         self._cfg_keep = (slo, shi)
         with sim._device_ctx():
             sim.backend.check(sim.backend.lib.anm_model_set_env(sim._handle, C.byref(cfg)), "anm_model_set_env")
-        self._gather = None  # (index, scale, low, high) device tensors for list-form observations
+        # list-form observations (anm_env.py:497-521): gathered, scaled and clipped inside the step kernel when
+        # the library can (anm_model_set_obs), else by anm_gather_obs_f64 from the electrical-state dump
+        self._gather = None  # (index, scale, low, high) device tensors
+        self._obs_fused = False
+        self._obs_buf = None
         if self.obs_values is not None and not self._obs_is_state:
             self._gather = self._build_gather(self.obs_values)
-        self._need_full = self._gather is not None or self.obs_values is None
-        self._obs_buf = None
+            lib = sim.backend.lib
+            if fuse_observation and lib.anm_model_obs_fusable(sim._handle):
+                idx, sc, lo_, hi_ = (t.cpu().numpy() for t in self._gather)
+                a_i, p_i = _lib.as_c(idx, np.int32)
+                (a_s, p_s), (a_l, p_l), (a_h, p_h) = (_lib.as_c(x, np.float64) for x in (sc, lo_, hi_))
+                with sim._device_ctx():
+                    sim.backend.check(lib.anm_model_set_obs(sim._handle, len(a_i), p_i, p_s, p_l, p_h), "anm_model_set_obs")
+                self._obs_fused = True
+                self._obs_buf = torch.zeros((E_, len(a_i)), dtype=torch.float64, device=self.device)
+        # track_full: also dump the electrical state of every step, so that simulator.state /
+        # simulator.pfe_converged follow the environment like the reference's (simulator.py:529-537)
+        self.track_full = bool(track_full)
+        self._need_full_reset = self._gather is not None or self.track_full
+        self._need_full = (self._gather is not None and not self._obs_fused) or self.track_full
+        self._after_step = False
         self._step_args = None
         self._reset_count_ptr = self._reset_count.data_ptr()
         # compact time index next to `state` (series mode, thread-per-environment family): enables the
         # coalesced-row step kernel
         self._aux_index = None
-        if self._series is not None and K == 1 and sim.impl == "thread" and self._obs_is_state:
+        if self._series is not None and K == 1 and sim.impl == "thread":
             self._aux_index = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._aux_index_ptr = None if self._aux_index is None else self._aux_index.data_ptr()
         # two-phase step (see anm_step_ws in include/anm_mi355x.h): the first launch stops after
@@ -235,7 +253,8 @@ class BatchedANMEnv(GymEnv):
                     obs_values[idx] = tuple(list(o) + [STATE_VARIABLES[o[0]][0]])
         elif callable(observation):
             obs_values = None
-            self.observation = observation
+            self.observation = observation  # shadows the method below, like the reference (anm_env.py:511-514)
+            self.observation_fn = observation
         else:
             raise E.ObsSpaceError()
         return self._expand_all_ids(obs_values)
@@ -341,7 +360,10 @@ class BatchedANMEnv(GymEnv):
 
     @property
     def pfe_converged(self):
-        return self._conv_u8.bool()
+        """Convergence of the last power flow of every environment (simulator.pfe_converged in the
+        reference): that of the reset right after a reset; after a step an environment has converged iff
+        it is not terminated (anm_env.py:421)."""
+        return ~self._term_bool if self._after_step else self._conv_u8.bool()
 
     # ---- reset (anm_env.py:235-311) --------------------------------------------------------------------------
     def _launch_reset(self, init_state, mask_u8):
@@ -352,10 +374,14 @@ class BatchedANMEnv(GymEnv):
                 None if mask_u8 is None else mask_u8.data_ptr(), self.rng_seed, self.env_offset, self._reset_count_ptr,
                 sim.soc.data_ptr(), self.state.data_ptr(), self._state_obs.data_ptr(), self._conv_u8.data_ptr(),
                 self._term_u8.data_ptr(), self.timestep.data_ptr(), sim.nr_iters.data_ptr(),
-                sim.full.data_ptr() if self._need_full else None, self._aux_index_ptr, C.byref(sim.opts),
-                _stream_ptr(self.device),
+                sim.full.data_ptr() if (self._need_full_reset or self._need_full) else None, self._aux_index_ptr,
+                C.byref(sim.opts), _stream_ptr(self.device),
             )  # fmt: skip
         sim.backend.check(rc, "anm_reset_f64")
+        self._after_step = False
+        if self._need_full_reset or self._need_full:
+            sim.state = StateView(sim, sim.full)
+            sim.pfe_converged = self._conv_u8.bool()
 
     def reset(self, *, seed=None, options=None):
         """Reset every environment (or those selected by ``options["mask"]``).
@@ -450,8 +476,9 @@ class BatchedANMEnv(GymEnv):
         if args is None:
             args = self._step_args = (
                 sim.soc.data_ptr(), self.state.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(),
-                self._state_obs.data_ptr(), self.reward.data_ptr(), self.e_loss.data_ptr(), self.penalty.data_ptr(),
-                sim.nr_iters.data_ptr(), sim.full.data_ptr() if self._need_full else None,
+                (self._obs_buf if self._obs_fused else self._state_obs).data_ptr(), self.reward.data_ptr(),
+                self.e_loss.data_ptr(), self.penalty.data_ptr(), sim.nr_iters.data_ptr(),
+                sim.full.data_ptr() if self._need_full else None,
             )  # fmt: skip
         fn = sim.backend.lib.anm_step_f64
         if switch:
@@ -492,8 +519,17 @@ class BatchedANMEnv(GymEnv):
             aux = v[:, n_exo:].contiguous()
             exo_ptr, aux_ptr = exo.data_ptr(), (aux.data_ptr() if self.K > 0 else None)
         self._step_call(action.data_ptr(), exo_ptr, aux_ptr)
+        self._after_step = True
+        if self._need_full:
+            sim.state = StateView(sim, sim.full)
+            sim.pfe_converged = ~self._term_bool
         if self._obs_is_state:
             obs = self._state_obs
+        elif self._obs_fused:
+            obs = self._obs_buf  # written by the step kernel itself
+        elif self.obs_values is None:
+            obs = self.observation_fn(self.state)
+            obs = torch.where(self._term_bool.unsqueeze(1), torch.zeros_like(obs), obs)  # anm_env.py:365-367, 442-446
         else:
             obs = self.observation(self.state)  # the gather kernel zeroes the rows of terminated environments
         return obs, self.reward, self._term_bool, self._truncated, {}

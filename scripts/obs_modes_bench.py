@@ -1,5 +1,6 @@
-"""Step time by observation mode: "state" (fused rows kernel) vs a list-form observation (plain step
-kernel with the full electrical-state dump + gather kernel).  ANM6Easy, random agent."""
+"""Step time by observation mode: "state" (fast-path kernel), a list-form observation gathered inside the
+general step kernel ("list"), the same through the electrical-state dump + gather kernel ("list-unfused"), and
+"state" with the dump of every step (track_full).  ANM6Easy, random agent."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,13 +22,13 @@ class ListObs(ANM6EasyVec):
 dev = torch.device("cuda", 0)
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for cap in (20, 100):
-    for mode in ("state", "list"):
+    for mode in ("state", "list", "list-unfused", "state+dump"):
         kw = dict(num_envs=E, device=dev, seed=1, tol=1e-6, max_iter=cap, autoreset=True)
-        if mode == "list":
+        if mode.startswith("list"):
             obs = [("bus_v_magn", "all", "pu"), ("branch_s", "all", "MVA"), ("des_soc", "all", "MWh"), ("aux", "all", None)]
-            env = ListObs(obs, **kw)
+            env = ListObs(obs, fuse_observation=(mode == "list"), **kw)
         else:
-            env = ANM6EasyVec(**kw)
+            env = ANM6EasyVec(track_full=(mode == "state+dump"), **kw)
         env.check_actions = False
         env.reset(seed=1)
         g = torch.Generator(device=dev).manual_seed(0)
@@ -38,4 +39,4 @@ for cap in (20, 100):
         t = time.perf_counter(); n = 100
         for i in range(n): env.step(pool[i % 8])
         torch.cuda.synchronize()
-        print("E=%d cap=%3d obs=%-5s %.1f us/step" % (E, cap, mode, (time.perf_counter() - t) / n * 1e6), flush=True)
+        print("E=%d cap=%3d obs=%-12s %.1f us/step" % (E, cap, mode, (time.perf_counter() - t) / n * 1e6), flush=True)

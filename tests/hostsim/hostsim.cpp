@@ -155,6 +155,11 @@ int anm_time_step_launches(anm_model*, int64_t, const double*, double*, double*,
   return fail("hostsim: no device timing");
 }
 
+int anm_model_obs_fusable(const anm_model*) { return 0; }  // the test double has no fused gather
+int anm_model_set_obs(anm_model*, int32_t n_obs, const int32_t*, const double*, const double*, const double*) {
+  return n_obs > 0 ? fail("the host test double gathers with anm_gather_obs_f64") : 0;
+}
+
 int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t state_dim, int32_t K, const double* state,
                        const uint8_t* terminated, int32_t n_obs, const int32_t* index, const double* scale,
                        const double* low, const double* high, double* obs, void*) {

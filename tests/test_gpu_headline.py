@@ -139,3 +139,69 @@ def test_captured_two_launch_step_replays_bit_identically(n_capture):
                      (graphed._reset_count, eager._reset_count), (graphed.timestep, eager.timestep)):  # fmt: skip
             assert torch.equal(x, y), rep
     assert n_term > 100
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_all_state_variables_observation(fuse):
+    """Every STATE_VARIABLE in every unit, gathered inside the step kernel (fuse=True, no dump, one launch)
+    and by the separate gather kernel from the dump: both against the golden transitions."""
+    env = pc.all_state_variables_observation(KW, fuse_observation=fuse)
+    assert env._obs_fused == fuse and env.observation_N == 2 * (6 * 6 + 2 * 7 + 1 + 2 + 4 * 5) + 5 + 1
+
+
+def test_fused_list_observation_equals_the_gather_kernel_with_autoreset():
+    """Series-mode task with a list observation and in-kernel autoreset: the fused epilogue (general step
+    kernel) and the dump + gather kernel agree bit for bit, resets and terminal rows included, and the
+    "state" fast path steps the same environments identically."""
+    from gym_anm_amd.envs.anm6 import ANM6Vec, anm6easy_series
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    spec = [("bus_v_magn", "all", "pu"), ("branch_s", [(1, 2), (2, 4)], "MVA"), ("des_soc", "all"), ("dev_p", [0, 6], "MW"),
+            ("bus_v_ang", [3], "degree"), ("branch_i_magn", "all", "pu"), ("aux", [0])]  # fmt: skip
+    E_ = 8192
+    mk = lambda fuse: ANM6Vec(spec, 1, 0.25, 0.995, 100, aux_bounds=np.array([[0, 95]]), costs_clipping=(1, 100), num_envs=E_,
+                              device=DEV, series=anm6easy_series(), seed=3, autoreset=True, tol=1e-6, fuse_observation=fuse)
+    fused, plain = mk(True), mk(False)
+    ref = ANM6EasyVec(num_envs=E_, device=DEV, seed=3, autoreset=True, tol=1e-6)
+    assert fused._obs_fused and not plain._obs_fused and not fused._need_full and plain._need_full
+    for env in (fused, plain, ref):
+        env.check_actions = False
+        env.reset(seed=3, options={"sampler": "device"})
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    n_term = 0
+    for t in range(30):
+        a = _uniform_actions(ref, gen)
+        o1, r1, t1, _, _ = fused.step(a)
+        o2, r2, t2, _, _ = plain.step(a)
+        o3, r3, t3, _, _ = ref.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2), t
+        assert torch.equal(r1, r3) and torch.equal(t1, t3) and torch.equal(fused.state, ref.state), t
+        assert torch.equal(fused._reset_count, ref._reset_count) and torch.equal(fused.timestep, ref.timestep)
+        assert not bool(o1[t1].any())
+        n_term += int(t1.sum())
+    assert n_term > 20 and int(fused._reset_count.sum()) > 20
+
+
+def test_track_full_follows_the_steps():
+    """track_full=True: simulator.state / pfe_converged are refreshed by every step (the reference's
+    Simulator does that on every transition, simulator.py:529-537)."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 512
+    env = ANM6EasyVec(num_envs=E_, device=DEV, seed=2, track_full=True)
+    plain = ANM6EasyVec(num_envs=E_, device=DEV, seed=2)
+    for e_ in (env, plain):
+        e_.check_actions = False
+        e_.reset(seed=2)
+    assert env.simulator.state is not None
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for t in range(5):
+        a = _uniform_actions(env, gen)
+        o, r, term, _, _ = env.step(a)
+        o2, r2, term2, _, _ = plain.step(a)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(term, term2)
+        live = ~term
+        st = env.simulator.state
+        npt.assert_allclose(st.tensor("dev_p", "MW")[live].cpu().numpy(), env.state[live, :7].cpu().numpy(), rtol=0, atol=1e-9)
+        assert torch.equal(env.simulator.pfe_converged, ~term) and torch.equal(env.pfe_converged, ~term)
+        assert torch.equal(plain.pfe_converged, ~term)

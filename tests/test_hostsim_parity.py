@@ -205,3 +205,7 @@ def test_sharded_batches_equal_the_unsharded_batch():
 
 def test_callable_observation_and_two_aux_variables():
     pc.callable_observation_and_two_aux(_KW, E_=24, T=12)
+
+
+def test_all_state_variables_observation():
+    pc.all_state_variables_observation(_KW, n_cases=300)
