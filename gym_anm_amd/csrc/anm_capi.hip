@@ -140,10 +140,21 @@ int upload_const(anm_model* m) {
 int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
   const int per_wave = 64 / m->plan.d.G;
   const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
-  if (precision == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(radial::k_radial<float>, dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
-  else
-    hipLaunchKernelGGL(radial::k_radial<double>, dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+  // the model is the compiled tree: the specialised Newton loop; else (generic mode) the table-driven one
+  bool spec = false;
+  if constexpr (Topo::TREE != 0) spec = m->tpe_ok && m->plan.d.G == Topo::GRP && !getenv("ANM_RADIAL_GENERIC");
+  if (spec) {
+    if constexpr (Topo::TREE != 0) {
+      if (precision == ANM_SOLVE_F32)
+        hipLaunchKernelGGL((radial::k_radial<float, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+      else
+        hipLaunchKernelGGL((radial::k_radial<double, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+    }
+  } else if (precision == ANM_SOLVE_F32) {
+    hipLaunchKernelGGL((radial::k_radial<float, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+  } else {
+    hipLaunchKernelGGL((radial::k_radial<double, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_radial");
   return 0;

@@ -138,72 +138,61 @@ struct Shape {
   static constexpr int NG = 64 / G;       // environments per wavefront
 };
 
-// Continue the Newton-Raphson solves of the lanes with st.active (they have done st.it iterations and
-// hold their iterate in w.vm / st.cs / st.sn) until each converges, fails (NaN) or reaches max_iter --
-// NG solves at a time, one per lane group.  On return the owner lanes hold the final iterate, st.it and
-// a st.diff that reproduces the reference's flags (NaN: failed; 0: converged; +inf: cap reached).
-// `lds`: >= NG * Slot<T>::SIZE doubles, private to this wavefront; every lane of the wave must call.
-template <class T, class JT>
-__device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFState<T>& st, bool mine, double tol, int max_iter,
-                                   double* lds) {
-  typedef Layout<T> L;
-  typedef Slot<T> S;
-  constexpr int G = Shape<T>::G, NG = Shape<T>::NG, NB = T::NB;
-  const int lane = threadIdx.x & 63;
-  const int l = lane & (G - 1);        // position inside the group
-  const int gb = lane - l;             // first lane of this group
-  const int grp = lane / G;
-  constexpr int PAD = first_padding_lane<T>();
-  static_assert(PAD >= 0, "a lane group needs a padding lane (codegen.tree_tables)");
-
-  // ---- per-lane view of the tree (constant tables indexed by the lane: loaded once)
-  const int b = T::T_LANE_BUS[l];                    // bus played by this lane, 0: padding lane
-  const bool lane_bus = b > 0;
-  const int parent = T::T_PARENT[b];                 // 0: slack (b is a root of the elimination forest)
-  const int height = lane_bus ? T::T_HEIGHT[b] : -1;
-  const int depth = lane_bus ? T::T_DEPTH[b] : -1;
-  const int nch = lane_bus ? T::T_NCH[b] : 0;
+// What a lane knows about its place in the tree (constant tables indexed by the lane: loaded once).
+template <class T>
+struct LaneView {
+  int l, gb, b;            // position in the group, first lane of the group, bus played (0: padding lane)
+  bool lane_bus;
+  int height, depth, nch;
   Lanes<T> X;
-  X.psrc4 = 4 * (gb + ((lane_bus && parent > 0) ? T::T_POS[parent] : PAD));
-  static_for<0, T::T_MAXCH>([&](auto Cc) {
-    const int c = lane_bus ? T::T_CH[b * T::T_MAXCH + Cc] : -1;
-    X.csrc4[Cc] = 4 * (gb + (c > 0 ? T::T_POS[c] : PAD));
-  });
-  double ybb_r = 0, ybb_i = 0, ybp_r = 0, ybp_i = 0, ypb_r = 0, ypb_i = 0;   // padding lanes: Y = 0 -> W = 0
-  if (lane_bus) {
-    ybb_r = C[L::Y_RE + T::T_ZBB[b]]; ybb_i = C[L::Y_IM + T::T_ZBB[b]];
-    ybp_r = C[L::Y_RE + T::T_ZBP[b]]; ybp_i = C[L::Y_IM + T::T_ZBP[b]];
-    ypb_r = C[L::Y_RE + T::T_ZPB[b]]; ypb_i = C[L::Y_IM + T::T_ZPB[b]];
+  double ybb_r, ybb_i, ybp_r, ybp_i, ypb_r, ypb_i;   // Y_bb, Y_b,parent, Y_parent,b (padding lanes: 0 -> W = 0)
+  unsigned long long gmask; // lanes of my group
+
+  __device__ __forceinline__ void init() {
+    constexpr int G = T::GRP;
+    constexpr int PAD = first_padding_lane<T>();
+    static_assert(PAD >= 0, "a lane group needs a padding lane (codegen.tree_tables)");
+    const int lane = threadIdx.x & 63;
+    l = lane & (G - 1);
+    gb = lane - l;
+    b = T::T_LANE_BUS[l];
+    lane_bus = b > 0;
+    const int parent = T::T_PARENT[b];               // 0: slack (b is a root of the elimination forest)
+    height = lane_bus ? T::T_HEIGHT[b] : -1;
+    depth = lane_bus ? T::T_DEPTH[b] : -1;
+    nch = lane_bus ? T::T_NCH[b] : 0;
+    X.psrc4 = 4 * (gb + ((lane_bus && parent > 0) ? T::T_POS[parent] : PAD));
+    static_for<0, T::T_MAXCH>([&](auto Cc) {
+      const int c = lane_bus ? T::T_CH[b * T::T_MAXCH + Cc] : -1;
+      X.csrc4[Cc] = 4 * (gb + (c > 0 ? T::T_POS[c] : PAD));
+    });
+    gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gb;
+    ybb_r = ybb_i = ybp_r = ybp_i = ypb_r = ypb_i = 0.0;
   }
-  const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gb;
-
-  // ---- which lanes hand over, in lane order; NG at a time
-  const unsigned long long todo = __ballot(mine);
-  const int n_todo = __popcll(todo);
-  const int rank = __popcll(todo & ((1ull << lane) - 1ull));
-  for (int base = 0; base < n_todo; base += NG) {
-    const bool send = mine && rank >= base && rank < base + NG;
-    if (send) {
-      double* s = lds + (rank - base) * S::SIZE;
-      static_for<1, NB>([&](auto I) {
-        constexpr int i = I;
-        s[S::VM + i] = w.vm[i]; s[S::CS + i] = st.cs[i]; s[S::SN + i] = st.sn[i];
-        s[S::P + i] = w.bus_p[i]; s[S::Q + i] = w.bus_q[i];
-      });
-      s[S::IT] = double(st.it);
+  __device__ __forceinline__ void load_y(cptr_t C) {   // admittances of the compiled network
+    typedef Layout<T> L;
+    if (lane_bus) {
+      ybb_r = C[L::Y_RE + T::T_ZBB[b]]; ybb_i = C[L::Y_IM + T::T_ZBB[b]];
+      ybp_r = C[L::Y_RE + T::T_ZBP[b]]; ybp_i = C[L::Y_IM + T::T_ZBP[b]];
+      ypb_r = C[L::Y_RE + T::T_ZPB[b]]; ypb_i = C[L::Y_IM + T::T_ZPB[b]];
     }
-    ANM_WAVE_SYNC();
-    const bool gvalid = base + grp < n_todo;           // this group holds a solve
-    const bool isbus = lane_bus && gvalid;
-    double vm = 1.0, cs = 1.0, sn = 0.0, bus_p = 0.0, bus_q = 0.0;
-    int it = 0;
-    {
-      const double* s = lds + grp * S::SIZE;
-      if (isbus) { vm = s[S::VM + b]; cs = s[S::CS + b]; sn = s[S::SN + b]; bus_p = s[S::P + b]; bus_q = s[S::Q + b]; }
-      if (gvalid) it = int(s[S::IT]);
-    }
-    ANM_WAVE_SYNC();
+  }
+};
 
+// The Newton-Raphson loop of every lane group of the wavefront, from the iterate (vm, cs, sn) each bus lane
+// holds, `it` iterations already done.  gvalid (uniform per group): the group holds a solve.  Every lane of
+// the wavefront must call.  On return: the final iterate, `it`, and the group's verdict in tb / tn
+// (tb != 0: ||F||inf > tol or NaN; tn != 0: F has a NaN).
+template <class T, class JT>
+__device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
+                                              double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
+                                              double tol, int max_iter) {
+  const Lanes<T>& X = V.X;
+  const int height = V.height, depth = V.depth, nch = V.nch;
+  const double ybb_r = V.ybb_r, ybb_i = V.ybb_i, ybp_r = V.ybp_r, ybp_i = V.ybp_i, ypb_r = V.ypb_r, ypb_i = V.ypb_i;
+  const unsigned long long gmask = V.gmask;
+  const bool isbus = V.lane_bus && gvalid;
+  {
     // ---- the reference's loop, rotated like pf_iterate (anm_device.hpp): evaluate; account for the update of
     // the previous trip; leave when no group runs; update.  `running` is uniform over a group; a group that
     // stopped (or holds no solve) rides along: its lanes keep executing, nothing of it changes any more.
@@ -212,7 +201,7 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
     const unsigned long long busm = __builtin_amdgcn_uicmp(isbus ? 1u : 0u, 0u, ICMP_NE);
     unsigned long long runm = __builtin_amdgcn_uicmp(gvalid ? 1u : 0u, 0u, ICMP_NE);
     const unsigned glo = unsigned(gmask & busm), ghi = unsigned((gmask & busm) >> 32);   // bus lanes of my group
-    unsigned tb = 0u, tn = 0u;   // != 0: ||F||inf > tol (or NaN) / F has a NaN, somewhere in my group
+    tb = 0u; tn = 0u;
     it -= gvalid ? 1 : 0;        // the first trip only evaluates: its `it += running` is undone here
     // What a lane publishes for its parent (Schur complement, reduced right-hand side) and its Newton step:
     // a bus lane rewrites them at its own level of every trip before anybody reads them; a padding lane never
@@ -333,6 +322,55 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
         sn = fma(s0, cd_, -(c0 * sd_));
       }
     }
+
+  }
+}
+
+// Continue the Newton-Raphson solves of the lanes with st.active (they have done st.it iterations and
+// hold their iterate in w.vm / st.cs / st.sn) until each converges, fails (NaN) or reaches max_iter --
+// NG solves at a time, one per lane group.  On return the owner lanes hold the final iterate, st.it and
+// a st.diff that reproduces the reference's flags (NaN: failed; 0: converged; +inf: cap reached).
+// `lds`: >= NG * Slot<T>::SIZE doubles, private to this wavefront; every lane of the wave must call.
+template <class T, class JT>
+__device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFState<T>& st, bool mine, double tol, int max_iter,
+                                   double* lds) {
+  typedef Slot<T> S;
+  constexpr int G = Shape<T>::G, NG = Shape<T>::NG, NB = T::NB;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / G;
+  LaneView<T> V;
+  V.init();
+  V.load_y(C);
+  const int b = V.b;
+
+  // ---- which lanes hand over, in lane order; NG at a time
+  const unsigned long long todo = __ballot(mine);
+  const int n_todo = __popcll(todo);
+  const int rank = __popcll(todo & ((1ull << lane) - 1ull));
+  for (int base = 0; base < n_todo; base += NG) {
+    const bool send = mine && rank >= base && rank < base + NG;
+    if (send) {
+      double* s = lds + (rank - base) * S::SIZE;
+      static_for<1, NB>([&](auto I) {
+        constexpr int i = I;
+        s[S::VM + i] = w.vm[i]; s[S::CS + i] = st.cs[i]; s[S::SN + i] = st.sn[i];
+        s[S::P + i] = w.bus_p[i]; s[S::Q + i] = w.bus_q[i];
+      });
+      s[S::IT] = double(st.it);
+    }
+    ANM_WAVE_SYNC();
+    const bool gvalid = base + grp < n_todo;           // this group holds a solve
+    const bool isbus = V.lane_bus && gvalid;
+    double vm = 1.0, cs = 1.0, sn = 0.0, bus_p = 0.0, bus_q = 0.0;
+    int it = 0;
+    {
+      const double* s = lds + grp * S::SIZE;
+      if (isbus) { vm = s[S::VM + b]; cs = s[S::CS + b]; sn = s[S::SN + b]; bus_p = s[S::P + b]; bus_q = s[S::Q + b]; }
+      if (gvalid) it = int(s[S::IT]);
+    }
+    ANM_WAVE_SYNC();
+    unsigned tb, tn;
+    newton_groups<T, JT>(V, gvalid, vm, cs, sn, bus_p, bus_q, it, tb, tn, tol, max_iter);
 
     // ---- results back to the owner lanes
     if (isbus) {

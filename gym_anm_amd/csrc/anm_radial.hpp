@@ -243,9 +243,13 @@ enum { A_VR = 0, A_VI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N }; 
 #ifndef ANM_RADIAL_WAVES
 #define ANM_RADIAL_WAVES 1
 #endif
-template <class JT>
+// TT: the compiled topology (Topo) when the model IS that network and it is a tree -- the Newton loop is then
+// the compile-time specialised lane-group loop of anm_group.hpp (unrolled levels, register hand-overs) instead
+// of the table-driven one below; void: any radial network (generic mode).
+template <class JT, class TT>
 __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const int* __restrict__ ri, const double* __restrict__ rd, IO io,
                                               SolverOpts so, int64_t n_env) {
+  constexpr bool USE_T = !std::is_void<TT>::value;
   __shared__ double sh[A_N][64];
   __shared__ int sh_lists[256];  // children / bus-device index lists (read every Newton iteration)
   const int t = threadIdx.x;
@@ -402,6 +406,31 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   // comes from W_ik = V_i conj(Y_ik V_k).  A lane owns W_bb, W_bp (its row, parent column) and W_pb
   // (parent row, its column); S_b = W_bb + W_bp + sum over children c of W_pb(c), gathered through LDS.
   double wpb_r = 0.0, wpb_i = 0.0;
+  bool f_nan = false, f_bad = false;   // verdict on the final iterate: F has a NaN / ||F||inf > tol (or NaN)
+  if constexpr (USE_T) {
+    // lane l plays bus l + 1 here; the specialised loop may place the buses differently inside the group
+    // (TT::T_LANE_BUS): move the inputs there, the final iterate back
+    group::LaneView<TT> V;
+    V.init();
+    const int to4 = 4 * (gb + (V.lane_bus ? V.b - 1 : l));
+    V.ybb_r = group::bperm(ybb_r, to4); V.ybb_i = group::bperm(ybb_i, to4);
+    V.ybp_r = group::bperm(ybp_r, to4); V.ybp_i = group::bperm(ybp_i, to4);
+    V.ypb_r = group::bperm(ypb_r, to4); V.ypb_i = group::bperm(ypb_i, to4);
+    double gp = group::bperm(bus_p, to4), gq = group::bperm(bus_q, to4);
+    if (!V.lane_bus) { V.ybb_r = V.ybb_i = V.ybp_r = V.ybp_i = V.ypb_r = V.ypb_i = 0.0; gp = gq = 0.0; }
+    double gvm = 1.0, gcs = 1.0, gsn = 0.0;   // flat start (solve_load_flow.py:36-39)
+    int git = 0;
+    unsigned tb, tn;
+    group::newton_groups<TT, JT>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn, so.tol, so.max_iter);
+    const int back4 = 4 * (gb + (isbus ? TT::T_POS[l + 1] : l));
+    vm = group::bperm(gvm, back4); cs = group::bperm(gcs, back4); sn = group::bperm(gsn, back4);
+    // iteration count and verdict are uniform over a group: every lane takes those of the lane playing bus 1
+    // (all lanes execute the hand-over: an inactive source lane would read as 0)
+    const int one4 = 4 * (gb + TT::T_POS[1]);
+    it = __builtin_amdgcn_ds_bpermute(one4, git);
+    f_nan = __builtin_amdgcn_ds_bpermute(one4, int(tn)) != 0;
+    f_bad = __builtin_amdgcn_ds_bpermute(one4, int(tb)) != 0;
+  } else {
   for (;;) {
     // ---- V; the parent's V comes through LDS
     vr = vm * cs;
@@ -501,6 +530,17 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     }
     it = active ? it + 1 : it;
   }
+  f_nan = (diff != diff);
+  f_bad = !(diff <= so.tol);
+  }
+  // V of the final iterate; the parent's through LDS
+  vr = vm * cs;
+  vi = vm * sn;
+  sh[A_VR][t] = vr; sh[A_VI][t] = vi;
+  ANM_GROUP_SYNC();
+  vpr = 1.0; vpi = 0.0;
+  if (parent >= 0) { vpr = sh[A_VR][pl]; vpi = sh[A_VI][pl]; }
+  ANM_GROUP_SYNC();
   // bus currents I = Y V of the final iterate (solve_load_flow.py:52-60), once
   {
     sh[A_UPR][t] = fma(ypb_r, vr, -(ypb_i * vi));
@@ -515,8 +555,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     }
     ANM_GROUP_SYNC();
   }
-  const bool conv_nan = (diff != diff);
-  const bool converged = !conv_nan && (diff <= so.tol);
+  const bool converged = !f_nan && !f_bad;
 
   // ---------------- slack injection, branch flows, reward --------------------------------------
   // I_0 = Y_00 + sum over the buses attached to the slack of Y_0b V_b  (fixed butterfly order)
