@@ -44,30 +44,34 @@ int fail_hip(hipError_t e, const char* where) {
 #endif
 
 template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C, TransitionIO io, SolverOpts so, int64_t n) {
+__global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C0, TransitionIO io, SolverOpts so, int64_t n, ClassSel cs) {
   const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
   if (e >= n) return;
+  const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   op_transition<Topo, JT>(C, io, so, e);
 }
 
 template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+__global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs) {
   const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
   if (e >= n) return;
+  const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   op_reset<Topo, JT>(C, io, so, e);
 }
 
 // fast path of the step (series mode, K = 1, "state" observation): see op_step_rows
 template <class JT, bool FULL>
-__global__ __launch_bounds__(BLOCK, ANM_ROWS_WAVES) void k_step_rows(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+__global__ __launch_bounds__(BLOCK, ANM_ROWS_WAVES) void k_step_rows(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs) {
   __shared__ double lds[64 * (Topo::SDIM + 2)];
+  const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   op_step_rows<Topo, JT, FULL>(C, io, so, n, lds);
 }
 
 // general step (host next_vars, K != 1, list-form observations, `full` dump): see op_step_general
 template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_step_general(cptr_t C, EnvIO io, SolverOpts so, int64_t n) {
+__global__ __launch_bounds__(BLOCK) void k_step_general(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs) {
   extern __shared__ double lds_dyn[];
+  const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   op_step_general<Topo, JT>(C, io, so, n, lds_dyn);
 }
 
@@ -119,6 +123,10 @@ struct anm_model {
   int32_t* d_obs_index = nullptr;            // [2][n_obs]: compact-layout indices, identity-layout indices
   double* d_obs_tab = nullptr;               // [3][n_obs]: scale, low, high
   std::vector<double> h_const;
+  // parameter classes 1.. (class 0 is the network the model was created from): same topology, other numbers
+  std::vector<std::vector<double>> x_const;   // thread-per-environment constants of each extra class
+  std::vector<std::vector<double>> x_hd;      // lane-group tables of each extra class
+  const int32_t* d_env_class = nullptr;       // caller's device array [num_envs] (anm_model_bind_env_classes)
   std::vector<cplx> ybus;
 };
 
@@ -127,14 +135,26 @@ namespace {
 int upload_const(anm_model* m) {
   hipError_t e = hipSuccess;
   if (m->tpe_ok) {
-    e = hipMemcpy(m->d_const, m->h_const.data(), m->h_const.size() * sizeof(double), hipMemcpyHostToDevice);
+    const size_t n = m->h_const.size();
+    e = hipMemcpy(m->d_const, m->h_const.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    for (size_t k = 0; k < m->x_const.size() && e == hipSuccess; ++k)
+      e = hipMemcpy(m->d_const + (k + 1) * n, m->x_const[k].data(), n * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail_hip(e, "hipMemcpy(constants)");
   }
   if (m->radial_ok) {
-    e = hipMemcpy(m->d_rd, m->plan.hd.data(), m->plan.hd.size() * sizeof(double), hipMemcpyHostToDevice);
+    const size_t n = m->plan.hd.size();
+    e = hipMemcpy(m->d_rd, m->plan.hd.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    for (size_t k = 0; k < m->x_hd.size() && e == hipSuccess; ++k)
+      e = hipMemcpy(m->d_rd + (k + 1) * n, m->x_hd[k].data(), n * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail_hip(e, "hipMemcpy(radial tables)");
   }
   return 0;
+}
+
+ClassSel class_sel(const anm_model* m, bool radial) {
+  ClassSel cs{m->d_env_class, 0};
+  if (cs.env_class) cs.stride = radial ? int(m->plan.hd.size()) : int(m->h_const.size());
+  return cs;
 }
 
 int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
@@ -146,14 +166,14 @@ int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const r
   if (spec) {
     if constexpr (Topo::TREE != 0) {
       if (precision == ANM_SOLVE_F32)
-        hipLaunchKernelGGL((radial::k_radial<float, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+        hipLaunchKernelGGL((radial::k_radial<float, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
       else
-        hipLaunchKernelGGL((radial::k_radial<double, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+        hipLaunchKernelGGL((radial::k_radial<double, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
     }
   } else if (precision == ANM_SOLVE_F32) {
-    hipLaunchKernelGGL((radial::k_radial<float, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+    hipLaunchKernelGGL((radial::k_radial<float, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
   } else {
-    hipLaunchKernelGGL((radial::k_radial<double, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n);
+    hipLaunchKernelGGL((radial::k_radial<double, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_radial");
@@ -307,6 +327,8 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
     g_err = err;
     return -3;
   }
+  if (m->tpe_ok)
+    for (auto& xc : m->x_const) pack_env<Topo>(*cfg, xc, err);
   m->K = cfg->K;
   if (m->radial_ok) {
     radial::Plan& P = m->plan;
@@ -317,6 +339,13 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
     for (int k = 0; k < P.d.SDIM + cfg->K; ++k) {
       if (cfg->obs_low) P.hd[P.d.off_obs_lo + k] = cfg->obs_low[k];
       if (cfg->obs_high) P.hd[P.d.off_obs_hi + k] = cfg->obs_high[k];
+    }
+    for (auto& xh : m->x_hd) {
+      for (int f : {int(radial::SF_C1), int(radial::SF_C2), int(radial::SF_RTERM), int(radial::SF_PERIOD)}) xh[f] = P.hd[f];
+      for (int k = 0; k < P.d.SDIM + cfg->K; ++k) {
+        xh[P.d.off_obs_lo + k] = P.hd[P.d.off_obs_lo + k];
+        xh[P.d.off_obs_hi + k] = P.hd[P.d.off_obs_hi + k];
+      }
     }
   }
   if (m->d_series) {
@@ -336,6 +365,73 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   }
   m->env_set = true;
   return upload_const(m);
+}
+
+int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_desc* const* descs) {
+  if (!m) return fail("anm_model_set_classes: null model");
+  if (n_classes < 1 || n_classes > 65536) return fail("anm_model_set_classes: n_classes must be in [1, 65536]");
+  if (n_classes > 1 && !descs) return fail("anm_model_set_classes: null descriptions");
+  std::vector<std::vector<double>> xc, xh;
+  for (int k = 1; k < n_classes; ++k) {
+    if (!descs[k]) return fail("anm_model_set_classes: null description");
+    std::string err;
+    if (m->tpe_ok) {
+      std::vector<double> cbuf;
+      std::vector<cplx> y;
+      if (!pack_constants<Topo>(*descs[k], cbuf, y, err)) {
+        g_err = "class " + std::to_string(k) + ": " + err;
+        return -3;
+      }
+      xc.push_back(std::move(cbuf));
+    }
+    if (m->radial_ok) {
+      radial::Plan P;
+      if (!radial::build_plan(*descs[k], P, err) || P.hi != m->plan.hi || P.hd.size() != m->plan.hd.size()) {
+        g_err = "class " + std::to_string(k) + ": not the topology of the model" + (err.empty() ? "" : " (" + err + ")");
+        return -3;
+      }
+      xh.push_back(std::move(P.hd));
+    }
+  }
+  // (re)allocate the device buffers for n_classes consecutive copies
+  if (m->tpe_ok) {
+    double* p = nullptr;
+    hipError_t e = hipMalloc(&p, size_t(n_classes) * m->h_const.size() * sizeof(double));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(class constants)");
+    hipFree(m->d_const);
+    m->d_const = p;
+  }
+  if (m->radial_ok) {
+    double* p = nullptr;
+    hipError_t e = hipMalloc(&p, size_t(n_classes) * m->plan.hd.size() * sizeof(double));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(class tables)");
+    hipFree(m->d_rd);
+    m->d_rd = p;
+  }
+  m->x_const = std::move(xc);
+  m->x_hd = std::move(xh);
+  m->d_env_class = nullptr;
+  m->env_set = false;   // the task constants (anm_model_set_env) must be set again: they live in every class
+  return upload_const(m);
+}
+
+int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t num_envs) {
+  if (!m) return fail("anm_model_bind_env_classes: null model");
+  if (!env_class) {
+    m->d_env_class = nullptr;
+    return 0;
+  }
+  if (num_envs <= 0) return fail("anm_model_bind_env_classes: num_envs must be positive");
+  const int n_classes = 1 + int(m->tpe_ok ? m->x_const.size() : m->x_hd.size());
+  std::vector<int32_t> h(static_cast<size_t>(num_envs));
+  hipError_t e = hipMemcpy(h.data(), env_class, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail_hip(e, "anm_model_bind_env_classes");
+  for (int64_t i = 0; i < num_envs; ++i) {
+    if (h[i] < 0 || h[i] >= n_classes) return fail("anm_model_bind_env_classes: class index out of range");
+    if (h[i] != h[i - i % 64]) return fail("anm_model_bind_env_classes: a class must cover whole aligned blocks of 64 environments");
+  }
+  m->d_env_class = env_class;
+  return 0;
 }
 
 int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
@@ -444,9 +540,9 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   }
   cptr_t C = (cptr_t)m->d_const;
   if (prec == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(k_transition<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    hipLaunchKernelGGL(k_transition<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
   else
-    hipLaunchKernelGGL(k_transition<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    hipLaunchKernelGGL(k_transition<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_transition");
   return 0;
@@ -491,9 +587,9 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
   }
   cptr_t C = (cptr_t)m->d_const;
   if (prec == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(k_reset<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    hipLaunchKernelGGL(k_reset<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
   else
-    hipLaunchKernelGGL(k_reset<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+    hipLaunchKernelGGL(k_reset<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_reset");
   return 0;
@@ -556,7 +652,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
     }
   }
   io.ws = nullptr;
-  if (ws && ws->buf && m->tpe_ok) {
+  if (ws && ws->buf && m->tpe_ok && !m->d_env_class) {  // (the straggler launch packs records of all blocks together)
     const int64_t cap = (ws->n_doubles - Rec<Topo>::HEADER) / Rec<Topo>::SIZE;
     if (cap < 1 || ws->iter_cap < 1) return fail("anm_step_f64: step workspace too small or iter_cap < 1");
     io.ws = ws->buf;
@@ -580,9 +676,9 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
   if (io.aux_index && io.exo == nullptr && io.K == 1 && !io.full && io.n_obs == 0) {
     // fast path: series mode, "state" observation, nothing but the batch tensors
     if (prec == ANM_SOLVE_F32)
-      hipLaunchKernelGGL((k_step_rows<float, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+      hipLaunchKernelGGL((k_step_rows<float, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
     else
-      hipLaunchKernelGGL((k_step_rows<double, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n);
+      hipLaunchKernelGGL((k_step_rows<double, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_rows");
     if (io.ws && io.iter_cap < so.max_iter) {
@@ -613,9 +709,9 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
   if (GenLds<Topo>::FULL_OK && (io.n_obs > 0 || io.full)) doubles = std::max(doubles, size_t(64) * size_t(io.row_stride));
   const size_t lds_bytes = doubles * sizeof(double);
   if (prec == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(k_step_general<float>, dim3(grid_for(n)), dim3(BLOCK), lds_bytes, s, C, io, so, n);
+    hipLaunchKernelGGL(k_step_general<float>, dim3(grid_for(n)), dim3(BLOCK), lds_bytes, s, C, io, so, n, class_sel(m, false));
   else
-    hipLaunchKernelGGL(k_step_general<double>, dim3(grid_for(n)), dim3(BLOCK), lds_bytes, s, C, io, so, n);
+    hipLaunchKernelGGL(k_step_general<double>, dim3(grid_for(n)), dim3(BLOCK), lds_bytes, s, C, io, so, n, class_sel(m, false));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_step_general");
   return 0;

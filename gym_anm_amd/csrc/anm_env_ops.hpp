@@ -11,6 +11,22 @@
 
 namespace anm {
 
+// Parameter classes (anm_model_set_classes): networks with the topology of the model and other numbers.  The
+// constants of class k start k * stride doubles behind those of class 0; env_class[e] (device, int32) names
+// the class of environment e and is constant over every aligned block of 64 environments, so the constants
+// of a wavefront stay ONE wave-uniform buffer read through scalar loads -- parameter classes cost nothing.
+struct ClassSel {
+  const int32_t* env_class;  // null: one class
+  int stride;
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ cptr_t class_constants(cptr_t C, const ClassSel& cs, int64_t first_env) {
+  if (!cs.env_class) return C;
+  const int k = __builtin_amdgcn_readfirstlane(cs.env_class[first_env]);
+  return C + int64_t(k) * cs.stride;
+}
+#endif
+
 struct SolverOpts {
   double tol;
   int max_iter;

@@ -247,9 +247,15 @@ enum { A_VR = 0, A_VI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N }; 
 // the compile-time specialised lane-group loop of anm_group.hpp (unrolled levels, register hand-overs) instead
 // of the table-driven one below; void: any radial network (generic mode).
 template <class JT, class TT>
-__global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const int* __restrict__ ri, const double* __restrict__ rd, IO io,
-                                              SolverOpts so, int64_t n_env) {
+__global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0, IO io,
+                                              SolverOpts so, int64_t n_env, ClassSel cls) {
   constexpr bool USE_T = !std::is_void<TT>::value;
+  // parameter class of this wavefront's environments (uniform over aligned blocks of 64 environments)
+  const double* __restrict__ rd = rd0;
+  if (cls.env_class) {
+    const int64_t first = int64_t(blockIdx.x) * (64 / d.G);
+    rd = rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[first < n_env ? first : 0])) * cls.stride;
+  }
   __shared__ double sh[A_N][64];
   __shared__ int sh_lists[256];  // children / bus-device index lists (read every Newton iteration)
   const int t = threadIdx.x;

@@ -90,7 +90,7 @@ class BatchedANMEnv(GymEnv):
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
                  num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
                  env_offset=0, impl=None, straggler_after="auto", handoff_after="auto", track_full=False,
-                 fuse_observation=True, _backend=None):  # fmt: skip
+                 fuse_observation=True, variants=None, env_variant=None, _backend=None):  # fmt: skip
         GymEnv.reset(self, seed=seed)
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
         self.aux_bounds = aux_bounds
@@ -106,7 +106,8 @@ class BatchedANMEnv(GymEnv):
 
         self.simulator = BatchedSimulator(network, delta_t, lamb, num_envs=num_envs, device=device, tol=tol,
                                           max_iter=max_iter, precision=precision, impl=impl,
-                                          handoff_after=handoff_after, _backend=_backend)  # fmt: skip
+                                          handoff_after=handoff_after, variants=variants, env_variant=env_variant,
+                                          _backend=_backend)  # fmt: skip
         sim = self.simulator
         self.device = sim.device
         check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, sim.state_bounds)

@@ -136,3 +136,32 @@ def synthetic_radial_network(n_bus: int = 30, seed: int = 0) -> dict:
         "device": np.array(device, dtype=object),
         "branch": np.array(branch, dtype=float),
     }
+
+
+def perturbed_network(net: dict, seed: int, rel=0.2) -> dict:
+    """A variant of ``net`` with the same topology and other numbers: branch r, x, rating, tap and (small)
+    line charging, the voltage limits of the PQ buses and every finite device limit are scaled by factors
+    drawn uniformly in [1 - rel, 1 + rel] (limits keep their sign and their ordering).  Used for
+    per-environment heterogeneous networks (``BatchedSimulator(variants=...)``)."""
+    rng = np.random.default_rng(seed)
+    f = lambda n=None: rng.uniform(1 - rel, 1 + rel, size=n)  # noqa: E731
+    out = {"baseMVA": net["baseMVA"], "bus": np.array(net["bus"], dtype=float).copy(),
+           "device": np.array(net["device"], dtype=object).copy(), "branch": np.array(net["branch"], dtype=float).copy()}
+    br = out["branch"]
+    br[:, 2] *= f(len(br))
+    br[:, 3] *= f(len(br))
+    br[:, 4] = rng.uniform(0, 0.01, len(br))
+    br[:, 5] *= f(len(br))
+    br[:, 6] = np.where(rng.uniform(size=len(br)) < 0.3, rng.uniform(0.97, 1.03, len(br)), br[:, 6])
+    bus = out["bus"]
+    pq = bus[:, 1] != 0
+    bus[pq, 3] = 1.0 + 0.1 * f(int(pq.sum()))
+    bus[pq, 4] = 1.0 - 0.1 * f(int(pq.sum()))
+    for row in out["device"]:
+        s = f()
+        for col in (4, 5, 6, 7, 8, 9, 10, 11, 12):  # PMAX PMIN QMAX QMIN P+ P- Q+ Q- SOC_MAX: one factor per device
+            if row[col] is not None:
+                row[col] = float(row[col]) * s
+        if row[14] is not None:
+            row[14] = float(min(1.0, float(row[14]) * rng.uniform(0.9, 1.05)))
+    return out

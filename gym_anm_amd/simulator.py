@@ -73,7 +73,8 @@ class StateView:
 
 class BatchedSimulator:
     def __init__(self, network, delta_t, lamb, num_envs=1, device="cuda", tol=1e-5, max_iter=100,
-                 precision="f64", impl=None, handoff_after="auto", _backend=None):  # fmt: skip
+                 precision="f64", impl=None, handoff_after="auto", variants=None, env_variant=None,
+                 _backend=None):  # fmt: skip
         self.model = NetworkModel(network, delta_t, lamb)
         m = self.model
         self.baseMVA, self.delta_t, self.lamb = m.baseMVA, delta_t, lamb
@@ -114,6 +115,27 @@ class BatchedSimulator:
             code = {"thread": _lib.IMPL_THREAD, "radial": _lib.IMPL_RADIAL}[impl]
             self.backend.check(self.backend.lib.anm_model_set_impl(self._handle, code), "anm_model_set_impl")
         self.impl = {0: "thread", 1: "radial"}[self.backend.lib.anm_model_get_impl(self._handle)]
+        # per-environment heterogeneous networks (the reference builds one Simulator per network): `variants`
+        # are networks with the topology of `network` and other numbers, env_variant[e] in [0, len(variants)]
+        # picks the network of environment e (0 = `network`), constant over aligned blocks of 64 environments
+        self.variant_models = [self.model]
+        self.env_variant = None
+        if variants:
+            self.variant_models += [NetworkModel(v, delta_t, lamb) for v in variants]
+            for vm in self.variant_models[1:]:
+                if vm.topology() != m.topology():
+                    raise E.UnsupportedNetworkError("every variant must have the topology of the base network")
+            descs, self._keep_variants = zip(*[_lib.network_desc(vm) for vm in self.variant_models])
+            arr = (C.POINTER(_lib.NetworkDesc) * len(descs))(*[C.pointer(d) for d in descs])
+            with self._device_ctx():
+                self.backend.check(self.backend.lib.anm_model_set_classes(self._handle, len(descs), arr), "anm_model_set_classes")
+            ev = torch.zeros(self.num_envs, dtype=torch.int32) if env_variant is None else torch.as_tensor(env_variant)
+            self.env_variant = ev.to(dtype=torch.int32, device=self.device).contiguous()
+            if self.env_variant.shape != (self.num_envs,):
+                raise ValueError("env_variant must have shape (%d,)" % self.num_envs)
+            with self._device_ctx():
+                self.backend.check(self.backend.lib.anm_model_bind_env_classes(
+                    self._handle, self.env_variant.data_ptr(), self.num_envs), "anm_model_bind_env_classes")
         dims = _lib.Dims()
         self.backend.check(self.backend.lib.anm_model_dims(self._handle, C.byref(dims)), "anm_model_dims")
         self.dims = dims

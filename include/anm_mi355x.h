@@ -120,6 +120,18 @@ int anm_model_get_impl(const anm_model* m);
  * y[n_bus*n_bus*2] row-major (re, im). */
 int anm_model_get_ybus(const anm_model* m, double* y_host);
 
+/* Per-environment heterogeneous networks: PARAMETER CLASSES.  A model may hold several networks that share
+ * the topology of the one it was created from (class 0) and differ in their numbers -- admittances, taps,
+ * ratings, voltage limits, device limits, tau/rho, storage parameters.  descs[k] describes class k
+ * (descs[0] is ignored); anm_model_set_env must be called (again) afterwards.  anm_model_bind_env_classes
+ * names the class of every environment of the batch the model steps: env_class is a DEVICE int32 array of
+ * num_envs entries that stays alive and unchanged while bound, constant over every aligned block of 64
+ * environments (checked here) -- the constants of a wavefront then remain one wave-uniform buffer read by
+ * scalar loads, so classes cost nothing in the kernels.  NULL unbinds (all environments: class 0).  The
+ * two-launch step (anm_step_ws) is not used while classes are bound. */
+int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_desc* const* descs);
+int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t num_envs);
+
 /* precision of the Jacobian + block-LU inside Newton-Raphson; mismatch F, the stop test and the
  * state update are always fp64. */
 #define ANM_SOLVE_F64 0

@@ -155,6 +155,12 @@ int anm_time_step_launches(anm_model*, int64_t, const double*, double*, double*,
   return fail("hostsim: no device timing");
 }
 
+int anm_model_set_classes(anm_model*, int32_t n_classes, const anm_network_desc* const*) {
+  return n_classes > 1 ? fail("the host test double has no parameter classes") : 0;
+}
+int anm_model_bind_env_classes(anm_model*, const int32_t* env_class, int64_t) {
+  return env_class ? fail("the host test double has no parameter classes") : 0;
+}
 int anm_model_obs_fusable(const anm_model*) { return 0; }  // the test double has no fused gather
 int anm_model_set_obs(anm_model*, int32_t n_obs, const int32_t*, const double*, const double*, const double*) {
   return n_obs > 0 ? fail("the host test double gathers with anm_gather_obs_f64") : 0;

@@ -405,3 +405,80 @@ def all_state_variables_observation(kw, n_cases=None, **env_kw):
     npt.assert_allclose(r.cpu().numpy()[ok], np.maximum(-(np.sign(g["e_loss"][:M]) * np.minimum(np.abs(g["e_loss"][:M]), np.inf)
                                                            + g["penalty"][:M]), -np.inf)[ok], rtol=1e-9, atol=1e-9)
     return env
+
+
+def heterogeneous_networks(kw, n_variants=64, per_variant=64, n_check=2, impl=None):
+    """Per-environment heterogeneous networks (the reference builds a Simulator per network,
+    examples/custom_anm6.py:20): n_variants perturbed copies of ANM6 (same topology, other admittances,
+    ratings, limits), `per_variant` environments each; transitions against the oracle built from each
+    environment's own network, <= 1e-9; then a few ANM6Easy steps through the environment layer."""
+    import anm_oracle as O
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    base = networks.anm6_network()
+    variants = [networks.perturbed_network(base, 100 + k) for k in range(1, n_variants)]
+    E_ = n_variants * per_variant
+    env_variant = np.repeat(np.arange(n_variants), per_variant)
+    extra = {} if impl is None else {"impl": impl}
+    sim = BatchedSimulator(base, 0.25, 100, num_envs=E_, variants=variants, env_variant=env_variant, **kw(base), **extra)
+    nets = [base] + variants
+    m, b = sim.model, sim.model.baseMVA
+    rng = np.random.default_rng(5)
+    U = lambda lo, hi, w=1.0: rng.uniform(np.asarray(lo, float) * w, np.asarray(hi, float) * w, size=(E_, len(lo)))
+    pl = U(m.dev_p_min[m.load_idx] * b, 0 * m.dev_p_min[m.load_idx])
+    pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * b)
+    ps = U(m.dev_p_min[m.setp_idx] * b, m.dev_p_max[m.setp_idx] * b, 1.2)
+    qs = U(m.dev_q_min[m.setp_idx] * b, m.dev_q_max[m.setp_idx] * b, 1.2)
+    soc = U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx], 0.8)
+    sim.soc.copy_(torch.as_tensor(soc))
+    st, r, el, pen, conv = sim.transition(pl, pp, ps, qs)
+    full, sl = sim.full.cpu().numpy(), full_slices(sim)
+    n_conv = 0
+    for k in range(n_variants):
+        n = O.parse_network(nets[k], 0.25, 100)
+        for j in range(n_check):
+            e = k * per_variant + (j * 37) % per_variant
+            out = O.transition(n, pl[e], pp[e], ps[e], qs[e], soc[e], sparse=False)
+            assert out["converged"] == bool(conv[e]), (k, e)
+            npt.assert_allclose(full[e, sl["dev_p"]][1:], out["dev_p"][1:], rtol=0, atol=1e-12)
+            npt.assert_allclose(sim.soc[e].cpu().numpy(), out["soc_after"], rtol=0, atol=1e-12)
+            if not out["converged"]:
+                continue
+            n_conv += 1
+            assert int(sim.nr_iters[e]) == out["n_iter"], (k, e)
+            npt.assert_allclose(full[e, sl["bus_v_magn"]], np.abs(out["V"]), rtol=0, atol=1e-9)
+            npt.assert_allclose(full[e, sl["bus_v_ang"]], np.angle(out["V"]), rtol=0, atol=1e-9)
+            npt.assert_allclose(full[e, sl["branch_s"]], out["br_s"], rtol=0, atol=1e-9)
+            npt.assert_allclose(full[e, sl["dev_p"]], out["dev_p"], rtol=0, atol=1e-9)
+            npt.assert_allclose(float(r[e]), out["reward"], rtol=1e-9, atol=1e-9)
+    assert n_conv >= n_variants
+    # the class of an environment really is its own: environments of different variants given identical
+    # inputs answer differently
+    same = np.tile(np.concatenate((pl[:1], pp[:1], ps[:1], qs[:1]), 1), (E_, 1))
+    sim.soc.fill_(0.5)
+    sim.transition(same[:, :3], same[:, 3:5], same[:, 5:8], same[:, 8:11])
+    vm = sim.full[:, sl["bus_v_magn"]][:, 3].cpu().numpy().reshape(n_variants, per_variant)
+    assert (np.ptp(vm, axis=1) == 0).all() and len(np.unique(vm[:, 0])) == n_variants
+    # environment layer: ANM6Easy on the same variants, a few steps against OracleEnv
+    env = ANM6EasyVec(num_envs=E_, seed=4, variants=variants, env_variant=env_variant, **kw(base), **extra)
+    env.check_actions = False
+    env.reset(seed=4)
+    s0, c0 = env.state.cpu().numpy().copy(), env.simulator.soc.cpu().numpy().copy()
+    picks = [k * per_variant + 5 for k in range(0, n_variants, max(1, n_variants // 16))]
+    oracles = {}
+    for e in picks:
+        o = O.OracleEnv(nets[e // per_variant], sparse=False)
+        o.load_state(s0[e], c0[e])
+        # the observation Box of the batch is that of the base network (documented): clip like it
+        o.obs_low, o.obs_high = env.observation_space.low, env.observation_space.high
+        oracles[e] = o
+    gen = torch.Generator(device=env.device).manual_seed(6)
+    for t in range(4):
+        a = uniform_actions(env, gen)
+        obs, rew, term, _, _ = env.step(a)
+        for e, o in oracles.items():
+            oo, rr, tt = o.step(a[e].cpu().numpy())
+            assert tt == bool(term[e])
+            npt.assert_allclose(obs[e].cpu().numpy(), oo, rtol=0, atol=1e-8)
+            npt.assert_allclose(float(rew[e]), rr, rtol=1e-9, atol=1e-9)
+    return sim

@@ -205,3 +205,23 @@ def test_track_full_follows_the_steps():
         npt.assert_allclose(st.tensor("dev_p", "MW")[live].cpu().numpy(), env.state[live, :7].cpu().numpy(), rtol=0, atol=1e-9)
         assert torch.equal(env.simulator.pfe_converged, ~term) and torch.equal(env.pfe_converged, ~term)
         assert torch.equal(plain.pfe_converged, ~term)
+
+
+@pytest.mark.parametrize("impl", ["thread", "radial"])
+def test_heterogeneous_networks_64_parameter_classes(impl):
+    """64 distinct networks in one batch of 4096 environments, both kernel families, against the oracle."""
+    sim = pc.heterogeneous_networks(KW, impl=impl)
+    assert sim.impl == impl and len(sim.variant_models) == 64
+
+
+def test_parameter_classes_must_cover_aligned_blocks():
+    from gym_anm_amd import errors, networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    base = networks.anm6_network()
+    ev = np.zeros(128, dtype=np.int32)
+    ev[70:] = 1  # class changes in the middle of a 64-environment block
+    with pytest.raises(errors.HipExtensionError, match="aligned blocks of 64"):
+        BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.perturbed_network(base, 1)], env_variant=ev)
+    with pytest.raises(errors.UnsupportedNetworkError):
+        BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.two_bus_network()])
