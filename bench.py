@@ -112,9 +112,16 @@ def case30_side_figure(dev, E=16384, n=20):
             sim.transition(pl, pp, ps, qs)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / n
+        # HBM roofline of this launch (Simulator.transition with the electrical-state dump): compulsory bytes per
+        # transition = inputs (P_load, P_pot, P/Q set-points) + SoC in/out + dump + reward/e_loss/penalty +
+        # converged + nr_iters
+        nbytes = 8 * (m.N_load + m.N_non_slack_gen + 2 * len(m.setp_idx)) + 16 * m.N_des + 8 * sim.full_dim + 24 + 1 + 4
         out["case30_radial_16384_cap%d" % cap] = {
             "env_steps_per_s": E / dt, "us_per_launch": dt * 1e6, "impl": sim.impl,
             "converged_frac": float(sim.pfe_converged.double().mean()),
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_transition": nbytes, "achieved": nbytes * E / dt / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes * E / dt / 1e9 / HBM_PEAK_GBPS,
+                         "note": "wall clock per launch incl. the SoC restore copy; lane-group kernel, fp64"},
         }
     return out
 
@@ -147,11 +154,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_ranks = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL really spans `world` ranks: one all-reduce of ones must come back as the world size
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(round(float(ones.item())))
+        if rccl_ranks != world or dist.get_world_size() != world:
+            raise SystemExit("RCCL sees %d ranks (get_world_size %d), expected %d" % (rccl_ranks, dist.get_world_size(), world))
 
     from gym_anm_amd.envs import ANM6EasyVec
 
@@ -210,7 +224,7 @@ def main():
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = sim.backend.lib.anm_time_step_launches(
-            sim._handle, E, pool[0].data_ptr(), sim.soc.data_ptr(), env.state.data_ptr(), env._term_u8.data_ptr(),
+            sim._handle, E, pool[0].data_ptr(), sim.soc.data_ptr(), env._state_buf.data_ptr(), env._term_u8.data_ptr(),
             env.timestep.data_ptr(), env._state_obs.data_ptr(), env.reward.data_ptr(), env.e_loss.data_ptr(),
             env.penalty.data_ptr(), 1, env.rng_seed, env.env_offset, env._reset_count.data_ptr(), env._aux_index_ptr,
             env._ws_ref, C.byref(sim.opts), stream,
@@ -298,7 +312,12 @@ def main():
             "config": {
                 "workload": "ANM6Easy-v0 (6-bus), num_envs=%d per GPU, uniform random actions in the action Box, "
                             "in-kernel autoreset of collapsed environments" % E,
-                "num_envs_per_gpu": E, "global_num_envs": E * world, "parallelism": "env-sharded x%d" % world,
+                "num_envs_per_gpu": E, "global_num_envs": E * world,
+                "parallelism": "env-sharded x%d%s" % (world, "" if rccl_ranks is None else ", rccl_ranks=%d" % rccl_ranks),
+                "rccl_ranks": rccl_ranks,
+                "straggler_handoff": {"after_iterations": int(sim.opts.handoff_after), "meaning": "Newton iterations a "
+                                      "solve spends in its own lane before a still-running one continues on a lane "
+                                      "group of the same wavefront (-2: library default, -1: never)"},
                 "nr_tol": args.tol, "nr_max_iter": args.max_iter, "nr_start": "flat",
                 "mean_nr_iters": float(iters_sum.item() / 8), "collapsed_per_step": float(term_sum.item() / 8),
             },

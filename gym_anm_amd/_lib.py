@@ -91,6 +91,7 @@ ABI = {
                                                                       C.POINTER(StepWs), C.POINTER(SolverOpts), _P]),
     "anm_model_set_classes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(NetworkDesc))]),
     "anm_model_bind_env_classes": (C.c_int, [C.c_void_p, _P, C.c_int64]),
+    "anm_model_bind_state_same": (C.c_int, [C.c_void_p, _P]),
     "anm_model_obs_fusable": (C.c_int, [C.c_void_p]),
     "anm_model_set_obs": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p]),
     "anm_gather_obs_f64": (C.c_int, [C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P,

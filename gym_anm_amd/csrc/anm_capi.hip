@@ -127,6 +127,7 @@ struct anm_model {
   std::vector<std::vector<double>> x_const;   // thread-per-environment constants of each extra class
   std::vector<std::vector<double>> x_hd;      // lane-group tables of each extra class
   const int32_t* d_env_class = nullptr;       // caller's device array [num_envs] (anm_model_bind_env_classes)
+  uint8_t* d_state_same = nullptr;            // caller's device array [num_envs] (anm_model_bind_state_same)
   std::vector<cplx> ybus;
 };
 
@@ -434,6 +435,12 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
   return 0;
 }
 
+int anm_model_bind_state_same(anm_model* m, uint8_t* state_same) {
+  if (!m) return fail("anm_model_bind_state_same: null model");
+  m->d_state_same = state_same;
+  return 0;
+}
+
 int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
 
 static unsigned magic_div(int d) { return d > 0 ? unsigned((0x100000000ull + uint64_t(d) - 1) / uint64_t(d)) : 0u; }
@@ -631,6 +638,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   io.env_offset = env_offset;
   io.reset_count = reset_count;
   io.aux_index = aux_index;
+  io.state_same = m->d_state_same;
   io.n_obs = 0;
   io.state_magic = magic_div((m->tpe_ok ? Topo::SDIM : m->plan.d.SDIM) + m->K);
   if (m->tpe_ok && (m->n_obs > 0 || full)) {
@@ -667,6 +675,10 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
   int prec;
   SolverOpts so = solver(opts, prec);
   if (m->impl == ANM_IMPL_RADIAL) {
+    if (io.state_same) {
+      hipError_t em = hipMemsetAsync(io.state_same, 0, size_t(n), s);
+      if (em != hipSuccess) return fail_hip(em, "hipMemsetAsync(state_same)");
+    }
     radial::IO rio{};
     rio.mode = 2;
     rio.e = io;
@@ -698,6 +710,10 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
     return 0;
   }
   io.ws = nullptr;
+  if (io.state_same) {  // this kernel writes every state row: no row is "the same as obs and left out"
+    hipError_t em = hipMemsetAsync(io.state_same, 0, size_t(n), s);
+    if (em != hipSuccess) return fail_hip(em, "hipMemsetAsync(state_same)");
+  }
   if (io.full && !GenLds<Topo>::FULL_OK) {  // rows too wide for LDS: plain per-lane dump, no fused list
     io.n_obs = 0;
   }

@@ -120,6 +120,7 @@ struct EnvIO {
   uint64_t env_offset;      // global index of environment 0 of this batch (RNG key)
   int32_t* reset_count;     // [E] (autoreset)
   int32_t* aux_index;       // [E] series mode: compact copy of the time index (optional)
+  uint8_t* state_same;      // [E] or null (anm_model_bind_state_same): 1 = the state row equals the obs row and was not written
   // list-form observation produced inside the step kernel (anm_model_set_obs): obs[e, k] =
   // clip(src(e, obs_index[k]) * obs_scale[k], obs_lo[k], obs_hi[k]); n_obs == 0: obs = clip(state)
   int n_obs;
@@ -624,8 +625,16 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   }
   step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
   const bool store = valid && !pending;
+  // obs = clip(state) almost always IS the state: the duplicate row is then not written, only a flag
+  bool state_dup = false;
+  if (io.state_same) {
+    bool same = out.write_state && out.write_obs;
+    static_for<0, S>([&](auto Kc) { same = same && (out.state[Kc] == out.obs[Kc]); });
+    state_dup = same;
+  }
   if (store) {
     store_step_scalars<T, 1>(io, e, out, true, ts_prev);
+    if (io.state_same && out.write_state) io.state_same[e] = state_dup ? 1 : 0;
     if (out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
     if constexpr (FULL) {
       if (io.full && out.write_state) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
@@ -650,7 +659,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
     });
     ANM_WAVE_SYNC();
   };
-  store_rows(io.state + e0 * S, out.state, out.write_state);
+  store_rows(io.state + e0 * S, out.state, out.write_state && !state_dup);
   store_rows(io.obs + e0 * S, out.obs, out.write_obs);
   ANM_PHASE(6);
 }
@@ -878,6 +887,7 @@ __device__ void op_step_scatter(const EnvIO& io) {
   static_for<0, T::NDES>([&](auto I) { out.soc[I] = r[Q::SOC + I]; });
   store_step_scalars<T, 1>(io, e, out);
   if (out.write_state) {
+    if (io.state_same) io.state_same[e] = 0;
     io.aux_index[e] = int32_t(r[Q::STATE + T::SDIM]);
     static_for<0, S>([&](auto K) { io.state[e * S + K] = r[Q::STATE + K]; });
   }

@@ -130,7 +130,8 @@ class BatchedANMEnv(GymEnv):
         # ---- device-resident per-environment state ------------------------------------------------
         E_, S = self.num_envs, self.state_N
         f64 = dict(dtype=torch.float64, device=self.device)
-        self.state = torch.zeros((E_, S), **f64)
+        self._state_buf = torch.zeros((E_, S), **f64)
+        self._state_same = None  # uint8 [E]: 1 = the state row equals the obs row and was left unwritten (see `state`)
         self._state_obs = torch.zeros((E_, S), **f64)  # clip(state, state-space bounds), written by the kernel
         self.reward = torch.zeros(E_, **f64)
         self.e_loss = torch.zeros(E_, **f64)
@@ -195,6 +196,13 @@ class BatchedANMEnv(GymEnv):
         if self._series is not None and K == 1 and sim.impl == "thread":
             self._aux_index = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._aux_index_ptr = None if self._aux_index is None else self._aux_index.data_ptr()
+        # "state" observation on the fast path: obs = clip(state) is the state itself unless a bound bites, so
+        # the kernel writes the state row only then and flags the rest (anm_model_bind_state_same)
+        if self._aux_index is not None and self._obs_is_state and sim.backend.device_type == "cuda":
+            self._state_same = torch.zeros(E_, dtype=torch.uint8, device=self.device)
+            with sim._device_ctx():
+                sim.backend.check(sim.backend.lib.anm_model_bind_state_same(sim._handle, self._state_same.data_ptr()),
+                                  "anm_model_bind_state_same")
         # two-phase step (see anm_step_ws in include/anm_mi355x.h): the first launch stops after
         # `straggler_after` Newton iterations, a second launch continues the solves still running
         self._ws = None
@@ -348,12 +356,20 @@ class BatchedANMEnv(GymEnv):
             self._obs_buf = torch.zeros((self.num_envs, n_obs), dtype=torch.float64, device=self.device)
         with sim._device_ctx():
             rc = sim.backend.lib.anm_gather_obs_f64(
-                self.num_envs, sim.full.shape[1], sim.full.data_ptr(), self.state.shape[1], self.K,
-                self.state.data_ptr(), self._term_u8.data_ptr(), n_obs, index.data_ptr(), scale.data_ptr(),
+                self.num_envs, sim.full.shape[1], sim.full.data_ptr(), self._state_buf.shape[1], self.K,
+                self._state_buf.data_ptr(), self._term_u8.data_ptr(), n_obs, index.data_ptr(), scale.data_ptr(),
                 low.data_ptr(), high.data_ptr(), self._obs_buf.data_ptr(), _stream_ptr(self.device),
             )  # fmt: skip
         sim.backend.check(rc, "anm_gather_obs_f64")
         return self._obs_buf
+
+    @property
+    def state(self):
+        """State vectors ``[num_envs, state_N]`` (anm_env.py:139-147).  On the fast path this is assembled on
+        access: rows the kernel did not write because they equal the observation are taken from it."""
+        if self._state_same is None:
+            return self._state_buf
+        return torch.where(self._state_same.bool().unsqueeze(1), self._state_obs, self._state_buf)
 
     @property
     def terminated(self):
@@ -373,12 +389,17 @@ class BatchedANMEnv(GymEnv):
             rc = sim.backend.lib.anm_reset_f64(
                 sim._handle, self.num_envs, None if init_state is None else init_state.data_ptr(),
                 None if mask_u8 is None else mask_u8.data_ptr(), self.rng_seed, self.env_offset, self._reset_count_ptr,
-                sim.soc.data_ptr(), self.state.data_ptr(), self._state_obs.data_ptr(), self._conv_u8.data_ptr(),
+                sim.soc.data_ptr(), self._state_buf.data_ptr(), self._state_obs.data_ptr(), self._conv_u8.data_ptr(),
                 self._term_u8.data_ptr(), self.timestep.data_ptr(), sim.nr_iters.data_ptr(),
                 sim.full.data_ptr() if (self._need_full_reset or self._need_full) else None, self._aux_index_ptr,
                 C.byref(sim.opts), _stream_ptr(self.device),
             )  # fmt: skip
         sim.backend.check(rc, "anm_reset_f64")
+        if self._state_same is not None:  # the reset kernel writes both rows
+            if mask_u8 is None:
+                self._state_same.zero_()
+            else:
+                self._state_same.mul_(1 - mask_u8)
         self._after_step = False
         if self._need_full_reset or self._need_full:
             sim.state = StateView(sim, sim.full)
@@ -476,7 +497,7 @@ class BatchedANMEnv(GymEnv):
         args = self._step_args
         if args is None:
             args = self._step_args = (
-                sim.soc.data_ptr(), self.state.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(),
+                sim.soc.data_ptr(), self._state_buf.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(),
                 (self._obs_buf if self._obs_fused else self._state_obs).data_ptr(), self.reward.data_ptr(),
                 self.e_loss.data_ptr(), self.penalty.data_ptr(), sim.nr_iters.data_ptr(),
                 sim.full.data_ptr() if self._need_full else None,

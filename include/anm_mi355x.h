@@ -132,6 +132,13 @@ int anm_model_get_ybus(const anm_model* m, double* y_host);
 int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_desc* const* descs);
 int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t num_envs);
 
+/* The observation of the "state" form is clip(state, Box): the same numbers as the state row except when a
+ * bound bites.  With a flag array bound here (DEVICE uint8 [num_envs], caller-owned, alive while bound; NULL
+ * unbinds) anm_step_f64 does not write the duplicate: state_same[e] = 1 means "the state row of e equals its
+ * obs row and was not written" (the caller reads obs instead), 0 means the state row is valid.  Saves 8 S
+ * bytes of the 401 an ANM6Easy env-step moves.  Kernels that always write both rows clear the flags. */
+int anm_model_bind_state_same(anm_model* m, uint8_t* state_same);
+
 /* precision of the Jacobian + block-LU inside Newton-Raphson; mismatch F, the stop test and the
  * state update are always fp64. */
 #define ANM_SOLVE_F64 0

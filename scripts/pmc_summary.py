@@ -40,4 +40,5 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     fb, wb = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
     print("    FETCH_SIZE  %.2f MB raw, %.2f MB with the gfx950 x2 correction" % (fb / 1e6, 2 * fb / 1e6))
     print("    WRITE_SIZE  %.2f MB raw" % (wb / 1e6))
-    print("    HBM traffic per launch (corrected fetch + write) %.2f MB; algorithmic 65536 x 250 B = 16.38 MB" % ((2 * fb + wb) / 1e6))
+    print("    HBM traffic per launch (corrected fetch + write) %.2f MB" % ((2 * fb + wb) / 1e6))
+    print("    (headline: algorithmic 65536 x 250 B = 16.38 MB; config 4: 16384 x bench.py's algorithmic_bytes_per_transition)")

@@ -161,6 +161,7 @@ int anm_model_set_classes(anm_model*, int32_t n_classes, const anm_network_desc*
 int anm_model_bind_env_classes(anm_model*, const int32_t* env_class, int64_t) {
   return env_class ? fail("the host test double has no parameter classes") : 0;
 }
+int anm_model_bind_state_same(anm_model*, uint8_t* p) { return p ? fail("the host test double writes every state row") : 0; }
 int anm_model_obs_fusable(const anm_model*) { return 0; }  // the test double has no fused gather
 int anm_model_set_obs(anm_model*, int32_t n_obs, const int32_t*, const double*, const double*, const double*) {
   return n_obs > 0 ? fail("the host test double gathers with anm_gather_obs_f64") : 0;
