@@ -64,7 +64,7 @@ class FullLayout(C.Structure):
 
 
 SOLVE_F64, SOLVE_F32 = 0, 1
-IMPL_THREAD, IMPL_RADIAL = 0, 1
+IMPL_THREAD, IMPL_RADIAL, IMPL_MESH = 0, 1, 2
 HANDOFF_NEVER, HANDOFF_AUTO = -1, -2
 
 _P = C.c_void_p  # raw device (or, for the test double, host) pointers are passed as integers
@@ -155,14 +155,18 @@ def load_for_topology(topo, impl=None) -> Backend:
 
     * a library specialised for this topology (thread-per-environment kernels + the generic
       lane-group kernel) when it exists or when it is worth building (networks up to 12 buses);
-    * otherwise, for radial networks, any already-built library in *generic* mode: the lane-group
-      kernel is table-driven and needs no per-topology compilation;
-    * otherwise build the specialised library with hipcc (meshed networks above 12 buses)."""
+    * otherwise, for networks that fit a wavefront (radial: impl "radial"; any topology: impl "mesh"), any
+      already-built library in *generic* mode: the lane-group kernels are table-driven and need no
+      per-topology compilation;
+    * otherwise build the specialised library with hipcc."""
     name = codegen.topology_name(topo)
     if name in _CACHE:
         return _CACHE[name]
     path = codegen.lib_path(name)
-    if not os.path.exists(path) and _is_tree(topo) and (impl == "radial" or (impl is None and topo[0] > 12)):
+    fits_group = topo[0] - 1 <= 64 and len(topo[1]) <= 64 and len(topo[2]) <= 64
+    generic = (_is_tree(topo) and (impl == "radial" or (impl is None and topo[0] > 12))) or \
+              (fits_group and (impl == "mesh" or (impl is None and topo[0] > 12)))
+    if not os.path.exists(path) and generic:
         for cand in sorted(os.listdir(codegen.BUILD_DIR)) if os.path.isdir(codegen.BUILD_DIR) else []:
             if cand.startswith("libanm_") and cand.endswith(".so") and cand.count(".") == 1:
                 gpath = os.path.join(codegen.BUILD_DIR, cand)

@@ -18,6 +18,7 @@
 #include "anm_env_ops.hpp"
 #include "anm_pack.hpp"
 #include "anm_radial.hpp"
+#include "anm_mesh.hpp"
 
 using namespace anm;
 
@@ -108,6 +109,11 @@ struct anm_model {
   bool tpe_ok = false;          // the network has the topology this library was compiled for
   bool radial_ok = false;       // the network is a tree that fits one wavefront
   radial::Plan plan;            // per-lane tables of the lane-group kernel
+  bool mesh_ok = false;         // the general lane-group kernel can take the network
+  mesh::Plan mplan;
+  int* d_mi = nullptr;
+  double* d_md = nullptr;
+  std::vector<std::vector<double>> x_md;      // general lane-group tables of each extra class
   int* d_ri = nullptr;
   double* d_rd = nullptr;
   double* d_const = nullptr;    // device constant buffer (Layout<Topo>)
@@ -149,6 +155,13 @@ int upload_const(anm_model* m) {
       e = hipMemcpy(m->d_rd + (k + 1) * n, m->x_hd[k].data(), n * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail_hip(e, "hipMemcpy(radial tables)");
   }
+  if (m->mesh_ok) {
+    const size_t n = m->mplan.hd.size();
+    e = hipMemcpy(m->d_md, m->mplan.hd.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    for (size_t k = 0; k < m->x_md.size() && e == hipSuccess; ++k)
+      e = hipMemcpy(m->d_md + (k + 1) * n, m->x_md[k].data(), n * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpy(mesh tables)");
+  }
   return 0;
 }
 
@@ -156,6 +169,22 @@ ClassSel class_sel(const anm_model* m, bool radial) {
   ClassSel cs{m->d_env_class, 0};
   if (cs.env_class) cs.stride = radial ? int(m->plan.hd.size()) : int(m->h_const.size());
   return cs;
+}
+
+int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
+  const mesh::Dims& d = m->mplan.d;
+  const int per_wave = 64 / d.G;
+  const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
+  const size_t lds = size_t(per_wave) * d.lds_per_env * sizeof(double) + size_t(d.off_fill + d.n_fill - d.off_task) * sizeof(int);
+  ClassSel cs{m->d_env_class, 0};
+  if (cs.env_class) cs.stride = int(m->mplan.hd.size());
+  if (precision == ANM_SOLVE_F32)
+    hipLaunchKernelGGL(mesh::k_mesh<float>, dim3(grid), dim3(64), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+  else
+    hipLaunchKernelGGL(mesh::k_mesh<double>, dim3(grid), dim3(64), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_mesh");
+  return 0;
 }
 
 int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
@@ -239,15 +268,33 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
       if (ev && std::string(ev) == "radial") m->impl = ANM_IMPL_RADIAL;
     }
   }
-  if (!m->tpe_ok && !m->radial_ok) {
-    // neither the compiled topology nor a tree the generic lane-group kernel can take
+  {  // the general lane-group kernel: any topology that fits a wavefront
+    std::string err_mesh;
+    if (mesh::build_plan(*desc, m->mplan, err_mesh)) {
+      hipError_t e1 = hipMalloc(&m->d_mi, m->mplan.hi.size() * sizeof(int));
+      hipError_t e2 = hipMalloc(&m->d_md, m->mplan.hd.size() * sizeof(double));
+      if (e1 == hipSuccess && e2 == hipSuccess &&
+          hipMemcpy(m->d_mi, m->mplan.hi.data(), m->mplan.hi.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
+        m->mesh_ok = true;
+        // default for what neither of the other families serves well: not a tree, and either not the compiled
+        // topology or too large for one thread's registers
+        if (!m->radial_ok && (!m->tpe_ok || desc->n_bus > 12)) m->impl = ANM_IMPL_MESH;
+        const char* ev = getenv("ANM_IMPL");
+        if (ev && std::string(ev) == "mesh") m->impl = ANM_IMPL_MESH;
+      }
+    }
+  }
+  if (!m->tpe_ok && !m->radial_ok && !m->mesh_ok) {
+    // neither the compiled topology nor a network the generic lane-group kernels can take
     if (m->d_ri) hipFree(m->d_ri);
     if (m->d_rd) hipFree(m->d_rd);
+    if (m->d_mi) hipFree(m->d_mi);
+    if (m->d_md) hipFree(m->d_md);
     delete m;
     g_err = err_topo;
     return -3;
   }
-  if (!m->tpe_ok) {  // generic (radial-only) model: dense Y_bus for diagnostics
+  if (!m->tpe_ok) {  // generic model: dense Y_bus for diagnostics
     const int NB = desc->n_bus;
     m->ybus.assign(size_t(NB) * NB, cplx(0, 0));
     for (int b = 0; b < desc->n_branch; ++b) {
@@ -275,6 +322,8 @@ void anm_model_destroy(anm_model* m) {
   if (m->d_series) hipFree(m->d_series);
   if (m->d_ri) hipFree(m->d_ri);
   if (m->d_rd) hipFree(m->d_rd);
+  if (m->d_mi) hipFree(m->d_mi);
+  if (m->d_md) hipFree(m->d_md);
   if (m->d_obs_index) hipFree(m->d_obs_index);
   if (m->d_obs_tab) hipFree(m->d_obs_tab);
   delete m;
@@ -283,10 +332,13 @@ void anm_model_destroy(anm_model* m) {
 int anm_model_dims(const anm_model* m, anm_dims* out) {
   if (!m || !out) return fail("anm_model_dims: null argument");
   if (!m->tpe_ok) {
-    const radial::Dims& d = m->plan.d;
-    out->n_bus = d.NB; out->n_dev = d.ND; out->n_branch = d.NBR; out->n_load = d.NLOAD; out->n_gen = d.NGEN;
-    out->n_des = d.NDES; out->action_dim = 2 * (d.NGEN + d.NDES); out->state_base_dim = d.SDIM;
-    out->full_dim = d.FS; out->const_doubles = d.n_double;
+    auto fill = [&](const auto& d) {
+      out->n_bus = d.NB; out->n_dev = d.ND; out->n_branch = d.NBR; out->n_load = d.NLOAD; out->n_gen = d.NGEN;
+      out->n_des = d.NDES; out->action_dim = 2 * (d.NGEN + d.NDES); out->state_base_dim = d.SDIM;
+      out->full_dim = d.FS; out->const_doubles = d.n_double;
+    };
+    if (m->radial_ok) fill(m->plan.d);
+    else fill(m->mplan.d);
     return 0;
   }
   out->n_bus = Topo::NB;
@@ -304,6 +356,14 @@ int anm_model_dims(const anm_model* m, anm_dims* out) {
 
 int anm_model_full_layout(const anm_model* m, anm_full_layout* o) {
   if (!m || !o) return fail("anm_model_full_layout: null argument");
+  if (!m->tpe_ok && !m->radial_ok) {
+    const mesh::Dims& d = m->mplan.d;
+    o->bus_p = d.f_bus_p; o->bus_q = d.f_bus_q; o->bus_v_magn = d.f_bus_vm; o->bus_v_ang = d.f_bus_va;
+    o->bus_i_magn = d.f_bus_im; o->bus_i_ang = d.f_bus_ia; o->dev_p = d.f_dev_p; o->dev_q = d.f_dev_q;
+    o->des_soc = d.f_des_soc; o->gen_p_max = d.f_gen_pmax; o->branch_p = d.f_br_p; o->branch_q = d.f_br_q;
+    o->branch_s = d.f_br_s; o->branch_i_magn = d.f_br_im; o->branch_i_ang = d.f_br_ia; o->size = d.FS;
+    return 0;
+  }
   if (!m->tpe_ok) {
     const radial::Dims& d = m->plan.d;
     o->bus_p = d.f_bus_p; o->bus_q = d.f_bus_q; o->bus_v_magn = d.f_bus_vm; o->bus_v_ang = d.f_bus_va;
@@ -349,6 +409,21 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
       }
     }
   }
+  if (m->mesh_ok) {
+    mesh::Plan& P = m->mplan;
+    auto apply = [&](std::vector<double>& hd) {
+      hd[radial::SF_C1] = cfg->clip_e_loss;
+      hd[radial::SF_C2] = cfg->clip_penalty;
+      hd[radial::SF_RTERM] = -cfg->clip_penalty / (1 - cfg->gamma);
+      hd[radial::SF_PERIOD] = cfg->period;
+      for (int k = 0; k < P.d.SDIM + cfg->K; ++k) {
+        if (cfg->obs_low) hd[P.d.off_obs_lo + k] = cfg->obs_low[k];
+        if (cfg->obs_high) hd[P.d.off_obs_hi + k] = cfg->obs_high[k];
+      }
+    };
+    apply(P.hd);
+    for (auto& x : m->x_md) apply(x);
+  }
   if (m->d_series) {
     hipFree(m->d_series);
     m->d_series = nullptr;
@@ -356,7 +431,8 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
   m->period = 0;
   if (cfg->series && cfg->period > 0) {
     if (cfg->K != 1) return fail("series mode needs exactly K = 1 auxiliary variable (the time index)");
-    const size_t nexo = m->tpe_ok ? size_t(Dims<Topo>::NEXO) : size_t(m->plan.d.NLOAD + m->plan.d.NGEN);
+    const size_t nexo = m->tpe_ok ? size_t(Dims<Topo>::NEXO)
+                                  : (m->radial_ok ? size_t(m->plan.d.NLOAD + m->plan.d.NGEN) : size_t(m->mplan.d.NLOAD + m->mplan.d.NGEN));
     const size_t bytes = sizeof(double) * nexo * size_t(cfg->period);
     hipError_t e = hipMalloc(&m->d_series, bytes ? bytes : 8);
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(series)");
@@ -372,7 +448,7 @@ int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_des
   if (!m) return fail("anm_model_set_classes: null model");
   if (n_classes < 1 || n_classes > 65536) return fail("anm_model_set_classes: n_classes must be in [1, 65536]");
   if (n_classes > 1 && !descs) return fail("anm_model_set_classes: null descriptions");
-  std::vector<std::vector<double>> xc, xh;
+  std::vector<std::vector<double>> xc, xh, xm;
   for (int k = 1; k < n_classes; ++k) {
     if (!descs[k]) return fail("anm_model_set_classes: null description");
     std::string err;
@@ -393,6 +469,14 @@ int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_des
       }
       xh.push_back(std::move(P.hd));
     }
+    if (m->mesh_ok) {
+      mesh::Plan P;
+      if (!mesh::build_plan(*descs[k], P, err) || P.hi != m->mplan.hi || P.hd.size() != m->mplan.hd.size()) {
+        g_err = "class " + std::to_string(k) + ": not the topology of the model" + (err.empty() ? "" : " (" + err + ")");
+        return -3;
+      }
+      xm.push_back(std::move(P.hd));
+    }
   }
   // (re)allocate the device buffers for n_classes consecutive copies
   if (m->tpe_ok) {
@@ -409,8 +493,16 @@ int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_des
     hipFree(m->d_rd);
     m->d_rd = p;
   }
+  if (m->mesh_ok) {
+    double* p = nullptr;
+    hipError_t e = hipMalloc(&p, size_t(n_classes) * m->mplan.hd.size() * sizeof(double));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(class tables)");
+    hipFree(m->d_md);
+    m->d_md = p;
+  }
   m->x_const = std::move(xc);
   m->x_hd = std::move(xh);
+  m->x_md = std::move(xm);
   m->d_env_class = nullptr;
   m->env_set = false;   // the task constants (anm_model_set_env) must be set again: they live in every class
   return upload_const(m);
@@ -423,7 +515,7 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
     return 0;
   }
   if (num_envs <= 0) return fail("anm_model_bind_env_classes: num_envs must be positive");
-  const int n_classes = 1 + int(m->tpe_ok ? m->x_const.size() : m->x_hd.size());
+  const int n_classes = 1 + int(m->tpe_ok ? m->x_const.size() : (m->radial_ok ? m->x_hd.size() : m->x_md.size()));
   std::vector<int32_t> h(static_cast<size_t>(num_envs));
   hipError_t e = hipMemcpy(h.data(), env_class, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail_hip(e, "anm_model_bind_env_classes");
@@ -510,7 +602,10 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
   if (!m) return fail("anm_model_set_impl: null model");
   if (impl == ANM_IMPL_RADIAL && !m->radial_ok)
     return fail("the lane-group kernel needs a radial (tree) network with at most 64 buses and devices");
-  if (impl != ANM_IMPL_THREAD && impl != ANM_IMPL_RADIAL) return fail("anm_model_set_impl: unknown implementation");
+  if (impl == ANM_IMPL_MESH && !m->mesh_ok)
+    return fail("the general lane-group kernel needs a network of at most 65 buses, 64 branches, 64 devices");
+  if (impl != ANM_IMPL_THREAD && impl != ANM_IMPL_RADIAL && impl != ANM_IMPL_MESH)
+    return fail("anm_model_set_impl: unknown implementation");
   if (impl == ANM_IMPL_THREAD && !m->tpe_ok)
     return fail("this library was compiled for another topology: only the generic lane-group kernel is available");
   m->impl = impl;
@@ -539,11 +634,11 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   int prec;
   SolverOpts so = solver(opts, prec);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (m->impl == ANM_IMPL_RADIAL) {
+  if (m->impl == ANM_IMPL_RADIAL || m->impl == ANM_IMPL_MESH) {
     radial::IO rio{};
     rio.mode = 0;
     rio.t = io;
-    return launch_radial(m, prec, n, s, rio, so);
+    return m->impl == ANM_IMPL_MESH ? launch_mesh(m, prec, n, s, rio, so) : launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
   if (prec == ANM_SOLVE_F32)
@@ -586,11 +681,11 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
   int prec;
   SolverOpts so = solver(opts, prec);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (m->impl == ANM_IMPL_RADIAL) {
+  if (m->impl == ANM_IMPL_RADIAL || m->impl == ANM_IMPL_MESH) {
     radial::IO rio{};
     rio.mode = 1;
     rio.e = io;
-    return launch_radial(m, prec, n, s, rio, so);
+    return m->impl == ANM_IMPL_MESH ? launch_mesh(m, prec, n, s, rio, so) : launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
   if (prec == ANM_SOLVE_F32)
@@ -611,7 +706,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
   if (!action || !state || !terminated || !obs || !reward || !e_loss || !penalty)
     return fail("anm_step_f64: null argument");
-  if ((m->tpe_ok ? Topo::NDES : m->plan.d.NDES) > 0 && !soc) return fail("anm_step_f64: null soc");
+  if ((m->tpe_ok ? Topo::NDES : (m->radial_ok ? m->plan.d.NDES : m->mplan.d.NDES)) > 0 && !soc) return fail("anm_step_f64: null soc");
   const bool series = exo == nullptr;
   if (series && m->period <= 0) return fail("anm_step_f64: no exo given and the model has no series (set_env)");
   if (!series && m->K > 0 && !aux_next) return fail("anm_step_f64: exo given without aux_next");
@@ -640,7 +735,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   io.aux_index = aux_index;
   io.state_same = m->d_state_same;
   io.n_obs = 0;
-  io.state_magic = magic_div((m->tpe_ok ? Topo::SDIM : m->plan.d.SDIM) + m->K);
+  io.state_magic = magic_div((m->tpe_ok ? Topo::SDIM : (m->radial_ok ? m->plan.d.SDIM : m->mplan.d.SDIM)) + m->K);
   if (m->tpe_ok && (m->n_obs > 0 || full)) {
     // rows of the electrical state in LDS: identity layout when the dump is asked for, else only the classes
     // the observation list reads
@@ -674,7 +769,7 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
   EnvIO io = io_in;
   int prec;
   SolverOpts so = solver(opts, prec);
-  if (m->impl == ANM_IMPL_RADIAL) {
+  if (m->impl == ANM_IMPL_RADIAL || m->impl == ANM_IMPL_MESH) {
     if (io.state_same) {
       hipError_t em = hipMemsetAsync(io.state_same, 0, size_t(n), s);
       if (em != hipSuccess) return fail_hip(em, "hipMemsetAsync(state_same)");
@@ -682,7 +777,7 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
     radial::IO rio{};
     rio.mode = 2;
     rio.e = io;
-    return launch_radial(m, prec, n, s, rio, so);
+    return m->impl == ANM_IMPL_MESH ? launch_mesh(m, prec, n, s, rio, so) : launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
   if (io.aux_index && io.exo == nullptr && io.K == 1 && !io.full && io.n_obs == 0) {

@@ -1,0 +1,736 @@
+// anm_mesh.hpp -- lane-group kernel for ANY network topology (loops, parallel feeders, transformers) of up
+// to 64 buses / branches / devices: the general-sparsity sibling of anm_radial.hpp.
+//
+// The thread-per-environment kernels keep a whole environment in one thread's registers; that stops
+// working around a dozen buses (a meshed 30-bus network: 512 registers + scratch per lane, 2.8 ms per
+// 16 384 transitions).  The radial kernel spreads an environment over a lane group but relies on the
+// network being a tree.  Here the same lane group works on a general sparse Jacobian:
+//     lane l  <->  bus l + 1,  branch l,  device l           (three roles at once, as in anm_radial.hpp)
+// Per Newton iteration
+//   bus lanes publish V; BRANCH lanes form the products W_ft = V_f conj(Y_ft V_t), W_tf of their branch and
+//   with them the two off-diagonal 2x2 Jacobian blocks of the branch; bus lanes sum their row of W (mismatch,
+//   diagonal block); the group-wide inf-norm is a shuffle butterfly;
+//   the block matrix lives in LDS ([blocks][4] doubles per environment) and is eliminated with the static,
+//   fill-minimising order computed once per network on the host (build_plan: minimum degree), LEVEL by level:
+//   pivots of one level are pairwise non-adjacent, so they invert their diagonal blocks together, then every
+//   lane applies the updates of its own row (task list: pivot, its block L_ik, the (destination, source)
+//   block pairs); back substitution walks the levels in reverse.
+// A workgroup is one wavefront whose LDS operations complete in program order, so the hand-overs between
+// the phases need compiler fences only.  Nothing is compiled per topology: integer tables drive one generic
+// kernel (the reference solves whatever network it is given: solve_load_flow.py:123-164, 220 -- SciPy's
+// sparse LU on the same matrix).  Same reference semantics and the same formulation (W products, magnitude
+// columns scaled by |V|, (cos, sin) state, rotated stop test) as anm_device.hpp; see the citations there.
+#pragma once
+
+#include <algorithm>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "anm_radial.hpp"
+
+namespace anm {
+namespace mesh {
+
+using radial::DEV_NONE;
+using radial::KMAX;
+using radial::SF_BASE; using radial::SF_DT; using radial::SF_LAMB; using radial::SF_C1; using radial::SF_C2;
+using radial::SF_RTERM; using radial::SF_PERIOD; using radial::SF_Y00_RE; using radial::SF_Y00_IM;
+using radial::SF_SLACK_VMIN; using radial::SF_SLACK_VMAX; using radial::SF_COUNT;
+
+enum IField : int { IF_LEVEL = 0, IF_DIAG, IF_INC_BEG, IF_INC_END, IF_BD_BEG, IF_BD_END, IF_UP_BEG, IF_UP_END,
+                    IF_BR_F, IF_BR_T, IF_BR_BLK_FT, IF_BR_BLK_TF, IF_DEV_TYPE, IF_DEV_SLOT, IF_DEV_SET, IF_COUNT };
+enum DField : int { DF_YII_RE = 0, DF_YII_IM, DF_VMIN, DF_VMAX, DF_YFT_RE, DF_YFT_IM, DF_YTF_RE, DF_YTF_IM, DF_BRC,
+                    DF_COUNT = DF_BRC + 9 };
+
+struct Dims {
+  int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, n_levels, slack_dev, NBLK, n_fill;
+  int off_task, off_lists, n_lists, off_fill;              // ints: [IF_COUNT][G], task ranges [n_levels][2][G], lists, fill ids
+  int off_lane, off_dev, off_obs_lo, off_obs_hi, n_double;  // doubles
+  int l_v, l_bw, l_blk, l_r, l_x, l_dev, lds_per_env;       // LDS layout of one environment (doubles)
+  int f_bus_p, f_bus_q, f_bus_vm, f_bus_va, f_bus_im, f_bus_ia, f_dev_p, f_dev_q, f_des_soc, f_gen_pmax, f_br_p,
+      f_br_q, f_br_s, f_br_im, f_br_ia;
+};
+
+struct Plan {
+  Dims d;
+  std::vector<int> hi;
+  std::vector<double> hd;
+};
+
+inline bool fits(const anm_network_desc& n) {
+  return n.n_bus >= 2 && n.n_bus - 1 <= 64 && n.n_dev <= 64 && n.n_branch <= 64;
+}
+
+// Symbolic analysis + per-lane tables for one network.
+inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
+  if (!fits(n)) { err = "the general lane-group kernel takes networks of at most 65 buses, 64 branches, 64 devices"; return false; }
+  Dims& d = P.d;
+  d.NB = n.n_bus; d.ND = n.n_dev; d.NBR = n.n_branch;
+  d.NLOAD = d.NGEN = d.NDES = 0;
+  std::vector<int> slot(n.n_dev, -1), sset(n.n_dev, -1);
+  d.slack_dev = -1;
+  for (int k = 0; k < n.n_dev; ++k) {
+    const int t = n.dev_type[k];
+    if (t == DEV_LOAD) slot[k] = d.NLOAD++;
+    else if (t == DEV_CLASSICAL || t == DEV_RENEWABLE) slot[k] = d.NGEN++;
+    else if (t == DEV_STORAGE) slot[k] = d.NDES++;
+    else d.slack_dev = k;
+  }
+  d.NSET = 0;
+  for (int k = 0; k < n.n_dev; ++k)
+    if (n.dev_type[k] == DEV_CLASSICAL || n.dev_type[k] == DEV_RENEWABLE || n.dev_type[k] == DEV_STORAGE) sset[k] = d.NSET++;
+  d.SDIM = 2 * d.ND + d.NDES + d.NGEN;
+  const int need = std::max(std::max(d.NB - 1, d.ND), d.NBR);
+  d.G = 8;
+  while (d.G < need) d.G *= 2;
+  const int G = d.G, NB = d.NB;
+  d.f_bus_p = 0; d.f_bus_q = d.f_bus_p + NB; d.f_bus_vm = d.f_bus_q + NB; d.f_bus_va = d.f_bus_vm + NB;
+  d.f_bus_im = d.f_bus_va + NB; d.f_bus_ia = d.f_bus_im + NB; d.f_dev_p = d.f_bus_ia + NB;
+  d.f_dev_q = d.f_dev_p + d.ND; d.f_des_soc = d.f_dev_q + d.ND; d.f_gen_pmax = d.f_des_soc + d.NDES;
+  d.f_br_p = d.f_gen_pmax + d.NGEN; d.f_br_q = d.f_br_p + d.NBR; d.f_br_s = d.f_br_q + d.NBR;
+  d.f_br_im = d.f_br_s + d.NBR; d.f_br_ia = d.f_br_im + d.NBR; d.FS = d.f_br_ia + d.NBR;
+
+  // ---- Y (dense on the host; parallel branches between the same pair of buses are not supported, as in
+  // the reference whose Y[f, t] assignment keeps only the last one: refuse instead of silently differing)
+  std::vector<cplx> Y(size_t(NB) * NB, cplx(0, 0));
+  std::set<std::pair<int, int>> pairs;
+  for (int b = 0; b < d.NBR; ++b) {
+    const int f = n.br_from[b], t = n.br_to[b];
+    if (f == t || !pairs.insert({std::min(f, t), std::max(f, t)}).second) {
+      err = "parallel branches / self loops are not supported";
+      return false;
+    }
+    const cplx ys(n.br_series[2 * b], n.br_series[2 * b + 1]), sh(n.br_shunt[2 * b], n.br_shunt[2 * b + 1]);
+    const cplx tap(n.br_tap[2 * b], n.br_tap[2 * b + 1]);
+    Y[f * NB + t] = -ys / std::conj(tap);
+    Y[t * NB + f] = -ys / tap;
+    Y[f * NB + f] += (ys + sh) / (std::abs(tap) * std::abs(tap));
+    Y[t * NB + t] += ys + sh;
+  }
+
+  // ---- symbolic block LU over the non-slack buses: minimum degree (ties: larger bus first, leaves of a
+  // feeder before its trunk), fill, elimination levels
+  std::vector<std::set<int>> adj(NB);
+  for (int b = 0; b < d.NBR; ++b) {
+    const int f = n.br_from[b], t = n.br_to[b];
+    if (f != 0 && t != 0) { adj[f].insert(t); adj[t].insert(f); }
+  }
+  std::vector<std::vector<int>> blk(NB, std::vector<int>(NB, -1));
+  int nblk = 0;
+  for (int i = 1; i < NB; ++i) {
+    blk[i][i] = nblk++;
+    for (int j : adj[i]) blk[i][j] = nblk++;
+  }
+  std::vector<int> fill_ids;
+  std::vector<std::set<int>> work = adj;
+  std::vector<char> done(NB, 0);
+  std::vector<int> order, level(NB, 0);
+  std::vector<std::vector<int>> upper(NB);
+  for (int step = 1; step < NB; ++step) {
+    int best = -1, best_deg = 1 << 30;
+    for (int u = NB - 1; u >= 1; --u) {
+      if (done[u]) continue;
+      int deg = 0;
+      for (int v : work[u]) deg += !done[v];
+      if (deg < best_deg) { best_deg = deg; best = u; }
+    }
+    const int k = best;
+    done[k] = 1;
+    order.push_back(k);
+    std::vector<int> nb;
+    for (int v : work[k]) if (!done[v]) nb.push_back(v);
+    upper[k] = nb;
+    for (int i : nb)
+      for (int j : nb) {
+        if (blk[i][j] < 0) { blk[i][j] = nblk++; fill_ids.push_back(blk[i][j]); }
+        if (i != j) work[i].insert(j);
+      }
+    for (int i : nb) level[i] = std::max(level[i], level[k] + 1);
+  }
+  d.NBLK = nblk;
+  d.n_fill = int(fill_ids.size());
+  d.n_levels = 0;
+  for (int i = 1; i < NB; ++i) d.n_levels = std::max(d.n_levels, level[i] + 1);
+
+  // ---- int tables
+  P.hi.assign(size_t(IF_COUNT) * G, 0);
+  auto I = [&](int f, int l) -> int& { return P.hi[size_t(f) * G + l]; };
+  for (int l = 0; l < G; ++l) {
+    I(IF_LEVEL, l) = -1; I(IF_DIAG, l) = -1; I(IF_BR_F, l) = -1; I(IF_BR_T, l) = -1; I(IF_BR_BLK_FT, l) = -1;
+    I(IF_BR_BLK_TF, l) = -1; I(IF_DEV_TYPE, l) = DEV_NONE; I(IF_DEV_SLOT, l) = -1; I(IF_DEV_SET, l) = -1;
+  }
+  std::vector<int> lists;
+  for (int l = 0; l + 1 < NB; ++l) {
+    const int b = l + 1;
+    I(IF_LEVEL, l) = level[b];
+    I(IF_DIAG, l) = blk[b][b];
+    I(IF_INC_BEG, l) = int(lists.size());
+    for (int br = 0; br < d.NBR; ++br) {  // branch order = the order the reference sums a row of Y V in
+      if (n.br_from[br] == b) lists.push_back(br << 1);
+      else if (n.br_to[br] == b) lists.push_back((br << 1) | 1);
+    }
+    I(IF_INC_END, l) = int(lists.size());
+    I(IF_BD_BEG, l) = int(lists.size());
+    for (int k = 0; k < d.ND; ++k)
+      if (n.dev_bus[k] == b) lists.push_back(k);
+    I(IF_BD_END, l) = int(lists.size());
+    I(IF_UP_BEG, l) = int(lists.size());
+    for (int j : upper[b]) { lists.push_back(j); lists.push_back(blk[b][j]); }
+    I(IF_UP_END, l) = int(lists.size());
+  }
+  for (int br = 0; br < d.NBR; ++br) {
+    const int f = n.br_from[br], t = n.br_to[br];
+    I(IF_BR_F, br) = f; I(IF_BR_T, br) = t;
+    I(IF_BR_BLK_FT, br) = (f != 0 && t != 0) ? blk[f][t] : -1;
+    I(IF_BR_BLK_TF, br) = (f != 0 && t != 0) ? blk[t][f] : -1;
+  }
+  for (int k = 0; k < d.ND; ++k) {
+    I(IF_DEV_TYPE, k) = n.dev_type[k];
+    I(IF_DEV_SLOT, k) = slot[k];
+    I(IF_DEV_SET, k) = sset[k];
+  }
+  // tasks of lane i at level lv: for every pivot k of that level adjacent to i (i eliminated later):
+  //   [k, diag block of k, block (i,k), n, n x (destination block (i,j), source block (k,j))]
+  std::vector<int> task_beg(size_t(d.n_levels) * G, 0), task_end(size_t(d.n_levels) * G, 0);
+  std::vector<std::vector<std::vector<int>>> tasks(d.n_levels, std::vector<std::vector<int>>(G));
+  for (int k : order)
+    for (int i : upper[k]) {
+      std::vector<int>& t = tasks[level[k]][i - 1];
+      t.push_back(k); t.push_back(blk[k][k]); t.push_back(blk[i][k]); t.push_back(int(upper[k].size()));
+      for (int j : upper[k]) { t.push_back(blk[i][j]); t.push_back(blk[k][j]); }
+    }
+  for (int lv = 0; lv < d.n_levels; ++lv)
+    for (int l = 0; l < G; ++l) {
+      task_beg[size_t(lv) * G + l] = int(lists.size());
+      lists.insert(lists.end(), tasks[lv][l].begin(), tasks[lv][l].end());
+      task_end[size_t(lv) * G + l] = int(lists.size());
+    }
+  d.off_task = int(P.hi.size());
+  P.hi.insert(P.hi.end(), task_beg.begin(), task_beg.end());
+  P.hi.insert(P.hi.end(), task_end.begin(), task_end.end());
+  d.off_lists = int(P.hi.size());
+  d.n_lists = int(lists.size());
+  P.hi.insert(P.hi.end(), lists.begin(), lists.end());
+  d.off_fill = int(P.hi.size());
+  P.hi.insert(P.hi.end(), fill_ids.begin(), fill_ids.end());
+  P.hi.push_back(0);
+
+  // ---- double tables
+  d.off_lane = SF_COUNT;
+  d.off_dev = d.off_lane + DF_COUNT * G;
+  d.off_obs_lo = d.off_dev + d.ND * SD_SIZE;
+  d.off_obs_hi = d.off_obs_lo + d.SDIM + KMAX;
+  d.n_double = d.off_obs_hi + d.SDIM + KMAX;
+  const double inf = std::numeric_limits<double>::infinity();
+  P.hd.assign(d.n_double, 0.0);
+  P.hd[SF_BASE] = n.base_mva; P.hd[SF_DT] = n.delta_t; P.hd[SF_LAMB] = n.lamb;
+  P.hd[SF_C1] = inf; P.hd[SF_C2] = inf; P.hd[SF_RTERM] = -inf;
+  P.hd[SF_Y00_RE] = Y[0].real(); P.hd[SF_Y00_IM] = Y[0].imag();
+  P.hd[SF_SLACK_VMIN] = n.bus_vmin[0]; P.hd[SF_SLACK_VMAX] = n.bus_vmax[0];
+  for (int k = 0; k < d.SDIM + KMAX; ++k) { P.hd[d.off_obs_lo + k] = -inf; P.hd[d.off_obs_hi + k] = inf; }
+  auto D = [&](int f, int l) -> double& { return P.hd[d.off_lane + size_t(f) * G + l]; };
+  for (int l = 0; l + 1 < NB; ++l) {
+    const int b = l + 1;
+    D(DF_YII_RE, l) = Y[b * NB + b].real(); D(DF_YII_IM, l) = Y[b * NB + b].imag();
+    D(DF_VMIN, l) = n.bus_vmin[b]; D(DF_VMAX, l) = n.bus_vmax[b];
+  }
+  for (int br = 0; br < d.NBR; ++br) {
+    const int f = n.br_from[br], t = n.br_to[br];
+    const cplx ys(n.br_series[2 * br], n.br_series[2 * br + 1]), sh(n.br_shunt[2 * br], n.br_shunt[2 * br + 1]);
+    const cplx tap(n.br_tap[2 * br], n.br_tap[2 * br + 1]);
+    D(DF_YFT_RE, br) = Y[f * NB + t].real(); D(DF_YFT_IM, br) = Y[f * NB + t].imag();
+    D(DF_YTF_RE, br) = Y[t * NB + f].real(); D(DF_YTF_IM, br) = Y[t * NB + f].imag();
+    const cplx c4[4] = {(ys + sh) / (std::abs(tap) * std::abs(tap)), -ys / std::conj(tap), ys + sh, -ys / tap};
+    for (int j = 0; j < 4; ++j) { D(DF_BRC + 2 * j, br) = c4[j].real(); D(DF_BRC + 2 * j + 1, br) = c4[j].imag(); }
+    D(DF_BRC + 8, br) = n.br_rate[br];
+  }
+  for (int k = 0; k < d.ND; ++k) pack_device(n, k, &P.hd[d.off_dev + k * SD_SIZE]);
+
+  // ---- LDS layout of one environment
+  d.l_v = 0;
+  d.l_bw = d.l_v + 2 * NB;
+  d.l_blk = d.l_bw + 4 * d.NBR;
+  d.l_r = d.l_blk + 4 * d.NBLK;
+  d.l_x = d.l_r + 2 * NB;
+  d.l_dev = d.l_x + 2 * NB;
+  d.lds_per_env = (d.l_dev + 2 * d.ND + 1) | 1;
+  if (size_t(64 / G) * d.lds_per_env * 8 + size_t(d.off_fill - d.off_task + d.n_fill) * 4 > 60 * 1024) {
+    err = "network too large for the general lane-group kernel (LDS)";
+    return false;
+  }
+  return true;
+}
+
+#if defined(__HIPCC__)
+
+#define ANM_MESH_SYNC() ANM_WAVE_SYNC()
+
+template <class JT>
+__global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0, radial::IO io,
+                                             SolverOpts so, int64_t n_env, ClassSel cls) {
+  extern __shared__ double sh_dyn[];
+  const int t = threadIdx.x;
+  const int G = d.G;
+  const int l = t & (G - 1);
+  const int per_wave = 64 / G;
+  const int grp = t / G;
+  const int64_t e = int64_t(blockIdx.x) * per_wave + grp;
+  const bool env_ok = e < n_env;
+  const int64_t ee = env_ok ? e : 0;
+  const double* __restrict__ rd = rd0;
+  if (cls.env_class) {
+    const int64_t first = int64_t(blockIdx.x) * per_wave;
+    rd = rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[first < n_env ? first : 0])) * cls.stride;
+  }
+  double* S = sh_dyn + grp * d.lds_per_env;                 // this environment's LDS
+  int* tab = reinterpret_cast<int*>(sh_dyn + per_wave * d.lds_per_env);   // task ranges, lists, fill ids (shared)
+  const int n_tab = d.off_fill + d.n_fill - d.off_task;
+  for (int k = t; k < n_tab; k += 64) tab[k] = ri[d.off_task + k];
+  ANM_MESH_SYNC();
+  const int* task_beg = tab;
+  const int* task_end = tab + d.n_levels * G;
+  const int* lists = tab + (d.off_lists - d.off_task);
+  const int* fills = tab + (d.off_fill - d.off_task);
+  auto RI = [&](int f) { return ri[f * G + l]; };
+  auto RD = [&](int f) { return rd[d.off_lane + f * G + l]; };
+  cptr_t C = (cptr_t)rd;
+  const double base = rd[SF_BASE], dt = rd[SF_DT];
+
+  const bool isbus = l < d.NB - 1;
+  const bool isbr = l < d.NBR;
+  const int bus = l + 1;
+  const int level = RI(IF_LEVEL), diag = RI(IF_DIAG);
+  const int inc_beg = RI(IF_INC_BEG), inc_end = RI(IF_INC_END);
+  const int up_beg = RI(IF_UP_BEG), up_end = RI(IF_UP_END);
+  const int br_f = RI(IF_BR_F), br_t = RI(IF_BR_T), blk_ft = RI(IF_BR_BLK_FT), blk_tf = RI(IF_BR_BLK_TF);
+  const int typ = RI(IF_DEV_TYPE), slot = RI(IF_DEV_SLOT), sset = RI(IF_DEV_SET);
+  const int mode = io.mode;
+  const int K = io.e.K;
+  const int SD_ = d.SDIM + K;
+
+  // ---------------- inputs per device lane (as anm_radial.hpp) ----------------------------------
+  bool skip = false, resetting = false, sampled = false;
+  int aux = 0;
+  double in_p = 0.0, in_q = 0.0, in_pot = 0.0, soc = 0.0, s0_q = 0.0, soc_req = 0.0;
+  if (mode == 0) {
+    if (typ == DEV_LOAD) in_p = io.t.p_load[ee * d.NLOAD + slot];
+    else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
+      in_pot = io.t.p_pot[ee * d.NGEN + slot];
+      in_p = io.t.p_set[ee * d.NSET + sset];
+      in_q = io.t.q_set[ee * d.NSET + sset];
+    } else if (typ == DEV_STORAGE) {
+      in_p = io.t.p_set[ee * d.NSET + sset];
+      in_q = io.t.q_set[ee * d.NSET + sset];
+      soc = io.t.soc[ee * d.NDES + slot];
+    }
+  } else {
+    const bool was_term = (mode == 2) && io.e.terminated[ee] != 0;
+    const bool series = io.e.exo == nullptr;
+    resetting = (mode == 1) || (was_term && io.e.autoreset && series);
+    skip = (mode == 2) && was_term && !resetting;
+    if (mode == 1 && io.e.mask && !io.e.mask[ee]) skip = true;
+    double s0_p = 0.0, s0_pm = 0.0;
+    sampled = resetting && !(mode == 1 && io.e.init_state);
+    if (mode == 1 && io.e.init_state) {
+      const double* s0 = io.e.init_state + ee * SD_;
+      if (typ != DEV_NONE) { s0_p = s0[l]; s0_q = s0[d.ND + l]; }
+      if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) s0_pm = s0[2 * d.ND + d.NDES + slot];
+      if (typ == DEV_STORAGE) soc_req = s0[2 * d.ND + slot];
+    } else if (resetting) {
+      const uint32_t epoch = uint32_t(io.e.reset_count[ee]);
+      uint32_t r[4];
+      Philox::generate(io.e.rng_seed, io.e.env_offset + uint64_t(ee), epoch, 0u, r);
+      aux = int((uint64_t(r[0]) * uint64_t(io.e.period)) >> 32);
+      cptr_t sd = C + d.off_dev + l * SD_SIZE;
+      if (typ == DEV_LOAD) s0_p = io.e.series[slot * io.e.period + aux];
+      else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
+        const int u = slot;
+        uint32_t qd[4];
+        Philox::generate(io.e.rng_seed, io.e.env_offset + uint64_t(ee), epoch, 1u + u / 2, qd);
+        const double uu = Philox::u01(qd[2 * (u % 2)], qd[2 * (u % 2) + 1]);
+        s0_p = s0_pm = io.e.series[(d.NLOAD + slot) * io.e.period + aux];
+        s0_q = sd[SD_QMIN] + (sd[SD_QMAX] - sd[SD_QMIN]) * uu;
+      } else if (typ == DEV_STORAGE) {
+        const int u = d.NGEN + slot;
+        uint32_t qd[4];
+        Philox::generate(io.e.rng_seed, io.e.env_offset + uint64_t(ee), epoch, 1u + u / 2, qd);
+        const double uu = Philox::u01(qd[2 * (u % 2)], qd[2 * (u % 2) + 1]);
+        soc_req = sd[SD_SOC_MIN] + (sd[SD_SOC_MAX] - sd[SD_SOC_MIN]) * uu;
+      }
+    }
+    if (resetting) {
+      in_p = s0_p; in_q = s0_q; in_pot = s0_pm;
+      if (typ == DEV_STORAGE) {
+        cptr_t sd = C + d.off_dev + l * SD_SIZE;
+        soc = (s0_p <= 0.0) ? sd[SD_SOC_MIN] : sd[SD_SOC_MAX];  // simulator.py:273-278
+      }
+    } else if (!skip) {
+      const double* a = io.e.action + ee * (2 * (d.NGEN + d.NDES));
+      if (series) {
+        const double av = io.e.state[ee * SD_ + d.SDIM];
+        aux = int(fmod(av + 1.0, double(io.e.period)));
+        if (typ == DEV_LOAD) in_p = io.e.series[slot * io.e.period + aux];
+        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.series[(d.NLOAD + slot) * io.e.period + aux];
+      } else {
+        if (typ == DEV_LOAD) in_p = io.e.exo[ee * (d.NLOAD + d.NGEN) + slot];
+        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.exo[ee * (d.NLOAD + d.NGEN) + d.NLOAD + slot];
+      }
+      if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) { in_p = a[slot]; in_q = a[d.NGEN + slot]; }
+      else if (typ == DEV_STORAGE) {
+        in_p = a[2 * d.NGEN + slot];
+        in_q = a[2 * d.NGEN + d.NDES + slot];
+        soc = io.e.soc[ee * d.NDES + slot];
+      }
+    }
+  }
+
+  // ---------------- device maps (lane = device), bus injection sums (lane = bus) ------------------
+  double dev_p = 0.0, dev_q = 0.0, p_pot = 0.0;
+  {
+    cptr_t sd = C + d.off_dev + l * SD_SIZE;
+    if (typ == DEV_LOAD) {
+      const double p = fmin(fmax(in_p / base, sd[0]), sd[1]);
+      dev_p = p;
+      dev_q = p * sd[2];
+    } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
+      p_pot = fmin(fmax(in_pot / base, sd[SD_PMIN]), sd[SD_PMAX]);
+      project_pq<2>(sd, in_p / base, in_q / base, sd[SD_PMIN], fmin(sd[SD_PMAX], p_pot), dev_p, dev_q);
+    } else if (typ == DEV_STORAGE) {
+      const double eff = sd[SD_EFF];
+      const double s_lo = (soc - sd[SD_SOC_MAX]) / (dt * eff);
+      const double s_hi = eff * (soc - sd[SD_SOC_MIN]) / dt;
+      project_pq<4>(sd, in_p / base, in_q / base, fmax(sd[SD_PMIN], s_lo), fmin(sd[SD_PMAX], s_hi), dev_p, dev_q);
+      const double ns = (dev_p <= 0.0) ? (soc - dt * eff * dev_p) : (soc - dt * dev_p / eff);
+      soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
+    }
+  }
+  double* Ldev = S + d.l_dev;
+  if (l < d.ND) { Ldev[l] = dev_p; Ldev[d.ND + l] = dev_q; }
+  ANM_MESH_SYNC();
+  double bus_p = 0.0, bus_q = 0.0;
+  if (isbus)
+    for (int k = RI(IF_BD_BEG); k < RI(IF_BD_END); ++k) {
+      const int dd = lists[k];
+      bus_p += Ldev[dd];
+      bus_q += Ldev[d.ND + dd];
+    }
+
+  // ---------------- Newton-Raphson ---------------------------------------------------------------
+  double* LV = S + d.l_v;       // vr[NB], vi[NB]
+  double* LBW = S + d.l_bw;     // wft_r, wft_i, wtf_r, wtf_i [NBR] each
+  double* LBLK = S + d.l_blk;   // [NBLK][4]
+  double* LR = S + d.l_r;       // r0[NB], r1[NB]
+  double* LX = S + d.l_x;       // x0[NB], x1[NB]
+  const int NB = d.NB, NBR = d.NBR;
+  const double yii_r = RD(DF_YII_RE), yii_i = RD(DF_YII_IM);
+  const double yft_r = RD(DF_YFT_RE), yft_i = RD(DF_YFT_IM), ytf_r = RD(DF_YTF_RE), ytf_i = RD(DF_YTF_IM);
+  double vm = 1.0, cs = 1.0, sn = 0.0, vr = 1.0, vi = 0.0;
+  int it = 0;
+  double diff = 0.0;
+  bool active = true;
+  if (l == 0) { LV[0] = 1.0; LV[NB] = 0.0; }   // slack bus: V_0 = 1
+  auto put_blk = [&](int b, double a, double bb, double c, double dd) {
+    double* p = LBLK + 4 * b;
+    p[0] = a; p[1] = bb; p[2] = c; p[3] = dd;
+  };
+  for (;;) {
+    vr = vm * cs;
+    vi = vm * sn;
+    if (isbus) { LV[bus] = vr; LV[NB + bus] = vi; }
+    ANM_MESH_SYNC();
+    // ---- branch lanes: W_ft = V_f conj(Y_ft V_t), W_tf = V_t conj(Y_tf V_f) and the two off-diagonal blocks
+    if (isbr) {
+      const double vfr = LV[br_f], vfi = LV[NB + br_f], vtr = LV[br_t], vti = LV[NB + br_t];
+      const double pr = fma(vfr, vtr, vfi * vti), pim = fma(vfi, vtr, -(vfr * vti));   // P = V_f conj(V_t)
+      const double wft_r = fma(yft_r, pr, yft_i * pim), wft_i = fma(yft_r, pim, -(yft_i * pr));
+      const double wtf_r = fma(ytf_r, pr, -(ytf_i * pim)), wtf_i = -fma(ytf_r, pim, ytf_i * pr);
+      LBW[l] = wft_r; LBW[NBR + l] = wft_i; LBW[2 * NBR + l] = wtf_r; LBW[3 * NBR + l] = wtf_i;
+      if (blk_ft >= 0) {
+        put_blk(blk_ft, wft_i, wft_r, -wft_r, wft_i);
+        put_blk(blk_tf, wtf_i, wtf_r, -wtf_r, wtf_i);
+      }
+    }
+    for (int k = l; k < d.n_fill; k += G) put_blk(fills[k], 0.0, 0.0, 0.0, 0.0);
+    ANM_MESH_SYNC();
+    // ---- bus lanes: S_i = W_ii + sum over the incident branches, mismatch, diagonal block
+    const double m2 = vm * vm;
+    const double wii_r = yii_r * m2, wii_i = -(yii_i * m2);
+    double sr = wii_r, si = wii_i;
+    for (int k = inc_beg; k < inc_end; ++k) {
+      const int code = lists[k];
+      const int br = code >> 1, side = code & 1;
+      sr += LBW[(2 * side) * NBR + br];
+      si += LBW[(2 * side + 1) * NBR + br];
+    }
+    const double fr = sr - bus_p, fi = si - bus_q;
+    double a = isbus ? fmax(fabs(fr), fabs(fi)) : 0.0;
+    double nanf = (isbus && (fr != fr || fi != fi)) ? 1.0 : 0.0;
+    for (int m = 1; m < G; m <<= 1) {
+      a = fmax(a, __shfl_xor(a, m, G));
+      nanf = fmax(nanf, __shfl_xor(nanf, m, G));
+    }
+    const double nd = (nanf > 0.0) ? NAN : a;
+    if (it == 0) diff = nd;
+    else if (active) diff = nd;
+    active = (diff > so.tol) && (it < so.max_iter);
+    if (!__any(active && env_ok && !skip)) break;
+    JT r0 = JT(fr), r1 = JT(fi);
+    if (isbus) put_blk(diag, -(si - wii_i), sr + wii_r, sr - wii_r, si + wii_i);
+    ANM_MESH_SYNC();
+    // ---- elimination, level by level
+    for (int lv = 0; lv < d.n_levels; ++lv) {
+      if (isbus && level == lv) {   // pivots of this level: invert the diagonal block, publish the right-hand side
+        double* p = LBLK + 4 * diag;
+        const Blk<JT> Di = blk_inv(Blk<JT>{JT(p[0]), JT(p[1]), JT(p[2]), JT(p[3])});
+        p[0] = double(Di.a); p[1] = double(Di.b); p[2] = double(Di.c); p[3] = double(Di.d);
+        LR[bus] = double(r0); LR[NB + bus] = double(r1);
+      }
+      ANM_MESH_SYNC();
+      for (int q = task_beg[lv * G + l]; q < task_end[lv * G + l];) {
+        const int k = lists[q], dk = lists[q + 1], bik = lists[q + 2], nu = lists[q + 3];
+        q += 4;
+        const double* pd = LBLK + 4 * dk;
+        const double* pl = LBLK + 4 * bik;
+        const Blk<JT> Lik = blk_mul(Blk<JT>{JT(pl[0]), JT(pl[1]), JT(pl[2]), JT(pl[3])},
+                                    Blk<JT>{JT(pd[0]), JT(pd[1]), JT(pd[2]), JT(pd[3])});
+        const JT rk0 = JT(LR[k]), rk1 = JT(LR[NB + k]);
+        r0 = fm(-Lik.b, rk1, fm(-Lik.a, rk0, r0));
+        r1 = fm(-Lik.d, rk1, fm(-Lik.c, rk0, r1));
+        for (int u = 0; u < nu; ++u, q += 2) {
+          double* pz = LBLK + 4 * lists[q];
+          const double* ps = LBLK + 4 * lists[q + 1];
+          Blk<JT> Z = Blk<JT>{JT(pz[0]), JT(pz[1]), JT(pz[2]), JT(pz[3])};
+          blk_submul(Z, Lik, Blk<JT>{JT(ps[0]), JT(ps[1]), JT(ps[2]), JT(ps[3])});
+          pz[0] = double(Z.a); pz[1] = double(Z.b); pz[2] = double(Z.c); pz[3] = double(Z.d);
+        }
+      }
+      ANM_MESH_SYNC();
+    }
+    // ---- back substitution, last level first
+    JT d0 = JT(0), d1 = JT(0);
+    for (int lv = d.n_levels - 1; lv >= 0; --lv) {
+      if (isbus && level == lv) {
+        JT a0 = r0, a1 = r1;
+        for (int q = up_beg; q < up_end; q += 2) {
+          const int j = lists[q];
+          const double* pu = LBLK + 4 * lists[q + 1];
+          const JT x0 = JT(LX[j]), x1 = JT(LX[NB + j]);
+          a0 = fm(-JT(pu[1]), x1, fm(-JT(pu[0]), x0, a0));
+          a1 = fm(-JT(pu[3]), x1, fm(-JT(pu[2]), x0, a1));
+        }
+        const double* p = LBLK + 4 * diag;
+        d0 = fm(JT(p[0]), a0, JT(p[1]) * a1);
+        d1 = fm(JT(p[2]), a0, JT(p[3]) * a1);
+        LX[bus] = double(d0); LX[NB + bus] = double(d1);
+      }
+      ANM_MESH_SYNC();
+    }
+    // ---- update (group-uniform `active`); d1 is the relative magnitude step
+    if (active && isbus) {
+      const double dth = double(d0);
+      vm = fma(-double(d1), fabs(vm), vm);
+      double sd_, cd_;
+      if (fabs(dth) <= 0.78) {
+        sincos_kernel(dth, 0, sd_, cd_);
+      } else if (fabs(dth) < 4.0e15) {
+        sincos_medium(dth, sd_, cd_);
+      } else {
+        const SinCos r = sincos_huge(dth);
+        sd_ = r.s; cd_ = r.c;
+      }
+      const double c0 = cs, s0v = sn;
+      cs = fma(c0, cd_, s0v * sd_);
+      sn = fma(s0v, cd_, -(c0 * sd_));
+    }
+    it = active ? it + 1 : it;
+  }
+  const bool f_nan = (diff != diff);
+  const bool converged = !f_nan && (diff <= so.tol);
+
+  // ---------------- currents, slack injection, branch flows, reward -------------------------------
+  // (LV holds the final V: the loop left through its break right after publishing it)
+  ANM_MESH_SYNC();
+  // branch lanes: the two terms of I = Y V their branch contributes, Y_ft V_t (to bus f) and Y_tf V_f (to bus t)
+  double vfr = 1.0, vfi = 0.0, vtr = 1.0, vti = 0.0;
+  if (isbr) {
+    vfr = LV[br_f]; vfi = LV[NB + br_f]; vtr = LV[br_t]; vti = LV[NB + br_t];
+    LBW[l] = fma(yft_r, vtr, -(yft_i * vti)); LBW[NBR + l] = fma(yft_r, vti, yft_i * vtr);
+    LBW[2 * NBR + l] = fma(ytf_r, vfr, -(ytf_i * vfi)); LBW[3 * NBR + l] = fma(ytf_r, vfi, ytf_i * vfr);
+  }
+  ANM_MESH_SYNC();
+  double ir = fma(yii_r, vr, -(yii_i * vi)), ii = fma(yii_r, vi, yii_i * vr);
+  for (int k = inc_beg; k < inc_end; ++k) {
+    const int code = lists[k];
+    const int br = code >> 1, side = code & 1;
+    ir += LBW[(2 * side) * NBR + br];
+    ii += LBW[(2 * side + 1) * NBR + br];
+  }
+  // I_0 = Y_00 + sum over the branches at the slack bus (fixed butterfly order)
+  double s0r = 0.0, s0i = 0.0;
+  if (isbr && br_f == 0) { s0r = LBW[l]; s0i = LBW[NBR + l]; }
+  if (isbr && br_t == 0) { s0r = LBW[2 * NBR + l]; s0i = LBW[3 * NBR + l]; }
+  for (int m = 1; m < G; m <<= 1) {
+    s0r += __shfl_xor(s0r, m, G);
+    s0i += __shfl_xor(s0i, m, G);
+  }
+  const double i0r = rd[SF_Y00_RE] + s0r, i0i = rd[SF_Y00_IM] + s0i;
+  const double slack_p = (i0r != i0r) ? INFINITY : i0r;
+  const double slack_q = (i0i != i0i) ? INFINITY : -i0i;
+  if (typ == DEV_SLACK) { dev_p = slack_p; dev_q = slack_q; }
+
+  double br_pf = 0, br_qf = 0, br_s = 0, br_ifr = 0, br_ifi = 0, pen = 0.0;
+  if (isbr) {
+    const double c0 = RD(DF_BRC + 0), c1 = RD(DF_BRC + 1), c2 = RD(DF_BRC + 2), c3 = RD(DF_BRC + 3);
+    const double c4 = RD(DF_BRC + 4), c5 = RD(DF_BRC + 5), c6 = RD(DF_BRC + 6), c7 = RD(DF_BRC + 7);
+    br_ifr = c0 * vfr - c1 * vfi + c2 * vtr - c3 * vti;
+    br_ifi = c0 * vfi + c1 * vfr + c2 * vti + c3 * vtr;
+    const double itr = c4 * vtr - c5 * vti + c6 * vfr - c7 * vfi;
+    const double iti = c4 * vti + c5 * vtr + c6 * vfi + c7 * vfr;
+    br_pf = vfr * br_ifr + vfi * br_ifi;
+    br_qf = vfi * br_ifr - vfr * br_ifi;
+    const double pt = vtr * itr + vti * iti, qt = vti * itr - vtr * iti;
+    const double sf2 = br_pf * br_pf + br_qf * br_qf, st2 = pt * pt + qt * qt;
+    const double sgn = (br_pf > 0.0) ? 1.0 : ((br_pf < 0.0) ? -1.0 : ((br_pf == 0.0) ? 0.0 : NAN));
+    const double smax = (sf2 != sf2 || st2 != st2) ? NAN : sqrt(fmax(sf2, st2));
+    br_s = sgn * smax;
+    const double over = fabs(br_s) - RD(DF_BRC + 8);
+    pen += (over != over) ? NAN : fmax(0.0, over);
+  }
+  if (isbus) {
+    const double vmag = fabs(vm);
+    const double hi = vmag - RD(DF_VMAX), lo = RD(DF_VMIN) - vmag;
+    pen += (vmag != vmag) ? NAN : (fmax(0.0, hi) + fmax(0.0, lo));
+  }
+  if (l == 0) pen += fmax(0.0, 1.0 - rd[SF_SLACK_VMAX]) + fmax(0.0, rd[SF_SLACK_VMIN] - 1.0);
+  double el = 0.0;
+  if (typ != DEV_NONE && typ != DEV_STORAGE) el += dev_p;
+  if (typ == DEV_RENEWABLE) {
+    const double curt = p_pot - dev_p;
+    el += (curt != curt) ? NAN : fmax(0.0, curt);
+  }
+  for (int m = 1; m < G; m <<= 1) {
+    pen += __shfl_xor(pen, m, G);
+    el += __shfl_xor(el, m, G);
+  }
+  const double e_loss = el * dt, penalty = pen * (dt * rd[SF_LAMB]);
+  const double reward = -(e_loss + penalty);
+
+  if (!env_ok) return;
+
+  // ---------------- outputs (as anm_radial.hpp; branch quantities come from the branch lanes) ------
+  double* full = (mode == 0) ? io.t.full : io.e.full;
+  auto write_full = [&]() {
+    if (!full) return;
+    double* f = full + e * d.FS;
+    if (isbus) {
+      f[d.f_bus_p + bus] = bus_p; f[d.f_bus_q + bus] = bus_q;
+      f[d.f_bus_vm + bus] = hypot(vr, vi); f[d.f_bus_va + bus] = atan2(vi, vr);
+      f[d.f_bus_im + bus] = hypot(ir, ii); f[d.f_bus_ia + bus] = atan2(ii, ir);
+    }
+    if (isbr) {
+      f[d.f_br_p + l] = br_pf; f[d.f_br_q + l] = br_qf; f[d.f_br_s + l] = br_s;
+      const double mag = hypot(br_ifr, br_ifi);
+      f[d.f_br_im + l] = (mag == 0.0) ? 0.0 : (br_ifr / mag) * mag;
+      f[d.f_br_ia + l] = atan2(br_ifi, br_ifr);
+    }
+    if (l == 0) {
+      f[d.f_bus_p] = slack_p; f[d.f_bus_q] = slack_q; f[d.f_bus_vm] = 1.0; f[d.f_bus_va] = 0.0;
+      f[d.f_bus_im] = hypot(i0r, i0i); f[d.f_bus_ia] = atan2(i0i, i0r);
+    }
+    if (typ != DEV_NONE) { f[d.f_dev_p + l] = dev_p; f[d.f_dev_q + l] = dev_q; }
+    if (typ == DEV_STORAGE) f[d.f_des_soc + slot] = soc;
+    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) f[d.f_gen_pmax + slot] = p_pot;
+  };
+
+  if (mode == 0) {
+    if (typ == DEV_STORAGE) io.t.soc[e * d.NDES + slot] = soc;
+    if (l == 0) {
+      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
+      io.t.converged[e] = converged ? 1 : 0;
+      if (io.t.nr_iters) io.t.nr_iters[e] = it;
+    }
+    write_full();
+    return;
+  }
+
+  double* state = io.e.state + e * SD_;
+  double* obs = io.e.obs + e * SD_;
+  cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
+  auto put = [&](int k, double v) {
+    state[k] = v;
+    obs[k] = fmin(fmax(v, lo[k]), hi[k]);
+  };
+  if (skip) {
+    if (mode == 2) {  // absorbing terminal state
+      for (int k = l; k < SD_; k += G) obs[k] = 0.0;
+      if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
+    }
+    return;
+  }
+  if (l == 0 && io.e.nr_iters) io.e.nr_iters[e] = it;
+  if (resetting) {
+    if (typ == DEV_STORAGE) {
+      soc = soc_req / base;  // simulator.py:284-288
+      io.e.soc[e * d.NDES + slot] = soc;
+    }
+    if (mode == 2 && !converged) {
+      for (int k = l; k < SD_; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+    } else {
+      if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
+      if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
+      if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) put(2 * d.ND + d.NDES + slot, p_pot * base);
+    }
+    if (mode == 1) {
+      if (sampled) {
+        if (l == 0) { put(d.SDIM, double(aux)); io.e.reset_count[e] += 1; }
+      } else {
+        const double* s0 = io.e.init_state + e * SD_;
+        for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
+      }
+      if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
+    } else {
+      if (l == 0) {
+        if (converged) put(d.SDIM, double(aux));
+        io.e.reset_count[e] += 1;
+        io.e.terminated[e] = converged ? 0 : 1;
+        if (io.e.timestep) io.e.timestep[e] = 0;
+        io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
+      }
+    }
+    write_full();
+    return;
+  }
+  if (typ == DEV_STORAGE) io.e.soc[e * d.NDES + slot] = soc;
+  const bool term = !converged;
+  if (!term) {
+    if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
+    if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
+    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) put(2 * d.ND + d.NDES + slot, p_pot * base);
+    if (io.e.exo == nullptr) {
+      if (l == 0) put(d.SDIM, double(aux));
+    } else {
+      for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * K + k]);
+    }
+  } else {
+    for (int k = l; k < SD_; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+  }
+  if (l == 0) {
+    const double c1 = rd[SF_C1], c2 = rd[SF_C2];
+    io.e.terminated[e] = term ? 1 : 0;
+    if (!term) {
+      const double sg2 = (e_loss > 0.0) ? 1.0 : ((e_loss < 0.0) ? -1.0 : 0.0);
+      const double elc = sg2 * fmin(fabs(e_loss), c1);
+      const double pn = fmin(fmax(penalty, 0.0), c2);
+      io.e.e_loss[e] = elc; io.e.penalty[e] = pn; io.e.reward[e] = -(elc + pn);
+    } else {
+      io.e.reward[e] = rd[SF_RTERM]; io.e.e_loss[e] = c1; io.e.penalty[e] = c2;
+    }
+    if (io.e.timestep) io.e.timestep[e] += 1;
+  }
+  write_full();
+}
+#endif  // __HIPCC__
+
+}  // namespace mesh
+}  // namespace anm

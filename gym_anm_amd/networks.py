@@ -165,3 +165,23 @@ def perturbed_network(net: dict, seed: int, rel=0.2) -> dict:
         if row[14] is not None:
             row[14] = float(min(1.0, float(row[14]) * rng.uniform(0.9, 1.05)))
     return out
+
+
+def synthetic_meshed_network(n_bus: int, seed: int, n_chords: int) -> dict:
+    """The random feeder of :func:`synthetic_radial_network` plus ``n_chords`` extra branches that close
+    loops, with line charging; the first chord is an off-nominal transformer with a phase shift.  Exercises
+    fill-in of the block LU, asymmetric admittance entries and both ends of every branch."""
+    net = synthetic_radial_network(n_bus, seed)
+    rng = np.random.default_rng(1000 + seed)
+    have = {(int(min(f, t)), int(max(f, t))) for f, t in net["branch"][:, :2]}
+    extra = []
+    while len(extra) < n_chords:
+        f, t = sorted(int(x) for x in rng.choice(np.arange(1, n_bus), size=2, replace=False))
+        if (f, t) in have:
+            continue
+        have.add((f, t))
+        tap, shift = (1.0, 0.0) if extra else (0.97, 3.0)
+        extra.append([f, t, float(rng.uniform(0.005, 0.03)), float(rng.uniform(0.03, 0.08)), float(rng.uniform(0, 0.02)),
+                      30.0, tap, shift])  # fmt: skip
+    net["branch"] = np.vstack([net["branch"], np.array(extra)])
+    return net

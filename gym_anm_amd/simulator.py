@@ -111,10 +111,10 @@ class BatchedSimulator:
         desc, self._keep = _lib.network_desc(m)
         with self._device_ctx():
             self.backend.check(self.backend.lib.anm_model_create(C.byref(desc), C.byref(self._handle)), "anm_model_create")
-        if impl is not None:  # "thread" (one thread per env) | "radial" (lane group per env); None = library default
-            code = {"thread": _lib.IMPL_THREAD, "radial": _lib.IMPL_RADIAL}[impl]
+        if impl is not None:  # "thread" (one thread per env) | "radial" / "mesh" (lane group per env: trees / any topology)
+            code = {"thread": _lib.IMPL_THREAD, "radial": _lib.IMPL_RADIAL, "mesh": _lib.IMPL_MESH}[impl]
             self.backend.check(self.backend.lib.anm_model_set_impl(self._handle, code), "anm_model_set_impl")
-        self.impl = {0: "thread", 1: "radial"}[self.backend.lib.anm_model_get_impl(self._handle)]
+        self.impl = {0: "thread", 1: "radial", 2: "mesh"}[self.backend.lib.anm_model_get_impl(self._handle)]
         # per-environment heterogeneous networks (the reference builds one Simulator per network): `variants`
         # are networks with the topology of `network` and other numbers, env_variant[e] in [0, len(variants)]
         # picks the network of environment e (0 = `network`), constant over aligned blocks of 64 environments

@@ -113,6 +113,12 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg);
  * The environment variable ANM_IMPL=thread|radial overrides the default at model creation. */
 #define ANM_IMPL_THREAD 0
 #define ANM_IMPL_RADIAL 1
+/*   ANM_IMPL_MESH    the same lane-group mapping for ANY topology (loops, several feeders off the slack): the
+ *                    2x2-block Jacobian lives in LDS and is eliminated level by level with the static
+ *                    minimum-degree order computed at anm_model_create; networks up to 65 buses / 64 branches /
+ *                    64 devices (default for non-radial networks above 12 buses, and for non-radial networks
+ *                    no library was compiled for). */
+#define ANM_IMPL_MESH 2
 int anm_model_set_impl(anm_model* m, int32_t impl);
 int anm_model_get_impl(const anm_model* m);
 

@@ -225,3 +225,72 @@ def test_parameter_classes_must_cover_aligned_blocks():
         BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.perturbed_network(base, 1)], env_variant=ev)
     with pytest.raises(errors.UnsupportedNetworkError):
         BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.two_bus_network()])
+
+
+# ---------------------------------------------------------------------------------------------------
+# the general lane-group family ("mesh"): any topology, block-sparse Jacobian in LDS
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(pc.golden_nets()))
+def test_mesh_transition_golden(name):
+    """Every golden network -- the tree ones and the 3-bus loop with its ten transformer variants -- through
+    the general lane-group kernel: flags and iteration counts exact, electrical state <= 1e-9."""
+    sim = pc.check_transition_against_golden(name, pc.golden_nets()[name], DEV, impl="mesh")
+    assert sim.impl == "mesh"
+
+
+def test_mesh_anm6easy_episodes():
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    env = pc.run_episodes(lambda n: ANM6EasyVec(num_envs=n, device=DEV, impl="mesh"))
+    assert env.simulator.impl == "mesh"
+
+
+@pytest.mark.parametrize("n_bus,seed,n_chords", [(5, 2, 2), (9, 4, 3), (14, 5, 3), (30, 6, 4), (30, 7, 8), (48, 8, 6), (64, 9, 1)])
+def test_mesh_random_meshed_networks_against_oracle(n_bus, seed, n_chords):
+    """Random meshed networks (loops, line charging, a phase-shifting transformer) nobody compiled a library
+    for: generic mode of the general lane-group kernel against the oracle, case by case."""
+    import anm_oracle as O
+    from gym_anm_amd import networks
+    from gym_anm_amd.model import NetworkModel
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords)
+    model = NetworkModel(net, 0.25, 100)
+    M = 96
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl="mesh" if n_bus <= 12 else None)
+    assert sim.impl == "mesh"
+    npt.assert_allclose(sim.device_ybus(), model.Y_bus, rtol=1e-15, atol=0)
+    rng = np.random.default_rng(seed)
+    b = model.baseMVA
+
+    def U(lo, hi, scale=1.0):
+        lo, hi = np.asarray(lo, float) * scale, np.asarray(hi, float) * scale
+        return lo + (hi - lo) * rng.uniform(size=(M, lo.size))
+
+    pl = U(model.dev_p_min[model.load_idx], 0 * model.dev_p_min[model.load_idx], 0.6 * b)
+    pp = U(0 * model.dev_p_max[model.gen_idx], model.dev_p_max[model.gen_idx], b)
+    ps = U(model.dev_p_min[model.setp_idx], model.dev_p_max[model.setp_idx], 1.2 * b)
+    qs = U(model.dev_q_min[model.setp_idx], model.dev_q_max[model.setp_idx], 1.2 * b)
+    soc = U(model.dev_soc_min[model.des_idx], model.dev_soc_max[model.des_idx])
+    pl[-4:] *= 40.0  # a few hopeless cases: both sides must give up the same way
+    sim.soc.copy_(torch.as_tensor(soc))
+    sim.transition(pl, pp, ps, qs)
+    full, sl = sim.full.cpu().numpy(), pc.full_slices(sim)
+    n = O.parse_network(net, 0.25, 100)
+    n_conv = 0
+    for e in range(M):
+        ref = O.transition(n, pl[e], pp[e], ps[e], qs[e], soc[e], tol=1e-8, sparse=False)
+        assert bool(sim.pfe_converged[e]) == bool(ref["converged"]), e
+        npt.assert_allclose(sim.soc[e].cpu().numpy(), ref["soc_after"], rtol=0, atol=1e-12)
+        if not ref["converged"]:
+            continue
+        n_conv += 1
+        assert int(sim.nr_iters[e]) == ref["n_iter"], e
+        npt.assert_allclose(full[e, sl["bus_v_magn"]], np.abs(ref["V"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["bus_v_ang"]], np.angle(ref["V"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["bus_i_magn"]], np.abs(ref["I"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["dev_p"]], ref["dev_p"], rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["branch_p"]], ref["br_p_from"], rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["branch_s"]], ref["br_s"], rtol=0, atol=1e-9)
+        npt.assert_allclose(float(sim.reward[e]), ref["reward"], rtol=1e-9, atol=1e-9)
+    assert n_conv >= M // 2

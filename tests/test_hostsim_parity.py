@@ -114,25 +114,9 @@ def test_numpy_vector_env_adapter():
 
 
 def _meshed_network(n_bus, seed, n_chords):
-    """Random feeder of `synthetic_radial_network` plus `n_chords` extra branches (loops), one of them an
-    off-nominal transformer with a phase shift: exercises fill-in of the block LU, asymmetric Y entries
-    and the pairing of the (i,k)/(k,i) products."""
     from gym_anm_amd import networks
 
-    net = networks.synthetic_radial_network(n_bus, seed)
-    rng = np.random.default_rng(1000 + seed)
-    have = {(int(min(f, t)), int(max(f, t))) for f, t in net["branch"][:, :2]}
-    extra = []
-    while len(extra) < n_chords:
-        f, t = sorted(int(x) for x in rng.choice(np.arange(1, n_bus), size=2, replace=False))
-        if (f, t) in have:
-            continue
-        have.add((f, t))
-        tap, shift = (1.0, 0.0) if extra else (0.97, 3.0)
-        extra.append([f, t, float(rng.uniform(0.005, 0.03)), float(rng.uniform(0.03, 0.08)), float(rng.uniform(0, 0.02)),
-                      30.0, tap, shift])  # fmt: skip
-    net["branch"] = np.vstack([net["branch"], np.array(extra)])
-    return net
+    return networks.synthetic_meshed_network(n_bus, seed, n_chords)
 
 
 @pytest.mark.parametrize("n_bus,seed,n_chords", [(4, 1, 1), (5, 2, 2), (7, 3, 2), (9, 4, 3)])
