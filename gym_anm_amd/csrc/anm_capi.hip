@@ -134,6 +134,7 @@ struct anm_model {
   std::vector<std::vector<double>> x_hd;      // lane-group tables of each extra class
   const int32_t* d_env_class = nullptr;       // caller's device array [num_envs] (anm_model_bind_env_classes)
   uint8_t* d_state_same = nullptr;            // caller's device array [num_envs] (anm_model_bind_state_same)
+  int32_t* d_zero = nullptr;                  // one zero: the class of every environment when no classes are bound
   std::vector<cplx> ybus;
 };
 
@@ -166,9 +167,8 @@ int upload_const(anm_model* m) {
 }
 
 ClassSel class_sel(const anm_model* m, bool radial) {
-  ClassSel cs{m->d_env_class, 0};
-  if (cs.env_class) cs.stride = radial ? int(m->plan.hd.size()) : int(m->h_const.size());
-  return cs;
+  if (!m->d_env_class) return ClassSel{m->d_zero, 0, 0};
+  return ClassSel{m->d_env_class, radial ? int(m->plan.hd.size()) : int(m->h_const.size()), 1};
 }
 
 int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
@@ -176,8 +176,7 @@ int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const rad
   const int per_wave = 64 / d.G;
   const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
   const size_t lds = size_t(per_wave) * d.lds_per_env * sizeof(double) + size_t(d.off_fill + d.n_fill - d.off_task) * sizeof(int);
-  ClassSel cs{m->d_env_class, 0};
-  if (cs.env_class) cs.stride = int(m->mplan.hd.size());
+  const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1} : ClassSel{m->d_zero, 0, 0};
   if (precision == ANM_SOLVE_F32)
     hipLaunchKernelGGL(mesh::k_mesh<float>, dim3(grid), dim3(64), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   else
@@ -308,6 +307,8 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
     }
   }
   int rc = upload_const(m);
+  if (rc == 0 && (hipMalloc(&m->d_zero, sizeof(int32_t)) != hipSuccess || hipMemset(m->d_zero, 0, sizeof(int32_t)) != hipSuccess))
+    rc = fail("hipMalloc(class selector)");
   if (rc) {
     anm_model_destroy(m);
     return rc;
@@ -324,6 +325,7 @@ void anm_model_destroy(anm_model* m) {
   if (m->d_rd) hipFree(m->d_rd);
   if (m->d_mi) hipFree(m->d_mi);
   if (m->d_md) hipFree(m->d_md);
+  if (m->d_zero) hipFree(m->d_zero);
   if (m->d_obs_index) hipFree(m->d_obs_index);
   if (m->d_obs_tab) hipFree(m->d_obs_tab);
   delete m;
@@ -816,9 +818,9 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
   const int S = Topo::SDIM + io.K;
   size_t doubles = size_t(GenLds<Topo>::G_MIN);
   doubles = std::max(doubles, size_t(64) * size_t(Dims<Topo>::ADIM + 1));
-  doubles = std::max(doubles, size_t(64) * size_t(S | 1));
   if (GenLds<Topo>::FULL_OK && (io.n_obs > 0 || io.full)) doubles = std::max(doubles, size_t(64) * size_t(io.row_stride));
-  const size_t lds_bytes = doubles * sizeof(double);
+  io.state_row_off = int(doubles);               // the state rows follow the buffer the other uses overlay
+  const size_t lds_bytes = (doubles + size_t(64) * size_t(S | 1)) * sizeof(double);
   if (prec == ANM_SOLVE_F32)
     hipLaunchKernelGGL(k_step_general<float>, dim3(grid_for(n)), dim3(BLOCK), lds_bytes, s, C, io, so, n, class_sel(m, false));
   else

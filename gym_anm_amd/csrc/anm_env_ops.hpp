@@ -16,13 +16,15 @@ namespace anm {
 // the class of environment e and is constant over every aligned block of 64 environments, so the constants
 // of a wavefront stay ONE wave-uniform buffer read through scalar loads -- parameter classes cost nothing.
 struct ClassSel {
-  const int32_t* env_class;  // null: one class
+  const int32_t* env_class;  // never null: without classes it points at one zero and `per_env` is 0
   int stride;
+  int per_env;               // 1: index env_class by the environment, 0: always entry 0
 };
 #if defined(__HIPCC__)
+// (branch-free on purpose: a conditional here keeps the selector alive in scalar registers through the whole
+// kernel, and the step kernel has none to spare -- measured: 80 bytes of scratch)
 __device__ __forceinline__ cptr_t class_constants(cptr_t C, const ClassSel& cs, int64_t first_env) {
-  if (!cs.env_class) return C;
-  const int k = __builtin_amdgcn_readfirstlane(cs.env_class[first_env]);
+  const int k = __builtin_amdgcn_readfirstlane(cs.env_class[first_env * cs.per_env]);
   return C + int64_t(k) * cs.stride;
 }
 #endif
@@ -41,14 +43,18 @@ struct Dims {
 };
 
 // state vector (anm_env.py:139-147): [dev_p MW, dev_q MVAr, des_soc MWh, gen_p_max MW, aux(K)]
-template <class T>
-ANM_HD void write_state_obs(cptr_t C, const EnvWork<T>& w, double* state, double* obs) {
+// `out`: where the state / observation entries go -- anything with put_st(k, v) / put_ob(k, v) (register
+// arrays: StepOut; rows in memory: RowPtrs; an LDS row: op_step_general).  Setters, not references: a
+// reference that may point at LDS or at a local is a generic pointer, and a local whose address becomes a
+// generic pointer lives in scratch.
+template <class T, class Out>
+ANM_HD void write_state_obs(cptr_t C, const EnvWork<T>& w, Out& out) {
   typedef Layout<T> L;
   const double base = C[L::SCALARS + SC_BASE];
   auto put = [&](int k, double v) {
-    state[k] = v;
+    out.put_st(k, v);
     // np.clip(obs, low, high)
-    obs[k] = fmin(fmax(v, C[L::OBS_LO + k]), C[L::OBS_HI + k]);
+    out.put_ob(k, fmin(fmax(v, C[L::OBS_LO + k]), C[L::OBS_HI + k]));
   };
   static_for<0, T::ND>([&](auto Di) {
     constexpr int d = Di;
@@ -58,6 +64,14 @@ ANM_HD void write_state_obs(cptr_t C, const EnvWork<T>& w, double* state, double
   static_for<0, T::NDES>([&](auto E) { put(2 * T::ND + E, w.soc[E] * base); });
   static_for<0, T::NGEN>([&](auto G) { put(2 * T::ND + T::NDES + G, w.p_pot[G] * base); });
 }
+
+// state / obs rows in memory
+struct RowPtrs {
+  double* state;
+  double* obs;
+  ANM_HD void put_st(int k, double v) { state[k] = v; }
+  ANM_HD void put_ob(int k, double v) { obs[k] = v; }
+};
 
 struct TransitionIO {
   const double* p_load;
@@ -128,6 +142,7 @@ struct EnvIO {
   unsigned state_magic;     // ceil(2^32 / (SDIM + K))
   unsigned obs_need;        // FullClass bits the list reads
   int row_stride;           // doubles per LDS row of the electrical state (odd)
+  int state_row_off;        // op_step_general: where the state rows start in its LDS buffer (doubles)
   int aux_off;              // where the aux variables sit in such a row
   short cls_off[FC_COUNT];  // where each class sits in such a row (compact: only the classes the list reads)
   const int32_t* obs_index; // indices into such a row
@@ -140,8 +155,9 @@ struct EnvIO {
 };
 
 // Split an init_state row (anm_env.py / simulator.py:248-268) into transition inputs.
-template <class T>
-ANM_HD void inputs_from_init_state(cptr_t C, const double* s0, EnvWork<T>& w,
+// (S0: anything indexable -- a row in memory or a register array with constant indices)
+template <class T, class S0>
+ANM_HD void inputs_from_init_state(cptr_t C, const S0& s0, EnvWork<T>& w,
                                    double (&P_load)[T::NLOAD > 0 ? T::NLOAD : 1],
                                    double (&P_pot)[T::NGEN > 0 ? T::NGEN : 1],
                                    double (&P_set)[T::NSET > 0 ? T::NSET : 1],
@@ -167,23 +183,22 @@ ANM_HD void inputs_from_init_state(cptr_t C, const double* s0, EnvWork<T>& w,
 }
 
 // Tail of Simulator.reset / ANMEnv.reset: SoC overwritten with the requested one, state & obs built.
-template <class T, int KCAP = Layout<T>::KMAX>
-ANM_HD void finish_reset(cptr_t C, EnvWork<T>& w, const double* s0, int K, double* soc, double* state,
-                         double* obs) {
+template <class T, int KCAP = Layout<T>::KMAX, class S0 = const double*, class Out = RowPtrs>
+ANM_HD void finish_reset(cptr_t C, EnvWork<T>& w, const S0& s0, int K, double* soc, Out& out) {
   typedef Layout<T> L;
   const double base = C[L::SCALARS + SC_BASE];
   static_for<0, T::NDES>([&](auto E) {
     w.soc[E] = s0[2 * T::ND + E] / base;  // simulator.py:284-288
     soc[E] = w.soc[E];
   });
-  write_state_obs<T>(C, w, state, obs);
+  write_state_obs<T>(C, w, out);
   // constant indices + predicate (not a runtime-indexed loop): callers keep these rows in registers
   static_for<0, KCAP>([&](auto Kc) {
     constexpr int k = Kc;
     if (k < K) {
       const double a = s0[T::SDIM + k];
-      state[T::SDIM + k] = a;
-      obs[T::SDIM + k] = fmin(fmax(a, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]);
+      out.put_st(T::SDIM + k, a);
+      out.put_ob(T::SDIM + k, fmin(fmax(a, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]));
     }
   });
 }
@@ -228,28 +243,35 @@ ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32
   return aux;
 }
 
-template <class T, class JT>
-ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
-  if (io.mask && !io.mask[e]) return;
+template <class T, class JT, class S0>
+ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const S0& s0) {
   const int S = T::SDIM + io.K;
   EnvWork<T> w;
   double P_load[T::NLOAD > 0 ? T::NLOAD : 1], P_pot[T::NGEN > 0 ? T::NGEN : 1];
   double P_set[T::NSET > 0 ? T::NSET : 1], Q_set[T::NSET > 0 ? T::NSET : 1];
-  double s0_drawn[T::SDIM + 1];
-  const double* s0 = io.init_state ? io.init_state + e * S : s0_drawn;
-  if (!io.init_state) {  // device sampler (series mode, K = 1): same draws as the autoreset path
-    sample_series_init_state<T>(C, io, e, uint32_t(io.reset_count[e]), s0_drawn);
-    io.reset_count[e] += 1;
-  }
   inputs_from_init_state<T>(C, s0, w, P_load, P_pot, P_set, Q_set);
   transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
-  finish_reset<T>(C, w, s0, io.K, io.soc + e * T::NDES, io.state + e * S, io.obs + e * S);
+  RowPtrs rows{io.state + e * S, io.obs + e * S};
+  finish_reset<T, Layout<T>::KMAX, S0>(C, w, s0, io.K, io.soc + e * T::NDES, rows);
   io.converged[e] = w.converged ? 1 : 0;
   io.terminated[e] = 0;
   if (io.timestep) io.timestep[e] = 0;
   if (io.nr_iters) io.nr_iters[e] = w.n_iter;
   if (io.aux_index && io.K == 1) io.aux_index[e] = int32_t(s0[T::SDIM]);
   if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+}
+
+template <class T, class JT>
+ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
+  if (io.mask && !io.mask[e]) return;
+  if (io.init_state) {  // the row given by the caller
+    reset_from<T, JT>(C, io, so, e, io.init_state + e * (T::SDIM + io.K));
+  } else {              // device sampler (series mode, K = 1): same draws as the autoreset path, kept in registers
+    double s0_drawn[T::SDIM + 1];
+    sample_series_init_state<T>(C, io, e, uint32_t(io.reset_count[e]), s0_drawn);
+    io.reset_count[e] += 1;
+    reset_from<T, JT>(C, io, so, e, s0_drawn);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -267,9 +289,9 @@ struct StepIn {
   int reset_count;
 };
 
-template <class T, int KCAP = Layout<T>::KMAX>  // KCAP: compile-time cap on the number of aux variables
-struct StepOut {
-  double state[T::SDIM + KCAP], obs[T::SDIM + KCAP];
+// what a step decides besides the state / observation rows
+template <class T>
+struct StepFlags {
   bool write_state, write_obs;     // absorbing terminal state: only the (zero) observation is written
   double reward, e_loss, penalty;
   bool write_costs;                // e_loss / penalty are left untouched in the absorbing state
@@ -280,6 +302,14 @@ struct StepOut {
   bool write_soc;
   bool inc_reset;
   int aux;
+};
+
+template <class T, int KCAP = Layout<T>::KMAX>  // KCAP: compile-time cap on the number of aux variables
+struct StepOut : StepFlags<T> {      // ... with the rows in registers
+  static constexpr int CAP = KCAP;
+  double state[T::SDIM + KCAP], obs[T::SDIM + KCAP];
+  ANM_HD void put_st(int k, double v) { state[k] = v; }
+  ANM_HD void put_ob(int k, double v) { obs[k] = v; }
 };
 
 // what step_end needs to know about how the step started
@@ -346,9 +376,9 @@ ANM_HD void step_begin(cptr_t C, CD Cd, const EnvIO& io, SolverOpts so, int64_t 
 // second half: solution -> flows, reward, clipping, terminal handling, state and observation rows
 // DO_TRANSITION_END = false: the caller has already run transition_end (it reads the electrical state in
 // between, see op_step_general)
-template <class T, int KCAP, bool DO_TRANSITION_END = true>
+template <class T, int KCAP, bool DO_TRANSITION_END = true, class Out = StepOut<T, KCAP>>
 ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const StepCtx<T>& ctx, EnvWork<T>& w,
-                     const PFState<T>& st, StepOut<T, KCAP>& out) {
+                     const PFState<T>& st, Out& out) {
   typedef Layout<T> L;
   const bool series = io.exo == nullptr;
   out.write_state = out.write_obs = out.write_costs = out.write_soc = out.inc_reset = false;
@@ -358,7 +388,7 @@ ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const 
   out.aux = ctx.aux;
   out.reward = out.e_loss = out.penalty = 0.0;
   if (ctx.absorbing) {  // absorbing terminal state (anm_env.py:365-367)
-    static_for<0, T::SDIM + KCAP>([&](auto Kc) { out.obs[Kc] = 0.0; });
+    static_for<0, T::SDIM + KCAP>([&](auto Kc) { out.put_ob(Kc, 0.0); });
     out.write_obs = true;
     return;
   }
@@ -372,13 +402,13 @@ ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const 
     double s0[T::SDIM + 1];
     static_for<0, T::NDES>([&](auto I) { s0[2 * T::ND + I] = ctx.soc_req[I]; });
     s0[T::SDIM] = double(ctx.aux);
-    finish_reset<T, 1>(C, w, s0, 1, out.soc, out.state, out.obs);
+    finish_reset<T, 1>(C, w, s0, 1, out.soc, out);
     out.inc_reset = true;
     out.terminated = w.converged ? 0 : 1;  // not converged: try another draw at the next call
     if (!w.converged) {  // ... and look exactly like the absorbing terminal state until then
       static_for<0, T::SDIM + 1>([&](auto Kc) {
-        out.state[Kc] = 0.0;
-        out.obs[Kc] = 0.0;
+        out.put_st(Kc, 0.0);
+        out.put_ob(Kc, 0.0);
       });
     }
     out.timestep_op = 1;
@@ -399,27 +429,27 @@ ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const 
     out.e_loss = el;
     out.penalty = pn;
     out.reward = -(el + pn);
-    write_state_obs<T>(C, w, out.state, out.obs);
+    write_state_obs<T>(C, w, out);
     if (series) {
-      out.state[T::SDIM] = double(ctx.aux);
-      out.obs[T::SDIM] = fmin(fmax(double(ctx.aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]);
+      out.put_st(T::SDIM, double(ctx.aux));
+      out.put_ob(T::SDIM, fmin(fmax(double(ctx.aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]));
     } else {
-      static_for<0, KCAP>([&](auto Kc) {
-        constexpr int k = Kc;
-        if (k < io.K) {
-          const double v = io.aux_next[e * io.K + k];
-          out.state[T::SDIM + k] = v;
-          out.obs[T::SDIM + k] = fmin(fmax(v, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]);
-        }
-      });
+      if (io.K > 0) {
+        static_for<0, KCAP>([&](auto Kc) {  // unconditional stores, see finish_reset
+          constexpr int k = Kc;
+          const double v = io.aux_next[e * io.K + (k < io.K ? k : 0)];
+          out.put_st(T::SDIM + k, v);
+          out.put_ob(T::SDIM + k, fmin(fmax(v, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]));
+        });
+      }
     }
   } else {
     out.reward = C[L::SCALARS + SC_RTERM];  // -c2 / (1 - gamma)
     out.e_loss = c1;
     out.penalty = c2;
     static_for<0, T::SDIM + KCAP>([&](auto Kc) {
-      out.state[Kc] = 0.0;
-      out.obs[Kc] = 0.0;
+      out.put_st(Kc, 0.0);
+      out.put_ob(Kc, 0.0);
     });
   }
   out.timestep_op = 2;
@@ -437,7 +467,7 @@ ANM_HD void step_compute(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, co
 
 // everything of StepOut except the state / obs rows
 template <class T, int KCAP>
-ANM_HD void store_step_scalars(const EnvIO& io, int64_t e, const StepOut<T, KCAP>& o, bool have_ts = false,
+ANM_HD void store_step_scalars(const EnvIO& io, int64_t e, const StepFlags<T>& o, bool have_ts = false,
                                int32_t ts_prev = 0) {  // have_ts: the caller already read timestep[e]
   if (o.write_soc) static_for<0, T::NDES>([&](auto I) { io.soc[e * T::NDES + I] = o.soc[I]; });
   if (o.terminated >= 0) io.terminated[e] = uint8_t(o.terminated);
@@ -766,12 +796,22 @@ __device__ void op_step_general(cptr_t C, const EnvIO& io, SolverOpts so, int64_
       dumped = true;
     }
   }
-  StepOut<T, KM> out;
-  step_end<T, KM, false>(C, io, so, ec, ctx, w, st, out);
+  // the state row of this environment is built directly in LDS (behind the electrical-state rows)
+  const int SPr = S | 1;
+  double* ldsS = lds + io.state_row_off;
+  struct RowOut : StepFlags<T> {
+    double* row;
+    int width;   // entries beyond the row (aux slots above K) are dropped: the next lane's row starts there
+    __device__ __forceinline__ void put_st(int k, double v) { if (k < width) row[k] = v; }
+    __device__ __forceinline__ void put_ob(int, double) {}   // formed from the state row when it is stored
+  } out;
+  out.row = ldsS + lane * SPr;
+  out.width = S;
+  step_end<T, KM, false, RowOut>(C, io, so, ec, ctx, w, st, out);
   const bool store = valid;
   if (store) {
     store_step_scalars<T, KM>(io, e, out, true, ts_prev);
-    if (io.aux_index && out.write_state) io.aux_index[e] = int32_t(out.state[T::SDIM]);
+    if (io.aux_index && out.write_state) io.aux_index[e] = int32_t(out.row[T::SDIM]);
   }
   const bool zero_obs = ctx.absorbing || out.terminated == 1;   // anm_env.py:365-367, 442-446
   const unsigned long long zero_rows = __ballot(zero_obs);
@@ -781,9 +821,7 @@ __device__ void op_step_general(cptr_t C, const EnvIO& io, SolverOpts so, int64_
   if constexpr (G::FULL_OK) {
     if (dumped) {
       double* row = ldsA + lane * RS;
-      static_for<0, KM>([&](auto Kc) {   // the aux variables sit behind the electrical state
-        if (Kc < K) row[io.aux_off + Kc] = out.state[T::SDIM + Kc];
-      });
+      for (int k = 0; k < K; ++k) row[io.aux_off + k] = out.row[T::SDIM + k];   // aux variables: behind the electrical state
       ANM_WAVE_SYNC();
       if (list) {  // obs[e0 + r, k] for flat index idx = r * n_obs + k: coalesced stores, LDS gathers
         const int total = rows * io.n_obs;
@@ -809,23 +847,24 @@ __device__ void op_step_general(cptr_t C, const EnvIO& io, SolverOpts so, int64_
   } else {
     if (io.full && out.write_state && store) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
   }
-  // ---- state rows, then (state observation) obs rows: through LDS region B, coalesced
-  const int SPr = S | 1;
-  auto store_rows = [&](double* gbase, const double* vals, unsigned long long mask) {
-    ANM_WAVE_SYNC();
-    static_for<0, T::SDIM + KM>([&](auto Kc) {
-      if (Kc < S) ldsB[lane * SPr + Kc] = vals[Kc];
-    });
-    ANM_WAVE_SYNC();
+  // ---- state rows through LDS, coalesced; the "state" observation is clip(state, Box) of the same rows
+  // (zeros for terminal rows, anm_env.py:365-367, 442-446), formed while they are stored
+  ANM_WAVE_SYNC();
+  {
     const int total = rows * S;
+    double* gstate = io.state + e0 * S;
+    double* gobs = io.obs + e0 * S;
     for (int idx = lane; idx < total; idx += 64) {
       const int r = int(__umulhi(unsigned(idx), io.state_magic));
       const int k = idx - r * S;
-      if ((mask >> r) & 1ull) gbase[idx] = ldsB[r * SPr + k];
+      const double v = ldsS[r * SPr + k];
+      if ((state_rows >> r) & 1ull) gstate[idx] = v;
+      if (!list && ((obs_rows >> r) & 1ull)) {
+        const double c = fmin(fmax(v, C[L::OBS_LO + k]), C[L::OBS_HI + k]);
+        gobs[idx] = ((zero_rows >> r) & 1ull) ? 0.0 : c;
+      }
     }
-  };
-  store_rows(io.state + e0 * S, out.state, state_rows);
-  if (!list) store_rows(io.obs + e0 * S, out.obs, obs_rows);
+  }
 }
 
 // second launch of the two-phase step: continue the handed-over solves (grid-stride over records)

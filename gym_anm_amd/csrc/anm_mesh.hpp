@@ -278,11 +278,9 @@ __global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri,
   const int64_t e = int64_t(blockIdx.x) * per_wave + grp;
   const bool env_ok = e < n_env;
   const int64_t ee = env_ok ? e : 0;
-  const double* __restrict__ rd = rd0;
-  if (cls.env_class) {
-    const int64_t first = int64_t(blockIdx.x) * per_wave;
-    rd = rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[first < n_env ? first : 0])) * cls.stride;
-  }
+  const int64_t first_env = int64_t(blockIdx.x) * per_wave;
+  const double* __restrict__ rd =
+      rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
   double* S = sh_dyn + grp * d.lds_per_env;                 // this environment's LDS
   int* tab = reinterpret_cast<int*>(sh_dyn + per_wave * d.lds_per_env);   // task ranges, lists, fill ids (shared)
   const int n_tab = d.off_fill + d.n_fill - d.off_task;

@@ -251,11 +251,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
                                               SolverOpts so, int64_t n_env, ClassSel cls) {
   constexpr bool USE_T = !std::is_void<TT>::value;
   // parameter class of this wavefront's environments (uniform over aligned blocks of 64 environments)
-  const double* __restrict__ rd = rd0;
-  if (cls.env_class) {
-    const int64_t first = int64_t(blockIdx.x) * (64 / d.G);
-    rd = rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[first < n_env ? first : 0])) * cls.stride;
-  }
+  const int64_t first_env = int64_t(blockIdx.x) * (64 / d.G);
+  const double* __restrict__ rd =
+      rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
   __shared__ double sh[A_N][64];
   __shared__ int sh_lists[256];  // children / bus-device index lists (read every Newton iteration)
   const int t = threadIdx.x;
