@@ -208,12 +208,13 @@ class BatchedANMEnv(GymEnv):
         self._ws = None
         self._ws_ref = None
         if straggler_after == "auto":
-            # measured on MI355X (scripts/two_phase_sweep.py, straggler_after_sweep.py): the hand-over pays once
-            # the batch exceeds the 65 536 lanes of the chip -- from 131 072 environments with the reference's
-            # cap of 100 iterations (1.4x there, 2.3x at 1 M), from ~512 K with a cap of 20 -- and costs 20 %
-            # below; the best hand-over point moves from 9 iterations (131 072) to 6 (>= 262 144)
-            big = 131072 if int(max_iter) >= 50 else 524288
-            straggler_after = (9 if self.num_envs < 262144 else 6) if self.num_envs >= big else None
+            # measured on MI355X (scripts/handoff_sweep.py, profiles/r02_*): up to 262 144 environments the in-wave
+            # lane-group hand-over (anm_solver_opts.handoff_after) is the faster cure for stragglers (65 536:
+            # 94 vs 169 us, 262 144: 189 vs 204 us); the two-launch step -- stragglers of the whole batch packed
+            # densely into a second launch -- wins once the batch is several times the 65 536 lanes of the chip
+            # (1 M: 328 vs 495 us with the reference's cap; a tie with a cap of 20)
+            big = 524288 if int(max_iter) >= 50 else 1048576
+            straggler_after = 6 if self.num_envs >= big else None
         rec = sim.backend.lib.anm_step_ws_record_doubles()
         if self._aux_index is not None and straggler_after and rec > 0 and int(straggler_after) < int(max_iter):
             n_rec = min(self.num_envs, 1 << 18)
