@@ -94,6 +94,7 @@ ABI = {
     "anm_model_bind_state_same": (C.c_int, [C.c_void_p, _P]),
     "anm_model_obs_fusable": (C.c_int, [C.c_void_p]),
     "anm_model_set_obs": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p]),
+    "anm_admm_update_f64": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_double] + [_P] * 9 + [_P]),
     "anm_gather_obs_f64": (C.c_int, [C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P,
                                      _P]),
     "anm_time_step_launches": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 9 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,

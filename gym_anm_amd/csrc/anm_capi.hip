@@ -102,6 +102,35 @@ __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__
   }
 }
 
+// ADMM step of the batched DC-OPF (gym_anm_amd/agents/mpc.py: BatchedADMM.solve), everything that is not a GEMM,
+// fused: relaxation, projection on [l, u], dual update and the right-hand side w = rho z - y of the next
+// linear solve, for every (environment, constraint) pair; the first n columns of each row do the x relaxation
+__global__ void k_admm_update(int64_t E, int n, int m, double alpha, const double* __restrict__ xt,
+                              const double* __restrict__ zt, const double* __restrict__ l, const double* __restrict__ u,
+                              const double* __restrict__ rv, double* __restrict__ x, double* __restrict__ z,
+                              double* __restrict__ y, double* __restrict__ xw) {
+  const int64_t total = E * int64_t(n + m);
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t e = t / (n + m);
+    const int k = int(t - e * (n + m));
+    if (k < n) {
+      const double xn = fma(alpha, xt[e * n + k], (1.0 - alpha) * x[e * n + k]);
+      x[e * n + k] = xn;
+      xw[t] = xn;                       // [x | w] is the left operand of the next GEMM
+    } else {
+      const int j = k - n;
+      const int64_t i = e * m + j;
+      const double r = rv[j];
+      const double zh = fma(alpha, zt[i], (1.0 - alpha) * z[i]);
+      const double zn = fmin(fmax(zh + y[i] / r, l[i]), u[i]);
+      const double yn = fma(r, zh - zn, y[i]);
+      z[i] = zn;
+      y[i] = yn;
+      xw[t] = fma(r, zn, -yn);
+    }
+  }
+}
+
 }  // namespace
 
 struct anm_model {
@@ -871,6 +900,20 @@ int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double
   if (rc) return rc;
   if (e != hipSuccess) return fail_hip(e, "event timing");
   *ms_per_launch = ms / float(n_launch);
+  return 0;
+}
+
+int anm_admm_update_f64(int64_t num_envs, int32_t n, int32_t m, double alpha, const double* xt, const double* zt,
+                        const double* l, const double* u, const double* rho, double* x, double* z, double* y, double* xw,
+                        void* stream) {
+  if (!xt || !zt || !l || !u || !rho || !x || !z || !y || !xw) return fail("anm_admm_update_f64: null argument");
+  if (num_envs <= 0 || n <= 0 || m <= 0) return 0;
+  const int64_t total = num_envs * int64_t(n + m);
+  const unsigned grid = unsigned(std::min<int64_t>((total + 255) / 256, 8192));
+  hipLaunchKernelGGL(k_admm_update, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), num_envs, n, m, alpha, xt,
+                     zt, l, u, rho, x, z, y, xw);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_admm_update");
   return 0;
 }
 

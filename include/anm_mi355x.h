@@ -251,6 +251,16 @@ int anm_model_obs_fusable(const anm_model* m);
 int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const double* scale, const double* low,
                       const double* high);
 
+/* One ADMM iteration of the batched MPC DC-OPF policy (gym_anm/agents/mpc.py:163-372 solved for all
+ * environments together, gym_anm_amd/agents/mpc.py), the part that is not a GEMM: with xt [E, n] and zt [E, m]
+ * the results of the two products of the iteration,
+ *   x <- alpha xt + (1 - alpha) x;   zh = alpha zt + (1 - alpha) z;   z <- clip(zh + y / rho, l, u);
+ *   y <- y + rho (zh - z);           xw[e] <- [x[e], rho z[e] - y[e]]   (left operand of the next product)
+ * l, u, z, y: [E, m]; rho: [m]; x: [E, n]; xw: [E, n + m].  All dev. */
+int anm_admm_update_f64(int64_t num_envs, int32_t n, int32_t m, double alpha, const double* xt, const double* zt,
+                        const double* l, const double* u, const double* rho, double* x, double* z, double* y, double* xw,
+                        void* stream);
+
 /* Offsets of each quantity inside one row of `full` (p.u. / rad), in the order of the reference's
  * STATE_VARIABLES (constants.py:31-48): bus_p, bus_q, bus_v_magn, bus_v_ang, bus_i_magn,
  * bus_i_ang [n_bus each], dev_p, dev_q [n_dev each], des_soc [n_des], gen_p_max [n_gen],

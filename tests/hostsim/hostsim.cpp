@@ -161,6 +161,24 @@ int anm_model_set_classes(anm_model*, int32_t n_classes, const anm_network_desc*
 int anm_model_bind_env_classes(anm_model*, const int32_t* env_class, int64_t) {
   return env_class ? fail("the host test double has no parameter classes") : 0;
 }
+int anm_admm_update_f64(int64_t E, int32_t n, int32_t m, double alpha, const double* xt, const double* zt, const double* l,
+                        const double* u, const double* rv, double* x, double* z, double* y, double* xw, void*) {
+  for (int64_t e = 0; e < E; ++e) {
+    for (int k = 0; k < n; ++k) {
+      x[e * n + k] = alpha * xt[e * n + k] + (1.0 - alpha) * x[e * n + k];
+      xw[e * (n + m) + k] = x[e * n + k];
+    }
+    for (int j = 0; j < m; ++j) {
+      const int64_t i = e * m + j;
+      const double zh = alpha * zt[i] + (1.0 - alpha) * z[i];
+      const double zn = std::fmin(std::fmax(zh + y[i] / rv[j], l[i]), u[i]);
+      y[i] += rv[j] * (zh - zn);
+      z[i] = zn;
+      xw[e * (n + m) + n + j] = rv[j] * zn - y[i];
+    }
+  }
+  return 0;
+}
 int anm_model_bind_state_same(anm_model*, uint8_t* p) { return p ? fail("the host test double writes every state row") : 0; }
 int anm_model_obs_fusable(const anm_model*) { return 0; }  // the test double has no fused gather
 int anm_model_set_obs(anm_model*, int32_t n_obs, const int32_t*, const double*, const double*, const double*) {
