@@ -127,26 +127,45 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   std::vector<char> done(NB, 0);
   std::vector<int> order, level(NB, 0);
   std::vector<std::vector<int>> upper(NB);
-  for (int step = 1; step < NB; ++step) {
-    int best = -1, best_deg = 1 << 30;
-    for (int u = NB - 1; u >= 1; --u) {
+  // Order: rounds of pairwise non-adjacent pivots of (near-)minimal degree -- the parallel tree contraction
+  // ("rake" the leaves, "compress" every other bus of a chain) generalised by the degree rule.  Plain minimum
+  // degree peels a feeder from its ends, one level per bus of its longest chain; with independent sets the
+  // number of LEVELS, which is what the level-synchronous kernel pays for, grows like log(n) for feeders.
+  for (int n_done = 0; n_done < NB - 1;) {
+    int dmin = 1 << 30;
+    std::vector<int> deg(NB, 0);
+    for (int u = 1; u < NB; ++u) {
       if (done[u]) continue;
-      int deg = 0;
-      for (int v : work[u]) deg += !done[v];
-      if (deg < best_deg) { best_deg = deg; best = u; }
+      for (int v : work[u]) deg[u] += !done[v];
+      dmin = std::min(dmin, deg[u]);
     }
-    const int k = best;
-    done[k] = 1;
-    order.push_back(k);
-    std::vector<int> nb;
-    for (int v : work[k]) if (!done[v]) nb.push_back(v);
-    upper[k] = nb;
-    for (int i : nb)
-      for (int j : nb) {
-        if (blk[i][j] < 0) { blk[i][j] = nblk++; fill_ids.push_back(blk[i][j]); }
-        if (i != j) work[i].insert(j);
-      }
-    for (int i : nb) level[i] = std::max(level[i], level[k] + 1);
+    const int dcut = std::max(dmin, 2);   // chains (degree 2) are compressed together with the leaves
+    std::vector<int> cand;
+    for (int u = NB - 1; u >= 1; --u)
+      if (!done[u] && deg[u] <= dcut) cand.push_back(u);
+    std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+    std::vector<char> blocked(NB, 0);
+    std::vector<int> round;
+    for (int u : cand) {
+      if (blocked[u]) continue;
+      round.push_back(u);
+      blocked[u] = 1;
+      for (int v : work[u]) blocked[v] = 1;
+    }
+    for (int k : round) {
+      done[k] = 1;
+      ++n_done;
+      order.push_back(k);
+      std::vector<int> nb;
+      for (int v : work[k]) if (!done[v]) nb.push_back(v);
+      upper[k] = nb;
+      for (int i : nb)
+        for (int j : nb) {
+          if (blk[i][j] < 0) { blk[i][j] = nblk++; fill_ids.push_back(blk[i][j]); }
+          if (i != j) work[i].insert(j);
+        }
+      for (int i : nb) level[i] = std::max(level[i], level[k] + 1);
+    }
   }
   d.NBLK = nblk;
   d.n_fill = int(fill_ids.size());
