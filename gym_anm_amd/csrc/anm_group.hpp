@@ -138,6 +138,19 @@ struct Shape {
   static constexpr int NG = 64 / G;       // environments per wavefront
 };
 
+// 2x2 inverse with ONE Newton step on v_rcp_f64 (measured on MI355X: rcp 24.4 bits, one step 48.7 bits = 2.2e-15
+// relative, two steps 52.2 bits).  An inexact inverse perturbs a Newton STEP by that much and nothing else -- the
+// fixed point is set by F, evaluated in full precision -- so the lane-group path, which only ever serves
+// diverging solves and the rare 7- or 8-iteration ones, trades the second step for a shorter dependent chain;
+// the thread-per-environment path keeps two steps (its iterates are pinned bit for bit by round-1 tests).
+__device__ __forceinline__ Blk<double> blk_inv_fast(const Blk<double>& m) {
+  const double det = fm(m.a, m.d, -(m.b * m.c));
+  double r = __builtin_amdgcn_rcp(det);
+  r = r * fma(-det, r, 2.0);
+  return Blk<double>{m.d * r, -m.b * r, -m.c * r, m.a * r};
+}
+__device__ __forceinline__ Blk<float> blk_inv_fast(const Blk<float>& m) { return blk_inv(m); }
+
 // What a lane knows about its place in the tree (constant tables indexed by the lane: loaded once).
 template <class T>
 struct LaneView {
@@ -237,7 +250,10 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       it += __builtin_amdgcn_inverse_ballot_w64(runm) ? 1 : 0;   // the update applied in the previous trip
       runm &= __builtin_amdgcn_uicmp(tb, 0u, ICMP_NE) & ~__builtin_amdgcn_uicmp(tn, 0u, ICMP_NE) &
               __builtin_amdgcn_sicmp(it, max_iter, ICMP_SLT);   // NaN > tol is false, like the reference
-      if (runm == 0ull) break;
+      // The loop is left at the END of the trip: the scalar chain compare -> masks -> branch then overlaps the
+      // elimination instead of stalling the wavefront in front of it every trip; the price is one idle
+      // elimination when the last group stops (its update is masked: `runm` is 0).
+      const bool all_done = runm == 0ull;
 
       // ---- Jacobian blocks (anm_device.hpp: newton_update): own diagonal and the two couplings with the parent
       Blk<JT> Dg = Blk<JT>{JT(-(si - wbb_i)), JT(sr + wbb_r), JT(sr - wbb_r), JT(si + wbb_i)};
@@ -264,7 +280,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
               r0 -= g0[Cc]; r1 -= g1[Cc];
             }
           });
-          Dg = blk_inv(Dg);
+          Dg = blk_inv_fast(Dg);
           if constexpr (h < T::T_MAXH) {  // a bus of maximal height hangs off the slack: nobody folds it
             const Blk<JT> Lk = blk_mul(Jpb, Dg);
             Sc = blk_mul(Lk, Jbp);
@@ -321,6 +337,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         cs = fma(c0, cd_, s0 * sd_);
         sn = fma(s0, cd_, -(c0 * sd_));
       }
+      if (all_done) break;
     }
 
   }
