@@ -202,14 +202,20 @@ ClassSel class_sel(const anm_model* m, bool radial) {
 
 int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
   const mesh::Dims& d = m->mplan.d;
-  const int per_wave = 64 / d.G;
-  const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
-  const size_t lds = size_t(per_wave) * d.lds_per_env * sizeof(double) + size_t(d.off_fill + d.n_fill - d.off_task) * sizeof(int);
+  const int waves = mesh::waves_per_block(d);
+  const int per_block = waves * (64 / d.G);
+  const unsigned grid = unsigned((n + per_block - 1) / per_block);
+  const size_t lds = mesh::lds_bytes(d, waves);
   const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1} : ClassSel{m->d_zero, 0, 0};
+  if (lds > 64 * 1024) {   // one wavefront per workgroup and still above the default limit: ask for the CU's LDS
+    hipError_t ea = hipFuncSetAttribute(precision == ANM_SOLVE_F32 ? (const void*)mesh::k_mesh<float> : (const void*)mesh::k_mesh<double>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(k_mesh, dynamic LDS)");
+  }
   if (precision == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(mesh::k_mesh<float>, dim3(grid), dim3(64), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    hipLaunchKernelGGL(mesh::k_mesh<float>, dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   else
-    hipLaunchKernelGGL(mesh::k_mesh<double>, dim3(grid), dim3(64), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    hipLaunchKernelGGL(mesh::k_mesh<double>, dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_mesh");
   return 0;

@@ -23,6 +23,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <set>
 #include <string>
 #include <vector>
@@ -38,16 +39,36 @@ using radial::SF_BASE; using radial::SF_DT; using radial::SF_LAMB; using radial:
 using radial::SF_RTERM; using radial::SF_PERIOD; using radial::SF_Y00_RE; using radial::SF_Y00_IM;
 using radial::SF_SLACK_VMIN; using radial::SF_SLACK_VMAX; using radial::SF_COUNT;
 
-enum IField : int { IF_LEVEL = 0, IF_DIAG, IF_INC_BEG, IF_INC_END, IF_BD_BEG, IF_BD_END, IF_UP_BEG, IF_UP_END,
-                    IF_BR_F, IF_BR_T, IF_BR_BLK_FT, IF_BR_BLK_TF, IF_DEV_TYPE, IF_DEV_SLOT, IF_DEV_SET, IF_COUNT };
+enum IField : int { IF_LEVEL = 0, IF_DIAG, IF_INC_BEG, IF_INC_END, IF_BD_BEG, IF_BD_END, IF_INC0, IF_DEG,
+                    IF_BR_F, IF_BR_T, IF_BR_BLK_FT, IF_BR_BLK_TF, IF_BR_POS_F, IF_BR_POS_T, IF_DEV_TYPE, IF_DEV_SLOT,
+                    IF_DEV_SET, IF_COUNT };
+// The elimination as a PROGRAM of steps (build_plan schedules it once per network; k_mesh interprets it): in every
+// step each lane carries out at most one small operation named by its descriptor -- 8 offsets (in doubles) into
+// the environment's LDS -- and a wavefront-wide fence separates the steps.  Operations are handed to lanes
+// wherever one is free (no lane "owns" a row), so a level of the elimination costs a fixed, short sequence of
+// instructions whatever the sparsity pattern, instead of a per-lane loop over task lists.
+// The right-hand side rides along as one more block column: r_i is kept as the block (r0, 0; r1, 0).
+//   step ST_PROD  OP_PROD (i, k, j)    s1 = D_k, s2 = A_ik, s3 = A_kj (or r_k), s4 = where the product
+//                                      M = A_ik D_k^-1 A_kj goes; s5 != 0: also leave D_k^-1 at s5
+//   step ST_SUM   OP_SUM  (i, j)       s1 = A_ij (or r_i) -= the products at s2, s3, s4, s5 in this order (the step
+//                                      says how many of them any of its lanes needs; an unused one is the zero block)
+//   step ST_BACK  OP_BACK (pivot k)    s1 = r_k, s2 = D_k^-1, s3 = x_k, (s4, s5), (s6, s7) = (A_kj, x_j) of two later buses
+//                 OP_INVBACK           the same for a bus nothing was eliminated into: s2 = D_k itself
+//   step ST_ACC   OP_ACC  (pivot k)    s1 = r_k (-= A_kj x_j for (s2, s3), (s4, s5), (s6, s7)): buses with more than two
+// s0 = the operation (0: the lane idles in this step).  Nothing a step reads is written in the same step, and
+// D_k, A_ik, A_kj stay as they are (the factor L_ik = A_ik D_k^-1 is never stored: every product recomputes it,
+// lanes are plentiful), so the operations of a level may be dealt to the lanes in any number of rounds.
+enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_BACK, OP_INVBACK, OP_ACC };
+enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_BACK = 2, ST_ACC = 3 };
 enum DField : int { DF_YII_RE = 0, DF_YII_IM, DF_VMIN, DF_VMAX, DF_YFT_RE, DF_YFT_IM, DF_YTF_RE, DF_YTF_IM, DF_BRC,
                     DF_COUNT = DF_BRC + 9 };
 
 struct Dims {
   int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, n_levels, slack_dev, NBLK, n_fill;
-  int off_task, off_lists, n_lists, off_fill;              // ints: [IF_COUNT][G], task ranges [n_levels][2][G], lists, fill ids
+  int off_lists, n_lists, off_fill;                        // ints: [IF_COUNT][G], lists, fill ids (staged in LDS) ...
+  int n_steps, off_stype, off_desc, n_stage, max_deg;      // ... step types (| run length << 8) [n_steps], descriptors [n_steps][G][4]
   int off_lane, off_dev, off_obs_lo, off_obs_hi, n_double;  // doubles
-  int l_v, l_bw, l_blk, l_r, l_x, l_dev, lds_per_env;       // LDS layout of one environment (doubles)
+  int l_v, l_bw, l_blk, l_r, l_x, l_dinv, l_zero, l_m, n_m, l_dev, lds_per_env;   // LDS layout of one environment (doubles)
   int f_bus_p, f_bus_q, f_bus_vm, f_bus_va, f_bus_im, f_bus_ia, f_dev_p, f_dev_q, f_des_soc, f_gen_pmax, f_br_p,
       f_br_q, f_br_s, f_br_im, f_br_ia;
 };
@@ -57,6 +78,17 @@ struct Plan {
   std::vector<int> hi;
   std::vector<double> hd;
 };
+
+// LDS of a workgroup of `waves` wavefronts: the environments' own areas + the staged tables (shared)
+inline size_t lds_bytes(const Dims& d, int waves) {
+  return size_t(waves) * (64 / d.G) * d.lds_per_env * sizeof(double) + size_t(d.n_stage) * sizeof(int);
+}
+// wavefronts per workgroup: as many as share one copy of the program within the default 64 KB
+inline int waves_per_block(const Dims& d) {
+  int w = 4;
+  while (w > 1 && lds_bytes(d, w) > 64 * 1024) w /= 2;
+  return w;
+}
 
 inline bool fits(const anm_network_desc& n) {
   return n.n_bus >= 2 && n.n_bus - 1 <= 64 && n.n_dev <= 64 && n.n_branch <= 64;
@@ -172,6 +204,16 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   d.n_levels = 0;
   for (int i = 1; i < NB; ++i) d.n_levels = std::max(d.n_levels, level[i] + 1);
 
+  // ---- LDS layout of one environment (doubles), up to the products (their number comes with the schedule)
+  d.l_v = 0;
+  d.l_bw = d.l_v + 2 * NB;
+  d.l_blk = d.l_bw + 4 * d.NBR;
+  d.l_r = d.l_blk + 4 * d.NBLK;          // r[NB] as blocks (r0, 0; r1, 0)
+  d.l_x = d.l_r + 4 * NB;                // x[NB][2]
+  d.l_dinv = d.l_x + 2 * NB;             // inverted pivots [NB][4]
+  d.l_zero = d.l_dinv + 4 * NB;          // 6 zeros nobody writes: what an unused operand slot of a descriptor reads
+  d.l_m = d.l_zero + 6;                  // products [n_m][4]
+
   // ---- int tables
   P.hi.assign(size_t(IF_COUNT) * G, 0);
   auto I = [&](int f, int l) -> int& { return P.hi[size_t(f) * G + l]; };
@@ -180,26 +222,32 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     I(IF_BR_BLK_TF, l) = -1; I(IF_DEV_TYPE, l) = DEV_NONE; I(IF_DEV_SLOT, l) = -1; I(IF_DEV_SET, l) = -1;
   }
   std::vector<int> lists;
+  // W entries: entry e holds (re, im) of one end of one branch at LDS doubles l_bw + 2e; the entries a bus sums
+  // are consecutive, in branch order (the order the reference sums a row of Y V in); the slack ends come last
+  int n_ent = 0;
+  d.max_deg = 0;
   for (int l = 0; l + 1 < NB; ++l) {
     const int b = l + 1;
     I(IF_LEVEL, l) = level[b];
     I(IF_DIAG, l) = blk[b][b];
     I(IF_INC_BEG, l) = int(lists.size());
-    for (int br = 0; br < d.NBR; ++br) {  // branch order = the order the reference sums a row of Y V in
-      if (n.br_from[br] == b) lists.push_back(br << 1);
-      else if (n.br_to[br] == b) lists.push_back((br << 1) | 1);
+    I(IF_INC0, l) = n_ent;
+    for (int br = 0; br < d.NBR; ++br) {
+      if (n.br_from[br] == b) { lists.push_back(br << 1); I(IF_BR_POS_F, br) = n_ent++; }
+      else if (n.br_to[br] == b) { lists.push_back((br << 1) | 1); I(IF_BR_POS_T, br) = n_ent++; }
     }
     I(IF_INC_END, l) = int(lists.size());
+    I(IF_DEG, l) = n_ent - I(IF_INC0, l);
+    d.max_deg = std::max(d.max_deg, I(IF_DEG, l));
     I(IF_BD_BEG, l) = int(lists.size());
     for (int k = 0; k < d.ND; ++k)
       if (n.dev_bus[k] == b) lists.push_back(k);
     I(IF_BD_END, l) = int(lists.size());
-    I(IF_UP_BEG, l) = int(lists.size());
-    for (int j : upper[b]) { lists.push_back(j); lists.push_back(blk[b][j]); }
-    I(IF_UP_END, l) = int(lists.size());
   }
   for (int br = 0; br < d.NBR; ++br) {
     const int f = n.br_from[br], t = n.br_to[br];
+    if (f == 0) I(IF_BR_POS_F, br) = n_ent++;
+    if (t == 0) I(IF_BR_POS_T, br) = n_ent++;
     I(IF_BR_F, br) = f; I(IF_BR_T, br) = t;
     I(IF_BR_BLK_FT, br) = (f != 0 && t != 0) ? blk[f][t] : -1;
     I(IF_BR_BLK_TF, br) = (f != 0 && t != 0) ? blk[t][f] : -1;
@@ -209,31 +257,119 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     I(IF_DEV_SLOT, k) = slot[k];
     I(IF_DEV_SET, k) = sset[k];
   }
-  // tasks of lane i at level lv: for every pivot k of that level adjacent to i (i eliminated later):
-  //   [k, diag block of k, block (i,k), n, n x (destination block (i,j), source block (k,j))]
-  std::vector<int> task_beg(size_t(d.n_levels) * G, 0), task_end(size_t(d.n_levels) * G, 0);
-  std::vector<std::vector<std::vector<int>>> tasks(d.n_levels, std::vector<std::vector<int>>(G));
-  for (int k : order)
-    for (int i : upper[k]) {
-      std::vector<int>& t = tasks[level[k]][i - 1];
-      t.push_back(k); t.push_back(blk[k][k]); t.push_back(blk[i][k]); t.push_back(int(upper[k].size()));
-      for (int j : upper[k]) { t.push_back(blk[i][j]); t.push_back(blk[k][j]); }
-    }
-  for (int lv = 0; lv < d.n_levels; ++lv)
-    for (int l = 0; l < G; ++l) {
-      task_beg[size_t(lv) * G + l] = int(lists.size());
-      lists.insert(lists.end(), tasks[lv][l].begin(), tasks[lv][l].end());
-      task_end[size_t(lv) * G + l] = int(lists.size());
-    }
-  d.off_task = int(P.hi.size());
-  P.hi.insert(P.hi.end(), task_beg.begin(), task_beg.end());
-  P.hi.insert(P.hi.end(), task_end.begin(), task_end.end());
   d.off_lists = int(P.hi.size());
   d.n_lists = int(lists.size());
   P.hi.insert(P.hi.end(), lists.begin(), lists.end());
   d.off_fill = int(P.hi.size());
   P.hi.insert(P.hi.end(), fill_ids.begin(), fill_ids.end());
   P.hi.push_back(0);
+
+  // ---- the step program
+  typedef std::array<int, 8> Desc;
+  std::vector<int> stype;
+  std::vector<std::vector<Desc>> steps;          // [step][lane]; a product slot m is written -(m + 1) until the layout is known
+  const Desc none = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto new_step = [&](int ty) { stype.push_back(ty); steps.push_back(std::vector<Desc>()); return int(steps.size()) - 1; };
+  const int oB = d.l_blk, oR = d.l_r, oX = d.l_x, oDI = d.l_dinv, oZ = d.l_zero;
+  std::vector<std::vector<int>> piv(d.n_levels);
+  for (int k : order) piv[level[k]].push_back(k);
+  int n_m = 0;
+  for (int lv = 0; lv < d.n_levels; ++lv) {
+    // destinations (block (i, j); j == NB: r_i) and, in pivot order, who contributes to them
+    struct Contribution { int i, k, j; };
+    std::vector<std::pair<int, int>> dsts;
+    std::vector<std::vector<Contribution>> contrib;
+    std::vector<std::vector<int>> dst_of(NB, std::vector<int>(NB + 1, -1));
+    for (int k : piv[lv])
+      for (int i : upper[k])
+        for (size_t q = 0; q <= upper[k].size(); ++q) {
+          const int j = q < upper[k].size() ? upper[k][q] : NB;
+          if (dst_of[i][j] < 0) { dst_of[i][j] = int(dsts.size()); dsts.push_back({i, j}); contrib.push_back({}); }
+          contrib[dst_of[i][j]].push_back(Contribution{i, k, j});
+        }
+    if (dsts.empty()) continue;
+    // summation rounds: up to four products per destination and round (an unused operand is the zero block);
+    // the products of a level are all alive at once, the next level reuses their places
+    size_t n_rounds = 0;
+    for (const auto& c : contrib) n_rounds = std::max(n_rounds, (c.size() + 3) / 4);
+    std::vector<Desc> prods;
+    std::vector<std::vector<Desc>> sums(n_rounds);
+    std::vector<char> dinv_done(NB, 0);
+    int m_lv = 0;
+    for (size_t r = 0; r < n_rounds; ++r)
+      for (size_t q = 0; q < dsts.size(); ++q) {
+        const auto& c = contrib[q];
+        if (c.size() <= 4 * r) continue;
+        const int dst = dsts[q].second == NB ? oR + 4 * dsts[q].first : oB + 4 * blk[dsts[q].first][dsts[q].second];
+        Desc sum = {OP_SUM, dst, oZ, oZ, oZ, oZ, int(std::min<size_t>(4, c.size() - 4 * r)), 0};
+        for (size_t u = 4 * r; u < std::min(c.size(), 4 * r + 4); ++u) {
+          const Contribution& x = c[u];
+          const int src = x.j == NB ? oR + 4 * x.k : oB + 4 * blk[x.k][x.j];
+          const int m = m_lv++;
+          sum[2 + (u - 4 * r)] = -(m + 1);
+          prods.push_back(Desc{OP_PROD, oB + 4 * blk[x.k][x.k], oB + 4 * blk[x.i][x.k], src, -(m + 1),
+                               dinv_done[x.k] ? 0 : oDI + 4 * x.k, 0, 0});
+          dinv_done[x.k] = 1;
+        }
+        sums[r].push_back(sum);
+      }
+    n_m = std::max(n_m, m_lv);
+    for (size_t q = 0; q < prods.size(); q += G) {
+      const int st = new_step(ST_PROD);
+      for (size_t u = q; u < std::min(prods.size(), q + G); ++u) steps[st].push_back(prods[u]);
+    }
+    for (size_t r = 0; r < n_rounds; ++r)
+      for (size_t q = 0; q < sums[r].size(); q += G) {
+        int run = 1;
+        for (size_t u = q; u < std::min(sums[r].size(), q + G); ++u) run = std::max(run, sums[r][u][6]);
+        const int st = new_step(ST_SUM | (run << 8));
+        for (size_t u = q; u < std::min(sums[r].size(), q + G); ++u) steps[st].push_back(sums[r][u]);
+      }
+  }
+  for (int lv = d.n_levels - 1; lv >= 0; --lv) {
+    // x_k = D_k^-1 (r_k - sum over the later buses j of A_kj x_j): two terms ride with the final operation, the
+    // others are subtracted from r_k first, three per step, in the order of upper[k]
+    size_t max_acc = 0;
+    for (int k : piv[lv]) max_acc = std::max(max_acc, upper[k].size() > 2 ? (upper[k].size() - 2 + 2) / 3 : size_t(0));
+    std::vector<int> acc(max_acc);
+    for (size_t a = 0; a < max_acc; ++a) acc[a] = new_step(ST_ACC);
+    const int fin = new_step(ST_BACK);
+    if (int(piv[lv].size()) > G) { err = "internal: more pivots in a level than lanes"; return false; }
+    for (int k : piv[lv]) {
+      const std::vector<int>& up = upper[k];
+      const size_t n_acc = up.size() > 2 ? (up.size() - 2 + 2) / 3 : 0;
+      size_t u = 0;
+      for (size_t a = 0; a < n_acc; ++a) {
+        Desc dsc = {OP_ACC, oR + 4 * k, oZ, oZ + 4, oZ, oZ + 4, oZ, oZ + 4};
+        for (int c = 0; c < 3 && up.size() - u > 2; ++c, ++u) { dsc[2 + 2 * c] = oB + 4 * blk[k][up[u]]; dsc[3 + 2 * c] = oX + 2 * up[u]; }
+        steps[acc[max_acc - n_acc + a]].push_back(dsc);
+      }
+      Desc dsc = {OP_BACK, oR + 4 * k, oDI + 4 * k, oX + 2 * k, oZ, oZ + 4, oZ, oZ + 4};
+      if (up.empty()) { dsc[0] = OP_INVBACK; dsc[2] = oB + 4 * blk[k][k]; }
+      for (int c = 0; u < up.size(); ++c, ++u) { dsc[4 + 2 * c] = oB + 4 * blk[k][up[u]]; dsc[5 + 2 * c] = oX + 2 * up[u]; }
+      steps[fin].push_back(dsc);
+    }
+  }
+  d.n_m = n_m;
+  d.l_dev = d.l_m + 4 * n_m;
+  d.lds_per_env = (d.l_dev + 2 * d.ND + 1) | 1;
+  if (d.lds_per_env >= 65536) { err = "network too large for the general lane-group kernel (LDS)"; return false; }
+  for (auto& st : steps)
+    for (Desc& q : st)
+      for (int& f : q)
+        if (f < 0) f = d.l_m + 4 * (-f - 1);
+  d.n_steps = int(steps.size());
+  d.off_stype = int(P.hi.size());
+  P.hi.insert(P.hi.end(), stype.begin(), stype.end());
+  while (P.hi.size() % 4) P.hi.push_back(0);     // descriptors are read as int4
+  d.off_desc = int(P.hi.size());
+  for (int st = 0; st < d.n_steps; ++st) {
+    if (int(steps[st].size()) > G) { err = "internal: step over-subscribed"; return false; }
+    for (int l = 0; l < G; ++l) {
+      const Desc& q = l < int(steps[st].size()) ? steps[st][l] : none;
+      for (int w = 0; w < 4; ++w) P.hi.push_back(int(unsigned(q[2 * w]) | (unsigned(q[2 * w + 1]) << 16)));
+    }
+  }
 
   // ---- double tables
   d.off_lane = SF_COUNT;
@@ -266,15 +402,8 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   }
   for (int k = 0; k < d.ND; ++k) pack_device(n, k, &P.hd[d.off_dev + k * SD_SIZE]);
 
-  // ---- LDS layout of one environment
-  d.l_v = 0;
-  d.l_bw = d.l_v + 2 * NB;
-  d.l_blk = d.l_bw + 4 * d.NBR;
-  d.l_r = d.l_blk + 4 * d.NBLK;
-  d.l_x = d.l_r + 2 * NB;
-  d.l_dev = d.l_x + 2 * NB;
-  d.lds_per_env = (d.l_dev + 2 * d.ND + 1) | 1;
-  if (size_t(64 / G) * d.lds_per_env * 8 + size_t(d.off_fill - d.off_task + d.n_fill) * 4 > 60 * 1024) {
+  d.n_stage = int(P.hi.size()) - d.off_lists;   // what a workgroup stages in LDS: lists, fill ids, the program
+  if (lds_bytes(d, 1) > 160 * 1024) {
     err = "network too large for the general lane-group kernel (LDS)";
     return false;
   }
@@ -286,29 +415,29 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 #define ANM_MESH_SYNC() ANM_WAVE_SYNC()
 
 template <class JT>
-__global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0, radial::IO io,
-                                             SolverOpts so, int64_t n_env, ClassSel cls) {
+__global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0, radial::IO io,
+                                              SolverOpts so, int64_t n_env, ClassSel cls) {
+  // a workgroup = 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet: a lane
+  // group lies within one wavefront, whose LDS operations complete in program order (fences only)
   extern __shared__ double sh_dyn[];
   const int t = threadIdx.x;
   const int G = d.G;
   const int l = t & (G - 1);
   const int per_wave = 64 / G;
+  const int per_block = int(blockDim.x) / G;
   const int grp = t / G;
-  const int64_t e = int64_t(blockIdx.x) * per_wave + grp;
+  const int64_t e = int64_t(blockIdx.x) * per_block + grp;
   const bool env_ok = e < n_env;
   const int64_t ee = env_ok ? e : 0;
-  const int64_t first_env = int64_t(blockIdx.x) * per_wave;
+  const int64_t first_env = int64_t(blockIdx.x) * per_block + (t >> 6) * per_wave;
   const double* __restrict__ rd =
       rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
   double* S = sh_dyn + grp * d.lds_per_env;                 // this environment's LDS
-  int* tab = reinterpret_cast<int*>(sh_dyn + per_wave * d.lds_per_env);   // task ranges, lists, fill ids (shared)
-  const int n_tab = d.off_fill + d.n_fill - d.off_task;
-  for (int k = t; k < n_tab; k += 64) tab[k] = ri[d.off_task + k];
-  ANM_MESH_SYNC();
-  const int* task_beg = tab;
-  const int* task_end = tab + d.n_levels * G;
-  const int* lists = tab + (d.off_lists - d.off_task);
-  const int* fills = tab + (d.off_fill - d.off_task);
+  int* tab = reinterpret_cast<int*>(sh_dyn + per_block * d.lds_per_env);   // lists, fill ids, the program (shared)
+  for (int k = t; k < d.n_stage; k += int(blockDim.x)) tab[k] = ri[d.off_lists + k];
+  __syncthreads();
+  const int* lists = tab;
+  const int* fills = tab + (d.off_fill - d.off_lists);
   auto RI = [&](int f) { return ri[f * G + l]; };
   auto RD = [&](int f) { return rd[d.off_lane + f * G + l]; };
   cptr_t C = (cptr_t)rd;
@@ -319,8 +448,9 @@ __global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri,
   const int bus = l + 1;
   const int level = RI(IF_LEVEL), diag = RI(IF_DIAG);
   const int inc_beg = RI(IF_INC_BEG), inc_end = RI(IF_INC_END);
-  const int up_beg = RI(IF_UP_BEG), up_end = RI(IF_UP_END);
+  const int inc0 = RI(IF_INC0), deg = RI(IF_DEG);
   const int br_f = RI(IF_BR_F), br_t = RI(IF_BR_T), blk_ft = RI(IF_BR_BLK_FT), blk_tf = RI(IF_BR_BLK_TF);
+  const int pos_f = RI(IF_BR_POS_F), pos_t = RI(IF_BR_POS_T);
   const int typ = RI(IF_DEV_TYPE), slot = RI(IF_DEV_SLOT), sset = RI(IF_DEV_SET);
   const int mode = io.mode;
   const int K = io.e.K;
@@ -437,20 +567,32 @@ __global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri,
   double* LV = S + d.l_v;       // vr[NB], vi[NB]
   double* LBW = S + d.l_bw;     // wft_r, wft_i, wtf_r, wtf_i [NBR] each
   double* LBLK = S + d.l_blk;   // [NBLK][4]
-  double* LR = S + d.l_r;       // r0[NB], r1[NB]
-  double* LX = S + d.l_x;       // x0[NB], x1[NB]
+  double* LR = S + d.l_r;       // r[NB] as blocks (r0, 0; r1, 0)
+  double* LX = S + d.l_x;       // x[NB][2]
   const int NB = d.NB, NBR = d.NBR;
   const double yii_r = RD(DF_YII_RE), yii_i = RD(DF_YII_IM);
   const double yft_r = RD(DF_YFT_RE), yft_i = RD(DF_YFT_IM), ytf_r = RD(DF_YTF_RE), ytf_i = RD(DF_YTF_IM);
   double vm = 1.0, cs = 1.0, sn = 0.0, vr = 1.0, vi = 0.0;
   int it = 0;
-  double diff = 0.0;
+  bool g_bad = false, g_nan = false;   // the group's ||F||inf > tol / F has a NaN, as of its last evaluation
   bool active = true;
+  const unsigned long long busm = __builtin_amdgcn_uicmp(isbus ? 1u : 0u, 0u, group::ICMP_NE);
+  const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << G) - 1ull)) << ((t & 63) - l);
+  const unsigned glo = unsigned(gmask), ghi = unsigned(gmask >> 32);
   if (l == 0) { LV[0] = 1.0; LV[NB] = 0.0; }   // slack bus: V_0 = 1
+  if (l < 6) S[d.l_zero + l] = 0.0;
+  for (int k = l; k < 4 * NB; k += G) LR[k] = 0.0;                // second column of the right-hand-side blocks
   auto put_blk = [&](int b, double a, double bb, double c, double dd) {
     double* p = LBLK + 4 * b;
     p[0] = a; p[1] = bb; p[2] = c; p[3] = dd;
   };
+  auto ld4 = [&](int o) { const double* p = S + o; return Blk<JT>{JT(p[0]), JT(p[1]), JT(p[2]), JT(p[3])}; };
+  auto st4 = [&](int o, const Blk<JT>& m) { double* p = S + o; p[0] = double(m.a); p[1] = double(m.b); p[2] = double(m.c); p[3] = double(m.d); };
+  // the step program (see OpKind): descriptor and type of the next step are fetched while this one runs
+  const int4* prog = reinterpret_cast<const int4*>(tab + (d.off_desc - d.off_lists));
+  const int* stype = tab + (d.off_stype - d.off_lists);
+  int4 nxt = prog[l];
+  int nxt_ty = stype[0];
   for (;;) {
     vr = vm * cs;
     vi = vm * sn;
@@ -462,7 +604,7 @@ __global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri,
       const double pr = fma(vfr, vtr, vfi * vti), pim = fma(vfi, vtr, -(vfr * vti));   // P = V_f conj(V_t)
       const double wft_r = fma(yft_r, pr, yft_i * pim), wft_i = fma(yft_r, pim, -(yft_i * pr));
       const double wtf_r = fma(ytf_r, pr, -(ytf_i * pim)), wtf_i = -fma(ytf_r, pim, ytf_i * pr);
-      LBW[l] = wft_r; LBW[NBR + l] = wft_i; LBW[2 * NBR + l] = wtf_r; LBW[3 * NBR + l] = wtf_i;
+      LBW[2 * pos_f] = wft_r; LBW[2 * pos_f + 1] = wft_i; LBW[2 * pos_t] = wtf_r; LBW[2 * pos_t + 1] = wtf_i;
       if (blk_ft >= 0) {
         put_blk(blk_ft, wft_i, wft_r, -wft_r, wft_i);
         put_blk(blk_tf, wtf_i, wtf_r, -wtf_r, wtf_i);
@@ -474,79 +616,103 @@ __global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri,
     const double m2 = vm * vm;
     const double wii_r = yii_r * m2, wii_i = -(yii_i * m2);
     double sr = wii_r, si = wii_i;
-    for (int k = inc_beg; k < inc_end; ++k) {
-      const int code = lists[k];
-      const int br = code >> 1, side = code & 1;
-      sr += LBW[(2 * side) * NBR + br];
-      si += LBW[(2 * side + 1) * NBR + br];
+    {
+      // the first four terms are fetched together (most buses have no more); what lies behind a bus's own
+      // entries is somebody else's, read and dropped
+      double er[4], ei[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { er[k] = LBW[2 * (inc0 + k)]; ei[k] = LBW[2 * (inc0 + k) + 1]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < deg) { sr += er[k]; si += ei[k]; }
+      for (int k = 4; k < d.max_deg; ++k)
+        if (k < deg) {
+          sr += LBW[2 * (inc0 + k)];
+          si += LBW[2 * (inc0 + k) + 1];
+        }
     }
     const double fr = sr - bus_p, fi = si - bus_q;
-    double a = isbus ? fmax(fabs(fr), fabs(fi)) : 0.0;
-    double nanf = (isbus && (fr != fr || fi != fi)) ? 1.0 : 0.0;
-    for (int m = 1; m < G; m <<= 1) {
-      a = fmax(a, __shfl_xor(a, m, G));
-      nanf = fmax(nanf, __shfl_xor(nanf, m, G));
-    }
-    const double nd = (nanf > 0.0) ? NAN : a;
-    if (it == 0) diff = nd;
-    else if (active) diff = nd;
-    active = (diff > so.tol) && (it < so.max_iter);
+    // group-wide stop test on lane masks (as anm_group.hpp): "||F||inf > tol" and "F has a NaN" are all the
+    // reference's loop and flags need; a group that stopped keeps its verdict
+    const unsigned long long badm = __builtin_amdgcn_fcmp(isbus ? fmax(fabs(fr), fabs(fi)) : 0.0, so.tol, group::FCMP_UGT);
+    const unsigned long long nanm = __builtin_amdgcn_fcmp(fr, fi, group::FCMP_UNO) & busm;
+    const bool nb = ((unsigned(badm) & glo) | (unsigned(badm >> 32) & ghi)) != 0u;
+    const bool nn = ((unsigned(nanm) & glo) | (unsigned(nanm >> 32) & ghi)) != 0u;
+    if (it == 0 || active) { g_bad = nb; g_nan = nn; }
+    active = g_bad && !g_nan && (it < so.max_iter);       // NaN > tol is false, like the reference
     if (!__any(active && env_ok && !skip)) break;
-    JT r0 = JT(fr), r1 = JT(fi);
-    if (isbus) put_blk(diag, -(si - wii_i), sr + wii_r, sr - wii_r, si + wii_i);
-    ANM_MESH_SYNC();
-    // ---- elimination, level by level
-    for (int lv = 0; lv < d.n_levels; ++lv) {
-      if (isbus && level == lv) {   // pivots of this level: invert the diagonal block, publish the right-hand side
-        double* p = LBLK + 4 * diag;
-        const Blk<JT> Di = blk_inv(Blk<JT>{JT(p[0]), JT(p[1]), JT(p[2]), JT(p[3])});
-        p[0] = double(Di.a); p[1] = double(Di.b); p[2] = double(Di.c); p[3] = double(Di.d);
-        LR[bus] = double(r0); LR[NB + bus] = double(r1);
-      }
-      ANM_MESH_SYNC();
-      for (int q = task_beg[lv * G + l]; q < task_end[lv * G + l];) {
-        const int k = lists[q], dk = lists[q + 1], bik = lists[q + 2], nu = lists[q + 3];
-        q += 4;
-        const double* pd = LBLK + 4 * dk;
-        const double* pl = LBLK + 4 * bik;
-        const Blk<JT> Lik = blk_mul(Blk<JT>{JT(pl[0]), JT(pl[1]), JT(pl[2]), JT(pl[3])},
-                                    Blk<JT>{JT(pd[0]), JT(pd[1]), JT(pd[2]), JT(pd[3])});
-        const JT rk0 = JT(LR[k]), rk1 = JT(LR[NB + k]);
-        r0 = fm(-Lik.b, rk1, fm(-Lik.a, rk0, r0));
-        r1 = fm(-Lik.d, rk1, fm(-Lik.c, rk0, r1));
-        for (int u = 0; u < nu; ++u, q += 2) {
-          double* pz = LBLK + 4 * lists[q];
-          const double* ps = LBLK + 4 * lists[q + 1];
-          Blk<JT> Z = Blk<JT>{JT(pz[0]), JT(pz[1]), JT(pz[2]), JT(pz[3])};
-          blk_submul(Z, Lik, Blk<JT>{JT(ps[0]), JT(ps[1]), JT(ps[2]), JT(ps[3])});
-          pz[0] = double(Z.a); pz[1] = double(Z.b); pz[2] = double(Z.c); pz[3] = double(Z.d);
-        }
-      }
-      ANM_MESH_SYNC();
+    if (isbus) {
+      put_blk(diag, -(si - wii_i), sr + wii_r, sr - wii_r, si + wii_i);
+      LR[4 * bus] = double(JT(fr)); LR[4 * bus + 2] = double(JT(fi));
     }
-    // ---- back substitution, last level first
-    JT d0 = JT(0), d1 = JT(0);
-    for (int lv = d.n_levels - 1; lv >= 0; --lv) {
-      if (isbus && level == lv) {
-        JT a0 = r0, a1 = r1;
-        for (int q = up_beg; q < up_end; q += 2) {
-          const int j = lists[q];
-          const double* pu = LBLK + 4 * lists[q + 1];
-          const JT x0 = JT(LX[j]), x1 = JT(LX[NB + j]);
-          a0 = fm(-JT(pu[1]), x1, fm(-JT(pu[0]), x0, a0));
-          a1 = fm(-JT(pu[3]), x1, fm(-JT(pu[2]), x0, a1));
+    ANM_MESH_SYNC();
+    // ---- elimination and back substitution: the step program
+    for (int sidx = 0; sidx < d.n_steps; ++sidx) {
+      const int4 cur = nxt;
+      const int ty = __builtin_amdgcn_readfirstlane(nxt_ty);
+      const int sn = (sidx + 1 == d.n_steps) ? 0 : sidx + 1;
+      nxt = prog[sn * G + l];
+      nxt_ty = stype[sn];
+      const int kind = cur.x & 0xffff;
+      const int o1 = int(unsigned(cur.x) >> 16), o2 = cur.y & 0xffff, o3 = int(unsigned(cur.y) >> 16);
+      const int o4 = cur.z & 0xffff, o5 = int(unsigned(cur.z) >> 16), o6 = cur.w & 0xffff, o7 = int(unsigned(cur.w) >> 16);
+      if ((ty & 0xff) == ST_PROD) {
+        if (kind != OP_NONE) {
+          const Blk<JT> Di = blk_inv(ld4(o1));
+          const Blk<JT> Lik = blk_mul(ld4(o2), Di);
+          st4(o4, blk_mul(Lik, ld4(o3)));
+          if (o5 != 0) st4(o5, Di);
         }
-        const double* p = LBLK + 4 * diag;
-        d0 = fm(JT(p[0]), a0, JT(p[1]) * a1);
-        d1 = fm(JT(p[2]), a0, JT(p[3]) * a1);
-        LX[bus] = double(d0); LX[NB + bus] = double(d1);
+      } else if ((ty & 0xff) == ST_SUM) {
+        if (kind != OP_NONE) {
+          Blk<JT> Z = ld4(o1);
+          const Blk<JT> M0 = ld4(o2);
+          Z.a -= M0.a; Z.b -= M0.b; Z.c -= M0.c; Z.d -= M0.d;
+          if ((ty >> 8) > 1) {
+            const Blk<JT> M1 = ld4(o3);
+            Z.a -= M1.a; Z.b -= M1.b; Z.c -= M1.c; Z.d -= M1.d;
+          }
+          if ((ty >> 8) > 2) {
+            const Blk<JT> M2 = ld4(o4), M3 = ld4(o5);
+            Z.a -= M2.a; Z.b -= M2.b; Z.c -= M2.c; Z.d -= M2.d;
+            Z.a -= M3.a; Z.b -= M3.b; Z.c -= M3.c; Z.d -= M3.d;
+          }
+          st4(o1, Z);
+        }
+      } else if ((ty & 0xff) == ST_BACK) {
+        if (kind != OP_NONE) {
+          JT a0 = JT(S[o1]), a1 = JT(S[o1 + 2]);
+          Blk<JT> Di = ld4(o2);
+          const Blk<JT> A0 = ld4(o4), A1 = ld4(o6);
+          const JT x00 = JT(S[o5]), x01 = JT(S[o5 + 1]), x10 = JT(S[o7]), x11 = JT(S[o7 + 1]);
+          if (kind == OP_INVBACK) Di = blk_inv(Di);
+          a0 = fm(-A0.b, x01, fm(-A0.a, x00, a0));
+          a1 = fm(-A0.d, x01, fm(-A0.c, x00, a1));
+          a0 = fm(-A1.b, x11, fm(-A1.a, x10, a0));
+          a1 = fm(-A1.d, x11, fm(-A1.c, x10, a1));
+          S[o3] = double(fm(Di.a, a0, Di.b * a1));
+          S[o3 + 1] = double(fm(Di.c, a0, Di.d * a1));
+        }
+      } else {
+        if (kind != OP_NONE) {
+          JT a0 = JT(S[o1]), a1 = JT(S[o1 + 2]);
+          const Blk<JT> A0 = ld4(o2), A1 = ld4(o4), A2 = ld4(o6);
+          const JT x00 = JT(S[o3]), x01 = JT(S[o3 + 1]), x10 = JT(S[o5]), x11 = JT(S[o5 + 1]), x20 = JT(S[o7]), x21 = JT(S[o7 + 1]);
+          a0 = fm(-A0.b, x01, fm(-A0.a, x00, a0));
+          a1 = fm(-A0.d, x01, fm(-A0.c, x00, a1));
+          a0 = fm(-A1.b, x11, fm(-A1.a, x10, a0));
+          a1 = fm(-A1.d, x11, fm(-A1.c, x10, a1));
+          a0 = fm(-A2.b, x21, fm(-A2.a, x20, a0));
+          a1 = fm(-A2.d, x21, fm(-A2.c, x20, a1));
+          S[o1] = double(a0); S[o1 + 2] = double(a1);
+        }
       }
       ANM_MESH_SYNC();
     }
     // ---- update (group-uniform `active`); d1 is the relative magnitude step
     if (active && isbus) {
-      const double dth = double(d0);
-      vm = fma(-double(d1), fabs(vm), vm);
+      const double dth = LX[2 * bus], d1 = LX[2 * bus + 1];
+      vm = fma(-d1, fabs(vm), vm);
       double sd_, cd_;
       if (fabs(dth) <= 0.78) {
         sincos_kernel(dth, 0, sd_, cd_);
@@ -562,8 +728,8 @@ __global__ __launch_bounds__(64) void k_mesh(Dims d, const int* __restrict__ ri,
     }
     it = active ? it + 1 : it;
   }
-  const bool f_nan = (diff != diff);
-  const bool converged = !f_nan && (diff <= so.tol);
+  const bool f_nan = g_nan;
+  const bool converged = !g_nan && !g_bad;
 
   // ---------------- currents, slack injection, branch flows, reward -------------------------------
   // (LV holds the final V: the loop left through its break right after publishing it)

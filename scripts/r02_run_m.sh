@@ -1,6 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-( time timeout 1700 python -m pytest tests -m gpu -q ) > gpurun_out/m_pytest.log 2>&1
-tail -6 gpurun_out/m_pytest.log
-timeout 900 python scripts/mpc_bench.py > gpurun_out/m_mpc.log 2>&1; cat gpurun_out/m_mpc.log
+( timeout 900 python -m pytest tests/test_gpu_headline.py -m gpu -q -x -k "mesh" ) 2>&1 | tail -5
+timeout 300 python scripts/mesh_caps.py 2>&1 | grep -v amdgpu
