@@ -40,8 +40,13 @@ using radial::SF_RTERM; using radial::SF_PERIOD; using radial::SF_Y00_RE; using 
 using radial::SF_SLACK_VMIN; using radial::SF_SLACK_VMAX; using radial::SF_COUNT;
 
 enum IField : int { IF_LEVEL = 0, IF_DIAG, IF_INC_BEG, IF_INC_END, IF_BD_BEG, IF_BD_END, IF_INC0, IF_DEG,
-                    IF_BR_F, IF_BR_T, IF_BR_BLK_FT, IF_BR_BLK_TF, IF_BR_POS_F, IF_BR_POS_T, IF_DEV_TYPE, IF_DEV_SLOT,
-                    IF_DEV_SET, IF_COUNT };
+                    IF_DEV_TYPE, IF_DEV_SLOT, IF_DEV_SET,
+                    IF_BR_F, IF_BR_T, IF_BR_BLK_FT, IF_BR_BLK_TF, IF_BR_POS_F, IF_BR_POS_T,   // branch l ...
+                    IF_BR_FIELDS = IF_BR_POS_T - IF_BR_F + 1,
+                    IF_COUNT = IF_BR_F + 2 * IF_BR_FIELDS };                                  // ... and branch G + l
+// (a lane plays up to BR_SLOTS branches: meshed networks have more branches than buses, and the group size
+// follows the buses -- two environments of a 30-bus, 41-branch network share a wavefront)
+constexpr int BR_SLOTS = 2;
 // The elimination as a PROGRAM of steps (build_plan schedules it once per network; k_mesh interprets it): in every
 // step each lane carries out at most one small operation named by its descriptor -- 8 offsets (in doubles) into
 // the environment's LDS -- and a wavefront-wide fence separates the steps.  Operations are handed to lanes
@@ -61,14 +66,14 @@ enum IField : int { IF_LEVEL = 0, IF_DIAG, IF_INC_BEG, IF_INC_END, IF_BD_BEG, IF
 enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_BACK, OP_INVBACK, OP_ACC };
 enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_BACK = 2, ST_ACC = 3 };
 enum DField : int { DF_YII_RE = 0, DF_YII_IM, DF_VMIN, DF_VMAX, DF_YFT_RE, DF_YFT_IM, DF_YTF_RE, DF_YTF_IM, DF_BRC,
-                    DF_COUNT = DF_BRC + 9 };
+                    DF_BR_FIELDS = DF_BRC + 9 - DF_YFT_RE, DF_COUNT = DF_YFT_RE + 2 * DF_BR_FIELDS };
 
 struct Dims {
-  int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, n_levels, slack_dev, NBLK, n_fill;
+  int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, n_levels, slack_dev, NBLK, n_fill, br_slots;
   int off_lists, n_lists, off_fill;                        // ints: [IF_COUNT][G], lists, fill ids (staged in LDS) ...
   int n_steps, off_stype, off_desc, n_stage, max_deg;      // ... step types (| run length << 8) [n_steps], descriptors [n_steps][G][4]
   int off_lane, off_dev, off_obs_lo, off_obs_hi, n_double;  // doubles
-  int l_v, l_bw, l_blk, l_r, l_x, l_dinv, l_zero, l_m, n_m, l_dev, lds_per_env;   // LDS layout of one environment (doubles)
+  int l_v, l_x, l_blk, l_r, l_dinv, l_zero, l_bw, l_m, n_m, l_dev, lds_per_env;   // LDS layout of one environment (doubles)
   int f_bus_p, f_bus_q, f_bus_vm, f_bus_va, f_bus_im, f_bus_ia, f_dev_p, f_dev_q, f_des_soc, f_gen_pmax, f_br_p,
       f_br_q, f_br_s, f_br_im, f_br_ia;
 };
@@ -83,20 +88,25 @@ struct Plan {
 inline size_t lds_bytes(const Dims& d, int waves) {
   return size_t(waves) * (64 / d.G) * d.lds_per_env * sizeof(double) + size_t(d.n_stage) * sizeof(int);
 }
-// wavefronts per workgroup: as many as share one copy of the program within the default 64 KB
+// wavefronts per workgroup (they share one copy of the tables): what puts most wavefronts on a compute unit's
+// 160 KB of LDS, the larger workgroup on a tie
 inline int waves_per_block(const Dims& d) {
-  int w = 4;
-  while (w > 1 && lds_bytes(d, w) > 64 * 1024) w /= 2;
-  return w;
+  int best = 1;
+  size_t best_waves = 0;
+  for (int w = 1; w <= 4; w *= 2) {
+    const size_t per_cu = lds_bytes(d, w) <= 160 * 1024 ? (160 * 1024 / lds_bytes(d, w)) * w : 0;
+    if (per_cu >= best_waves) { best_waves = per_cu; best = w; }
+  }
+  return best;
 }
 
 inline bool fits(const anm_network_desc& n) {
-  return n.n_bus >= 2 && n.n_bus - 1 <= 64 && n.n_dev <= 64 && n.n_branch <= 64;
+  return n.n_bus >= 2 && n.n_bus - 1 <= 64 && n.n_dev <= 64 && n.n_branch <= 64 * BR_SLOTS;
 }
 
 // Symbolic analysis + per-lane tables for one network.
 inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
-  if (!fits(n)) { err = "the general lane-group kernel takes networks of at most 65 buses, 64 branches, 64 devices"; return false; }
+  if (!fits(n)) { err = "the general lane-group kernel takes networks of at most 65 buses, 128 branches, 64 devices"; return false; }
   Dims& d = P.d;
   d.NB = n.n_bus; d.ND = n.n_dev; d.NBR = n.n_branch;
   d.NLOAD = d.NGEN = d.NDES = 0;
@@ -113,9 +123,10 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   for (int k = 0; k < n.n_dev; ++k)
     if (n.dev_type[k] == DEV_CLASSICAL || n.dev_type[k] == DEV_RENEWABLE || n.dev_type[k] == DEV_STORAGE) sset[k] = d.NSET++;
   d.SDIM = 2 * d.ND + d.NDES + d.NGEN;
-  const int need = std::max(std::max(d.NB - 1, d.ND), d.NBR);
+  const int need = std::max(std::max(d.NB - 1, d.ND), (d.NBR + BR_SLOTS - 1) / BR_SLOTS);
   d.G = 8;
   while (d.G < need) d.G *= 2;
+  d.br_slots = (d.NBR + d.G - 1) / d.G;
   const int G = d.G, NB = d.NB;
   d.f_bus_p = 0; d.f_bus_q = d.f_bus_p + NB; d.f_bus_vm = d.f_bus_q + NB; d.f_bus_va = d.f_bus_vm + NB;
   d.f_bus_im = d.f_bus_va + NB; d.f_bus_ia = d.f_bus_im + NB; d.f_dev_p = d.f_bus_ia + NB;
@@ -204,23 +215,30 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   d.n_levels = 0;
   for (int i = 1; i < NB; ++i) d.n_levels = std::max(d.n_levels, level[i] + 1);
 
-  // ---- LDS layout of one environment (doubles), up to the products (their number comes with the schedule)
+  // ---- LDS layout of one environment (doubles).  Two pairs of areas are never alive together and share their
+  // place: the branch products W (written and summed before the step program starts) with the products of the
+  // elimination, and V (read by the branch lanes at the start of a trip) with the Newton step x (written by the
+  // back substitution, read by the update at the end of the trip)
   d.l_v = 0;
-  d.l_bw = d.l_v + 2 * NB;
-  d.l_blk = d.l_bw + 4 * d.NBR;
+  d.l_x = d.l_v;                         // x[NB][2] / vr[NB], vi[NB]
+  d.l_blk = d.l_v + 2 * NB;
   d.l_r = d.l_blk + 4 * d.NBLK;          // r[NB] as blocks (r0, 0; r1, 0)
-  d.l_x = d.l_r + 4 * NB;                // x[NB][2]
-  d.l_dinv = d.l_x + 2 * NB;             // inverted pivots [NB][4]
+  d.l_dinv = d.l_r + 4 * NB;             // inverted pivots [NB][4]
   d.l_zero = d.l_dinv + 4 * NB;          // 6 zeros nobody writes: what an unused operand slot of a descriptor reads
-  d.l_m = d.l_zero + 6;                  // products [n_m][4]
+  d.l_bw = d.l_zero + 6;                 // W entries [2 NBR][2] / I = Y V terms [4][NBR] ...
+  d.l_m = d.l_bw;                        // ... / products [n_m][4]
 
   // ---- int tables
   P.hi.assign(size_t(IF_COUNT) * G, 0);
   auto I = [&](int f, int l) -> int& { return P.hi[size_t(f) * G + l]; };
   for (int l = 0; l < G; ++l) {
-    I(IF_LEVEL, l) = -1; I(IF_DIAG, l) = -1; I(IF_BR_F, l) = -1; I(IF_BR_T, l) = -1; I(IF_BR_BLK_FT, l) = -1;
-    I(IF_BR_BLK_TF, l) = -1; I(IF_DEV_TYPE, l) = DEV_NONE; I(IF_DEV_SLOT, l) = -1; I(IF_DEV_SET, l) = -1;
+    I(IF_LEVEL, l) = -1; I(IF_DIAG, l) = -1; I(IF_DEV_TYPE, l) = DEV_NONE; I(IF_DEV_SLOT, l) = -1; I(IF_DEV_SET, l) = -1;
+    for (int sl = 0; sl < BR_SLOTS; ++sl) {
+      I(IF_BR_F + sl * IF_BR_FIELDS, l) = -1; I(IF_BR_T + sl * IF_BR_FIELDS, l) = -1;
+      I(IF_BR_BLK_FT + sl * IF_BR_FIELDS, l) = -1; I(IF_BR_BLK_TF + sl * IF_BR_FIELDS, l) = -1;
+    }
   }
+  auto IB = [&](int f, int br) -> int& { return P.hi[size_t(f + (br / G) * IF_BR_FIELDS) * G + br % G]; };   // field of a branch
   std::vector<int> lists;
   // W entries: entry e holds (re, im) of one end of one branch at LDS doubles l_bw + 2e; the entries a bus sums
   // are consecutive, in branch order (the order the reference sums a row of Y V in); the slack ends come last
@@ -233,8 +251,8 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     I(IF_INC_BEG, l) = int(lists.size());
     I(IF_INC0, l) = n_ent;
     for (int br = 0; br < d.NBR; ++br) {
-      if (n.br_from[br] == b) { lists.push_back(br << 1); I(IF_BR_POS_F, br) = n_ent++; }
-      else if (n.br_to[br] == b) { lists.push_back((br << 1) | 1); I(IF_BR_POS_T, br) = n_ent++; }
+      if (n.br_from[br] == b) { lists.push_back(br << 1); IB(IF_BR_POS_F, br) = n_ent++; }
+      else if (n.br_to[br] == b) { lists.push_back((br << 1) | 1); IB(IF_BR_POS_T, br) = n_ent++; }
     }
     I(IF_INC_END, l) = int(lists.size());
     I(IF_DEG, l) = n_ent - I(IF_INC0, l);
@@ -246,11 +264,11 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   }
   for (int br = 0; br < d.NBR; ++br) {
     const int f = n.br_from[br], t = n.br_to[br];
-    if (f == 0) I(IF_BR_POS_F, br) = n_ent++;
-    if (t == 0) I(IF_BR_POS_T, br) = n_ent++;
-    I(IF_BR_F, br) = f; I(IF_BR_T, br) = t;
-    I(IF_BR_BLK_FT, br) = (f != 0 && t != 0) ? blk[f][t] : -1;
-    I(IF_BR_BLK_TF, br) = (f != 0 && t != 0) ? blk[t][f] : -1;
+    if (f == 0) IB(IF_BR_POS_F, br) = n_ent++;
+    if (t == 0) IB(IF_BR_POS_T, br) = n_ent++;
+    IB(IF_BR_F, br) = f; IB(IF_BR_T, br) = t;
+    IB(IF_BR_BLK_FT, br) = (f != 0 && t != 0) ? blk[f][t] : -1;
+    IB(IF_BR_BLK_TF, br) = (f != 0 && t != 0) ? blk[t][f] : -1;
   }
   for (int k = 0; k < d.ND; ++k) {
     I(IF_DEV_TYPE, k) = n.dev_type[k];
@@ -351,7 +369,7 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     }
   }
   d.n_m = n_m;
-  d.l_dev = d.l_m + 4 * n_m;
+  d.l_dev = d.l_m + std::max(4 * n_m, 4 * d.NBR);
   d.lds_per_env = (d.l_dev + 2 * d.ND + 1) | 1;
   if (d.lds_per_env >= 65536) { err = "network too large for the general lane-group kernel (LDS)"; return false; }
   for (auto& st : steps)
@@ -394,11 +412,12 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     const int f = n.br_from[br], t = n.br_to[br];
     const cplx ys(n.br_series[2 * br], n.br_series[2 * br + 1]), sh(n.br_shunt[2 * br], n.br_shunt[2 * br + 1]);
     const cplx tap(n.br_tap[2 * br], n.br_tap[2 * br + 1]);
-    D(DF_YFT_RE, br) = Y[f * NB + t].real(); D(DF_YFT_IM, br) = Y[f * NB + t].imag();
-    D(DF_YTF_RE, br) = Y[t * NB + f].real(); D(DF_YTF_IM, br) = Y[t * NB + f].imag();
+    auto DB = [&](int fld) -> double& { return D(fld + (br / G) * DF_BR_FIELDS, br % G); };
+    DB(DF_YFT_RE) = Y[f * NB + t].real(); DB(DF_YFT_IM) = Y[f * NB + t].imag();
+    DB(DF_YTF_RE) = Y[t * NB + f].real(); DB(DF_YTF_IM) = Y[t * NB + f].imag();
     const cplx c4[4] = {(ys + sh) / (std::abs(tap) * std::abs(tap)), -ys / std::conj(tap), ys + sh, -ys / tap};
-    for (int j = 0; j < 4; ++j) { D(DF_BRC + 2 * j, br) = c4[j].real(); D(DF_BRC + 2 * j + 1, br) = c4[j].imag(); }
-    D(DF_BRC + 8, br) = n.br_rate[br];
+    for (int j = 0; j < 4; ++j) { DB(DF_BRC + 2 * j) = c4[j].real(); DB(DF_BRC + 2 * j + 1) = c4[j].imag(); }
+    DB(DF_BRC + 8) = n.br_rate[br];
   }
   for (int k = 0; k < d.ND; ++k) pack_device(n, k, &P.hd[d.off_dev + k * SD_SIZE]);
 
@@ -444,13 +463,22 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   const double base = rd[SF_BASE], dt = rd[SF_DT];
 
   const bool isbus = l < d.NB - 1;
-  const bool isbr = l < d.NBR;
+  bool isbr[BR_SLOTS];
+  int br_f[BR_SLOTS], br_t[BR_SLOTS], blk_ft[BR_SLOTS], blk_tf[BR_SLOTS], pos_f[BR_SLOTS], pos_t[BR_SLOTS];
   const int bus = l + 1;
   const int level = RI(IF_LEVEL), diag = RI(IF_DIAG);
   const int inc_beg = RI(IF_INC_BEG), inc_end = RI(IF_INC_END);
   const int inc0 = RI(IF_INC0), deg = RI(IF_DEG);
-  const int br_f = RI(IF_BR_F), br_t = RI(IF_BR_T), blk_ft = RI(IF_BR_BLK_FT), blk_tf = RI(IF_BR_BLK_TF);
-  const int pos_f = RI(IF_BR_POS_F), pos_t = RI(IF_BR_POS_T);
+#pragma unroll
+  for (int sl = 0; sl < BR_SLOTS; ++sl) {
+    isbr[sl] = sl < d.br_slots && sl * G + l < d.NBR;
+    br_f[sl] = br_t[sl] = 0; blk_ft[sl] = blk_tf[sl] = -1; pos_f[sl] = pos_t[sl] = 0;
+    if (sl < d.br_slots) {
+      br_f[sl] = RI(IF_BR_F + sl * IF_BR_FIELDS); br_t[sl] = RI(IF_BR_T + sl * IF_BR_FIELDS);
+      blk_ft[sl] = RI(IF_BR_BLK_FT + sl * IF_BR_FIELDS); blk_tf[sl] = RI(IF_BR_BLK_TF + sl * IF_BR_FIELDS);
+      pos_f[sl] = RI(IF_BR_POS_F + sl * IF_BR_FIELDS); pos_t[sl] = RI(IF_BR_POS_T + sl * IF_BR_FIELDS);
+    }
+  }
   const int typ = RI(IF_DEV_TYPE), slot = RI(IF_DEV_SLOT), sset = RI(IF_DEV_SET);
   const int mode = io.mode;
   const int K = io.e.K;
@@ -571,7 +599,15 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   double* LX = S + d.l_x;       // x[NB][2]
   const int NB = d.NB, NBR = d.NBR;
   const double yii_r = RD(DF_YII_RE), yii_i = RD(DF_YII_IM);
-  const double yft_r = RD(DF_YFT_RE), yft_i = RD(DF_YFT_IM), ytf_r = RD(DF_YTF_RE), ytf_i = RD(DF_YTF_IM);
+  double yft_r[BR_SLOTS], yft_i[BR_SLOTS], ytf_r[BR_SLOTS], ytf_i[BR_SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < BR_SLOTS; ++sl) {
+    yft_r[sl] = yft_i[sl] = ytf_r[sl] = ytf_i[sl] = 0.0;
+    if (sl < d.br_slots) {
+      yft_r[sl] = RD(DF_YFT_RE + sl * DF_BR_FIELDS); yft_i[sl] = RD(DF_YFT_IM + sl * DF_BR_FIELDS);
+      ytf_r[sl] = RD(DF_YTF_RE + sl * DF_BR_FIELDS); ytf_i[sl] = RD(DF_YTF_IM + sl * DF_BR_FIELDS);
+    }
+  }
   double vm = 1.0, cs = 1.0, sn = 0.0, vr = 1.0, vi = 0.0;
   int it = 0;
   bool g_bad = false, g_nan = false;   // the group's ||F||inf > tol / F has a NaN, as of its last evaluation
@@ -579,7 +615,6 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   const unsigned long long busm = __builtin_amdgcn_uicmp(isbus ? 1u : 0u, 0u, group::ICMP_NE);
   const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << G) - 1ull)) << ((t & 63) - l);
   const unsigned glo = unsigned(gmask), ghi = unsigned(gmask >> 32);
-  if (l == 0) { LV[0] = 1.0; LV[NB] = 0.0; }   // slack bus: V_0 = 1
   if (l < 6) S[d.l_zero + l] = 0.0;
   for (int k = l; k < 4 * NB; k += G) LR[k] = 0.0;                // second column of the right-hand-side blocks
   auto put_blk = [&](int b, double a, double bb, double c, double dd) {
@@ -597,19 +632,22 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
     vr = vm * cs;
     vi = vm * sn;
     if (isbus) { LV[bus] = vr; LV[NB + bus] = vi; }
+    if (l == 0) { LV[0] = 1.0; LV[NB] = 0.0; }   // slack bus: V_0 = 1 (every trip: the area also serves as x)
     ANM_MESH_SYNC();
     // ---- branch lanes: W_ft = V_f conj(Y_ft V_t), W_tf = V_t conj(Y_tf V_f) and the two off-diagonal blocks
-    if (isbr) {
-      const double vfr = LV[br_f], vfi = LV[NB + br_f], vtr = LV[br_t], vti = LV[NB + br_t];
-      const double pr = fma(vfr, vtr, vfi * vti), pim = fma(vfi, vtr, -(vfr * vti));   // P = V_f conj(V_t)
-      const double wft_r = fma(yft_r, pr, yft_i * pim), wft_i = fma(yft_r, pim, -(yft_i * pr));
-      const double wtf_r = fma(ytf_r, pr, -(ytf_i * pim)), wtf_i = -fma(ytf_r, pim, ytf_i * pr);
-      LBW[2 * pos_f] = wft_r; LBW[2 * pos_f + 1] = wft_i; LBW[2 * pos_t] = wtf_r; LBW[2 * pos_t + 1] = wtf_i;
-      if (blk_ft >= 0) {
-        put_blk(blk_ft, wft_i, wft_r, -wft_r, wft_i);
-        put_blk(blk_tf, wtf_i, wtf_r, -wtf_r, wtf_i);
+#pragma unroll
+    for (int sl = 0; sl < BR_SLOTS; ++sl)
+      if (isbr[sl]) {
+        const double vfr = LV[br_f[sl]], vfi = LV[NB + br_f[sl]], vtr = LV[br_t[sl]], vti = LV[NB + br_t[sl]];
+        const double pr = fma(vfr, vtr, vfi * vti), pim = fma(vfi, vtr, -(vfr * vti));   // P = V_f conj(V_t)
+        const double wft_r = fma(yft_r[sl], pr, yft_i[sl] * pim), wft_i = fma(yft_r[sl], pim, -(yft_i[sl] * pr));
+        const double wtf_r = fma(ytf_r[sl], pr, -(ytf_i[sl] * pim)), wtf_i = -fma(ytf_r[sl], pim, ytf_i[sl] * pr);
+        LBW[2 * pos_f[sl]] = wft_r; LBW[2 * pos_f[sl] + 1] = wft_i; LBW[2 * pos_t[sl]] = wtf_r; LBW[2 * pos_t[sl] + 1] = wtf_i;
+        if (blk_ft[sl] >= 0) {
+          put_blk(blk_ft[sl], wft_i, wft_r, -wft_r, wft_i);
+          put_blk(blk_tf[sl], wtf_i, wtf_r, -wtf_r, wtf_i);
+        }
       }
-    }
     for (int k = l; k < d.n_fill; k += G) put_blk(fills[k], 0.0, 0.0, 0.0, 0.0);
     ANM_MESH_SYNC();
     // ---- bus lanes: S_i = W_ii + sum over the incident branches, mismatch, diagonal block
@@ -735,11 +773,16 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   // (LV holds the final V: the loop left through its break right after publishing it)
   ANM_MESH_SYNC();
   // branch lanes: the two terms of I = Y V their branch contributes, Y_ft V_t (to bus f) and Y_tf V_f (to bus t)
-  double vfr = 1.0, vfi = 0.0, vtr = 1.0, vti = 0.0;
-  if (isbr) {
-    vfr = LV[br_f]; vfi = LV[NB + br_f]; vtr = LV[br_t]; vti = LV[NB + br_t];
-    LBW[l] = fma(yft_r, vtr, -(yft_i * vti)); LBW[NBR + l] = fma(yft_r, vti, yft_i * vtr);
-    LBW[2 * NBR + l] = fma(ytf_r, vfr, -(ytf_i * vfi)); LBW[3 * NBR + l] = fma(ytf_r, vfi, ytf_i * vfr);
+  double vfr[BR_SLOTS], vfi[BR_SLOTS], vtr[BR_SLOTS], vti[BR_SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < BR_SLOTS; ++sl) {
+    vfr[sl] = 1.0; vfi[sl] = 0.0; vtr[sl] = 1.0; vti[sl] = 0.0;
+    if (isbr[sl]) {
+      const int b = sl * G + l;
+      vfr[sl] = LV[br_f[sl]]; vfi[sl] = LV[NB + br_f[sl]]; vtr[sl] = LV[br_t[sl]]; vti[sl] = LV[NB + br_t[sl]];
+      LBW[b] = fma(yft_r[sl], vtr[sl], -(yft_i[sl] * vti[sl])); LBW[NBR + b] = fma(yft_r[sl], vti[sl], yft_i[sl] * vtr[sl]);
+      LBW[2 * NBR + b] = fma(ytf_r[sl], vfr[sl], -(ytf_i[sl] * vfi[sl])); LBW[3 * NBR + b] = fma(ytf_r[sl], vfi[sl], ytf_i[sl] * vfr[sl]);
+    }
   }
   ANM_MESH_SYNC();
   double ir = fma(yii_r, vr, -(yii_i * vi)), ii = fma(yii_r, vi, yii_i * vr);
@@ -751,8 +794,12 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   }
   // I_0 = Y_00 + sum over the branches at the slack bus (fixed butterfly order)
   double s0r = 0.0, s0i = 0.0;
-  if (isbr && br_f == 0) { s0r = LBW[l]; s0i = LBW[NBR + l]; }
-  if (isbr && br_t == 0) { s0r = LBW[2 * NBR + l]; s0i = LBW[3 * NBR + l]; }
+#pragma unroll
+  for (int sl = 0; sl < BR_SLOTS; ++sl) {
+    const int b = sl * G + l;
+    if (isbr[sl] && br_f[sl] == 0) { s0r += LBW[b]; s0i += LBW[NBR + b]; }
+    if (isbr[sl] && br_t[sl] == 0) { s0r += LBW[2 * NBR + b]; s0i += LBW[3 * NBR + b]; }
+  }
   for (int m = 1; m < G; m <<= 1) {
     s0r += __shfl_xor(s0r, m, G);
     s0i += __shfl_xor(s0i, m, G);
@@ -762,23 +809,28 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   const double slack_q = (i0i != i0i) ? INFINITY : -i0i;
   if (typ == DEV_SLACK) { dev_p = slack_p; dev_q = slack_q; }
 
-  double br_pf = 0, br_qf = 0, br_s = 0, br_ifr = 0, br_ifi = 0, pen = 0.0;
-  if (isbr) {
-    const double c0 = RD(DF_BRC + 0), c1 = RD(DF_BRC + 1), c2 = RD(DF_BRC + 2), c3 = RD(DF_BRC + 3);
-    const double c4 = RD(DF_BRC + 4), c5 = RD(DF_BRC + 5), c6 = RD(DF_BRC + 6), c7 = RD(DF_BRC + 7);
-    br_ifr = c0 * vfr - c1 * vfi + c2 * vtr - c3 * vti;
-    br_ifi = c0 * vfi + c1 * vfr + c2 * vti + c3 * vtr;
-    const double itr = c4 * vtr - c5 * vti + c6 * vfr - c7 * vfi;
-    const double iti = c4 * vti + c5 * vtr + c6 * vfi + c7 * vfr;
-    br_pf = vfr * br_ifr + vfi * br_ifi;
-    br_qf = vfi * br_ifr - vfr * br_ifi;
-    const double pt = vtr * itr + vti * iti, qt = vti * itr - vtr * iti;
-    const double sf2 = br_pf * br_pf + br_qf * br_qf, st2 = pt * pt + qt * qt;
-    const double sgn = (br_pf > 0.0) ? 1.0 : ((br_pf < 0.0) ? -1.0 : ((br_pf == 0.0) ? 0.0 : NAN));
-    const double smax = (sf2 != sf2 || st2 != st2) ? NAN : sqrt(fmax(sf2, st2));
-    br_s = sgn * smax;
-    const double over = fabs(br_s) - RD(DF_BRC + 8);
-    pen += (over != over) ? NAN : fmax(0.0, over);
+  double br_pf[BR_SLOTS], br_qf[BR_SLOTS], br_s[BR_SLOTS], br_ifr[BR_SLOTS], br_ifi[BR_SLOTS], pen = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < BR_SLOTS; ++sl) {
+    br_pf[sl] = br_qf[sl] = br_s[sl] = br_ifr[sl] = br_ifi[sl] = 0.0;
+    if (isbr[sl]) {
+      const int o = sl * DF_BR_FIELDS;
+      const double c0 = RD(DF_BRC + 0 + o), c1 = RD(DF_BRC + 1 + o), c2 = RD(DF_BRC + 2 + o), c3 = RD(DF_BRC + 3 + o);
+      const double c4 = RD(DF_BRC + 4 + o), c5 = RD(DF_BRC + 5 + o), c6 = RD(DF_BRC + 6 + o), c7 = RD(DF_BRC + 7 + o);
+      br_ifr[sl] = c0 * vfr[sl] - c1 * vfi[sl] + c2 * vtr[sl] - c3 * vti[sl];
+      br_ifi[sl] = c0 * vfi[sl] + c1 * vfr[sl] + c2 * vti[sl] + c3 * vtr[sl];
+      const double itr = c4 * vtr[sl] - c5 * vti[sl] + c6 * vfr[sl] - c7 * vfi[sl];
+      const double iti = c4 * vti[sl] + c5 * vtr[sl] + c6 * vfi[sl] + c7 * vfr[sl];
+      br_pf[sl] = vfr[sl] * br_ifr[sl] + vfi[sl] * br_ifi[sl];
+      br_qf[sl] = vfi[sl] * br_ifr[sl] - vfr[sl] * br_ifi[sl];
+      const double pt = vtr[sl] * itr + vti[sl] * iti, qt = vti[sl] * itr - vtr[sl] * iti;
+      const double sf2 = br_pf[sl] * br_pf[sl] + br_qf[sl] * br_qf[sl], st2 = pt * pt + qt * qt;
+      const double sgn = (br_pf[sl] > 0.0) ? 1.0 : ((br_pf[sl] < 0.0) ? -1.0 : ((br_pf[sl] == 0.0) ? 0.0 : NAN));
+      const double smax = (sf2 != sf2 || st2 != st2) ? NAN : sqrt(fmax(sf2, st2));
+      br_s[sl] = sgn * smax;
+      const double over = fabs(br_s[sl]) - RD(DF_BRC + 8 + o);
+      pen += (over != over) ? NAN : fmax(0.0, over);
+    }
   }
   if (isbus) {
     const double vmag = fabs(vm);
@@ -811,12 +863,15 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
       f[d.f_bus_vm + bus] = hypot(vr, vi); f[d.f_bus_va + bus] = atan2(vi, vr);
       f[d.f_bus_im + bus] = hypot(ir, ii); f[d.f_bus_ia + bus] = atan2(ii, ir);
     }
-    if (isbr) {
-      f[d.f_br_p + l] = br_pf; f[d.f_br_q + l] = br_qf; f[d.f_br_s + l] = br_s;
-      const double mag = hypot(br_ifr, br_ifi);
-      f[d.f_br_im + l] = (mag == 0.0) ? 0.0 : (br_ifr / mag) * mag;
-      f[d.f_br_ia + l] = atan2(br_ifi, br_ifr);
-    }
+#pragma unroll
+    for (int sl = 0; sl < BR_SLOTS; ++sl)
+      if (isbr[sl]) {
+        const int b = sl * G + l;
+        f[d.f_br_p + b] = br_pf[sl]; f[d.f_br_q + b] = br_qf[sl]; f[d.f_br_s + b] = br_s[sl];
+        const double mag = hypot(br_ifr[sl], br_ifi[sl]);
+        f[d.f_br_im + b] = (mag == 0.0) ? 0.0 : (br_ifr[sl] / mag) * mag;
+        f[d.f_br_ia + b] = atan2(br_ifi[sl], br_ifr[sl]);
+      }
     if (l == 0) {
       f[d.f_bus_p] = slack_p; f[d.f_bus_q] = slack_q; f[d.f_bus_vm] = 1.0; f[d.f_bus_va] = 0.0;
       f[d.f_bus_im] = hypot(i0r, i0i); f[d.f_bus_ia] = atan2(i0i, i0r);

@@ -36,8 +36,9 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
   };
   for (int l = 0; l + 1 < NB; ++l) set_blk(I(mesh::IF_DIAG, l), l + 1, l + 1, 1.0, 8.0);
   for (int br = 0; br < d.NBR; ++br) {
-    const int f = I(mesh::IF_BR_F, br), t = I(mesh::IF_BR_T, br);
-    if (I(mesh::IF_BR_BLK_FT, br) >= 0) { set_blk(I(mesh::IF_BR_BLK_FT, br), f, t, 1.0, 0.0); set_blk(I(mesh::IF_BR_BLK_TF, br), t, f, 1.0, 0.0); }
+    auto IB = [&](int fld) { return I(fld + (br / G) * mesh::IF_BR_FIELDS, br % G); };   // branch br: slot br / G of lane br % G
+    const int f = IB(mesh::IF_BR_F), t = IB(mesh::IF_BR_T);
+    if (IB(mesh::IF_BR_BLK_FT) >= 0) { set_blk(IB(mesh::IF_BR_BLK_FT), f, t, 1.0, 0.0); set_blk(IB(mesh::IF_BR_BLK_TF), t, f, 1.0, 0.0); }
   }
   for (int k = 0; k < d.n_fill; ++k)
     for (int u = 0; u < 4; ++u) S[d.l_blk + 4 * P.hi[d.off_fill + k] + u] = 0.0;

@@ -1,0 +1,55 @@
+"""CPU tier: the step program the general lane-group kernel interprets (gym_anm_amd/csrc/anm_mesh.hpp,
+mesh::build_plan) is executed on the host with the kernel's semantics -- within a step every lane reads before
+any lane writes, no two lanes of a step write the same place -- on a random block matrix with the network's
+sparsity pattern and compared with dense Gaussian elimination (tests/hostsim/mesh_program_check.cpp).
+The reference solves whatever network it is given (solve_load_flow.py:220, SciPy's sparse LU)."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from gym_anm_amd import _lib, networks
+from gym_anm_amd.model import NetworkModel
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def checker():
+    out = os.path.join(HERE, "hostsim", "_build")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libmesh_program_check.so")
+    src = os.path.join(HERE, "hostsim", "mesh_program_check.cpp")
+    deps = [src] + [os.path.join(ROOT, "gym_anm_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "gym_anm_amd", "csrc")) if f.endswith(".hpp")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(p) for p in deps):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), src, "-o", lib],
+                       check=True, capture_output=True)
+    h = C.CDLL(lib)
+    h.mesh_program_check.argtypes = [C.POINTER(_lib.NetworkDesc), C.c_uint64, C.POINTER(C.c_double)] + [C.POINTER(C.c_int32)] * 3
+    return h
+
+
+def _check(checker, net, seed):
+    desc, keep = _lib.network_desc(NetworkModel(net, 0.25, 100))
+    err, steps, levels, group = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+    rc = checker.mesh_program_check(C.byref(desc), seed, C.byref(err), C.byref(steps), C.byref(levels), C.byref(group))
+    assert rc == 0, "schedule rejected (code %d)" % rc
+    assert err.value < 1e-12, err.value
+    return steps.value, levels.value, group.value
+
+
+def test_stock_networks(checker):
+    assert _check(checker, networks.anm6_network(), 1)[2] == 8
+    steps, levels, group = _check(checker, networks.synthetic_radial_network(30, 0), 2)
+    assert group == 32 and levels <= 6          # independent-set rounds: ~log(n) levels for a feeder
+    # 30 buses, 33 branches: the group follows the buses, a lane plays two branches
+    assert _check(checker, networks.synthetic_meshed_network(30, 6, 4), 3)[2] == 32
+
+
+@pytest.mark.parametrize("n_bus,seed,n_chords", [(4, 0, 1), (8, 1, 2), (12, 2, 3), (20, 3, 6), (33, 4, 8), (40, 5, 10),
+                                                 (50, 7, 14), (60, 8, 4), (64, 9, 20)])
+def test_random_meshed_networks(checker, n_bus, seed, n_chords):
+    for s in range(3):
+        _check(checker, networks.synthetic_meshed_network(n_bus, seed, n_chords), 10 * seed + s)
