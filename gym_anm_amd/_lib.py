@@ -164,7 +164,7 @@ def load_for_topology(topo, impl=None) -> Backend:
     if name in _CACHE:
         return _CACHE[name]
     path = codegen.lib_path(name)
-    fits_group = topo[0] - 1 <= 64 and len(topo[1]) <= 64 and len(topo[2]) <= 64
+    fits_group = topo[0] - 1 <= 64 and len(topo[1]) <= 128 and len(topo[2]) <= 64   # mesh::fits (anm_mesh.hpp)
     generic = (_is_tree(topo) and (impl == "radial" or (impl is None and topo[0] > 12))) or \
               (fits_group and (impl == "mesh" or (impl is None and topo[0] > 12)))
     if not os.path.exists(path) and generic:
@@ -179,6 +179,13 @@ def load_for_topology(topo, impl=None) -> Backend:
                     continue
                 be.generic = True
                 return be
+    if not os.path.exists(path) and topo[0] > 12 and impl is None and not generic:
+        # compiling the thread-per-environment kernels for a network of this size takes hipcc minutes to hours and
+        # yields a spilling kernel: only on explicit request
+        raise E.UnsupportedNetworkError(
+            "a %d-bus network with %d branches and %d devices fits neither lane-group kernel (at most 65 buses, "
+            "128 branches, 64 devices) and is too large for the thread-per-environment kernels; pass "
+            "impl='thread' to compile them anyway" % (topo[0], len(topo[1]), len(topo[2])))
     # build_library returns at once when the library's content stamp matches this tree's sources; a
     # stale library (edited kernels, changed C ABI) is rebuilt, or refused when hipcc is unavailable:
     # calling an old binary through the new ctypes signatures would be silent garbage

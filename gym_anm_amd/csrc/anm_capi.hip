@@ -207,11 +207,6 @@ int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const rad
   const unsigned grid = unsigned((n + per_block - 1) / per_block);
   const size_t lds = mesh::lds_bytes(d, waves);
   const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1} : ClassSel{m->d_zero, 0, 0};
-  if (lds > 64 * 1024) {   // one wavefront per workgroup and still above the default limit: ask for the CU's LDS
-    hipError_t ea = hipFuncSetAttribute(precision == ANM_SOLVE_F32 ? (const void*)mesh::k_mesh<float> : (const void*)mesh::k_mesh<double>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (ea != hipSuccess) return fail_hip(ea, "hipFuncSetAttribute(k_mesh, dynamic LDS)");
-  }
   if (precision == ANM_SOLVE_F32)
     hipLaunchKernelGGL(mesh::k_mesh<float>, dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   else
@@ -310,6 +305,15 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
       if (e1 == hipSuccess && e2 == hipSuccess &&
           hipMemcpy(m->d_mi, m->mplan.hi.data(), m->mplan.hi.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
         m->mesh_ok = true;
+        if (mesh::lds_bytes(m->mplan.d, mesh::waves_per_block(m->mplan.d)) > 64 * 1024) {
+          // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, here: an
+          // attribute call has no place in a launch path that may be under stream capture)
+          hipError_t a1 = hipFuncSetAttribute((const void*)mesh::k_mesh<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipError_t a2 = hipFuncSetAttribute((const void*)mesh::k_mesh<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (a1 != hipSuccess || a2 != hipSuccess) m->mesh_ok = false;
+        }
+      }
+      if (m->mesh_ok) {
         // default for what neither of the other families serves well: not a tree, and either not the compiled
         // topology or too large for one thread's registers
         if (!m->radial_ok && (!m->tpe_ok || desc->n_bus > 12)) m->impl = ANM_IMPL_MESH;

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <set>
 #include <string>
 #include <vector>
@@ -91,6 +92,10 @@ inline size_t lds_bytes(const Dims& d, int waves) {
 // wavefronts per workgroup (they share one copy of the tables): what puts most wavefronts on a compute unit's
 // 160 KB of LDS, the larger workgroup on a tie
 inline int waves_per_block(const Dims& d) {
+  if (const char* ev = getenv("ANM_MESH_WAVES")) {   // tuning experiments
+    const int w = atoi(ev);
+    if ((w == 1 || w == 2 || w == 4) && lds_bytes(d, w) <= 160 * 1024) return w;
+  }
   int best = 1;
   size_t best_waves = 0;
   for (int w = 1; w <= 4; w *= 2) {

@@ -245,10 +245,13 @@ def test_mesh_anm6easy_episodes():
     assert env.simulator.impl == "mesh"
 
 
-@pytest.mark.parametrize("n_bus,seed,n_chords", [(5, 2, 2), (9, 4, 3), (14, 5, 3), (30, 6, 4), (30, 7, 8), (48, 8, 6), (64, 9, 1)])
+@pytest.mark.parametrize("n_bus,seed,n_chords", [(5, 2, 2), (9, 4, 3), (14, 5, 3), (14, 3, 6), (30, 6, 4), (30, 7, 8), (33, 4, 8), (48, 8, 6), (64, 9, 1),
+                                                 (64, 10, 24)])
 def test_mesh_random_meshed_networks_against_oracle(n_bus, seed, n_chords):
     """Random meshed networks (loops, line charging, a phase-shifting transformer) nobody compiled a library
-    for: generic mode of the general lane-group kernel against the oracle, case by case."""
+    for: generic mode of the general lane-group kernel against the oracle, case by case.  (14, 3, 6), (33, 4, 8),
+    (64, 10, 24): more branches than lanes in the group -- a lane plays two; the last one also needs more than the
+    default 64 KB of LDS per workgroup.)"""
     import anm_oracle as O
     from gym_anm_amd import networks
     from gym_anm_amd.model import NetworkModel
