@@ -1,11 +1,16 @@
 """TEST INFRASTRUCTURE -- CPU oracle for the MPC DC-OPF policy (gym_anm/agents/mpc.py), one environment.
 
-The reference states the N-stage problem with cvxpy and solves it with cvxpy's default solver; neither is
-available in this image, so the reference itself cannot be run for this path: **parity unpinned** with
-respect to the reference's solver.  This module restates the program of ``mpc.py:163-319`` constraint by
-constraint (same variables, same constraint order) as a scipy LP (HiGHS), independently of the product's
-assembly in gym_anm_amd/agents/mpc.py.  cvxpy's ``maximum(0, abs(p) - beta rate)`` terms become epigraph
-variables, the standard LP reformulation cvxpy itself applies.
+This module restates the program of ``mpc.py:163-319`` constraint by constraint (same variables, same constraint
+order) as a scipy LP (HiGHS), independently of the product's assembly in gym_anm_amd/agents/mpc.py.  cvxpy's
+``maximum(0, abs(p) - beta rate)`` terms become epigraph variables, the standard LP reformulation cvxpy itself
+applies.
+
+Pinned (tests/test_mpc.py::test_oracle_program_has_the_value_of_the_reference_program) against
+tests/golden/mpc_anm6.npz: 300 programs built by the UNMODIFIED reference agents in closed loop (perfect and
+constant forecasts, N = 1, 3, 10, 20) -- equal optimal value to 1e-9, and the reference run's first-stage
+minimiser is optimal here too.  What is NOT pinned: cvxpy's default solver (absent from the image; the
+reference's program was solved by HiGHS behind oracle/ref_harness.py's stand-in for cvxpy's modelling API).
+An LP's optimal value does not depend on the solver; its minimiser may, where it is not unique.
 
 Only tests/ import this module.
 """
@@ -13,8 +18,10 @@ import numpy as np
 from scipy.optimize import linprog
 
 
-def solve_dcopf(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N):
+def solve_dcopf(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N, first_stage_p_dev=None):
     """net: anm_oracle.Net.  Forecasts [n_load, N] / [n_gen, N] in p.u. (device-id order), soc0 [n_des] p.u.
+    first_stage_p_dev [D]: additionally fix the first stage's device injections (to test whether a given
+    minimiser of somebody else's statement of the program is optimal for this one).
     Returns dict(objective, P_dev [N, D], theta [N, nb], status)."""
     nb, D, nbr = net.N, net.D, net.B
     loads, gens, des = list(net.loads), list(net.gens), list(net.des)
@@ -91,6 +98,9 @@ def solve_dcopf(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin
                 r[o + TH + f], r[o + TH + t], r[o + S + e] = sgn * B[f, t], -sgn * B[f, t], -1.0
                 A_ub.append(r)
                 b_ub.append(lim)
+    if first_stage_p_dev is not None:
+        for k in range(D):
+            lb[PD + k] = ub[PD + k] = first_stage_p_dev[k]
     res = linprog(c, A_ub=np.array(A_ub), b_ub=np.array(b_ub), A_eq=np.array(A_eq), b_eq=np.array(b_eq),
                   bounds=list(zip(lb, ub)), method="highs")
     x = res.x if res.x is not None else np.full(n, np.nan)
