@@ -196,7 +196,7 @@ struct LaneView {
 // holds, `it` iterations already done.  gvalid (uniform per group): the group holds a solve.  Every lane of
 // the wavefront must call.  On return: the final iterate, `it`, and the group's verdict in tb / tn
 // (tb != 0: ||F||inf > tol or NaN; tn != 0: F has a NaN).
-template <class T, class JT>
+template <class T, class JT, int EARLY_EXIT_TRIPS = 0>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
                                               double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
                                               double tol, int max_iter) {
@@ -221,6 +221,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
     // does, so these zeros are the neutral values the hand-overs rely on.
     Blk<JT> Sc = Blk<JT>{JT(0), JT(0), JT(0), JT(0)};
     JT Lr0 = JT(0), Lr1 = JT(0), d0 = JT(0), d1 = JT(0);
+    [[maybe_unused]] int trip = 0;
     for (;;) {
       const double vr = vm * cs, vi = vm * sn;
       const double vpr = X.from_parent(vr, 1.0), vpi = X.from_parent(vi, 0.0);
@@ -251,9 +252,18 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       runm &= __builtin_amdgcn_uicmp(tb, 0u, ICMP_NE) & ~__builtin_amdgcn_uicmp(tn, 0u, ICMP_NE) &
               __builtin_amdgcn_sicmp(it, max_iter, ICMP_SLT);   // NaN > tol is false, like the reference
       // The loop is left at the END of the trip: the scalar chain compare -> masks -> branch then overlaps the
-      // elimination instead of stalling the wavefront in front of it every trip; the price is one idle
-      // elimination when the last group stops (its update is masked: `runm` is 0).
+      // elimination instead of stalling the wavefront in front of it every trip (what counts for the ~94 trips
+      // of a diverging solve); the price is one idle elimination when the last group stops (its update is
+      // masked: `runm` is 0).  A caller whose whole batch passes through here (anm_radial.hpp: four or five
+      // trips per solve, so an idle elimination is one trip in five) asks for the branch to be taken on the
+      // spot during the first EARLY_EXIT_TRIPS trips.
       const bool all_done = runm == 0ull;
+      if constexpr (EARLY_EXIT_TRIPS > 0) {
+        if (trip < EARLY_EXIT_TRIPS) {
+          if (all_done) break;
+          ++trip;
+        }
+      }
 
       // ---- Jacobian blocks (anm_device.hpp: newton_update): own diagonal and the two couplings with the parent
       Blk<JT> Dg = Blk<JT>{JT(-(si - wbb_i)), JT(sr + wbb_r), JT(sr - wbb_r), JT(si + wbb_i)};

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     double gvm = 1.0, gcs = 1.0, gsn = 0.0;   // flat start (solve_load_flow.py:36-39)
     int git = 0;
     unsigned tb, tn;
-    group::newton_groups<TT, JT>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn, so.tol, so.max_iter);
+    group::newton_groups<TT, JT, 10>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn, so.tol, so.max_iter);
     const int back4 = 4 * (gb + (isbus ? TT::T_POS[l + 1] : l));
     vm = group::bperm(gvm, back4); cs = group::bperm(gcs, back4); sn = group::bperm(gsn, back4);
     // iteration count and verdict are uniform over a group: every lane takes those of the lane playing bus 1
