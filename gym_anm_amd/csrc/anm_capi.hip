@@ -76,9 +76,10 @@ __global__ __launch_bounds__(BLOCK) void k_step_general(cptr_t C0, EnvIO io, Sol
   op_step_general<Topo, JT>(C, io, so, n, lds_dyn);
 }
 
-template <class JT>
+template <class JT, bool GROUPS>
 __global__ __launch_bounds__(BLOCK) void k_step_stragglers(cptr_t C, EnvIO io, SolverOpts so) {
-  op_step_stragglers<Topo, JT>(C, io, so);
+  __shared__ double lds[GROUPS ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
+  op_step_stragglers<Topo, JT, GROUPS>(C, io, so, lds);
 }
 
 __global__ void k_step_scatter(EnvIO io) { op_step_scatter<Topo>(io); }
@@ -831,11 +832,25 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
     if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_rows");
     if (io.ws && io.iter_cap < so.max_iter) {
       // second launch: the handed-over solves, grid-stride over the records (count lives on the device)
-      const unsigned g2 = unsigned((io.ws_cap + BLOCK - 1) / BLOCK);  // covers every record
-      if (prec == ANM_SOLVE_F32)
-        hipLaunchKernelGGL(k_step_stragglers<float>, dim3(g2), dim3(BLOCK), 0, s, C, io, so);
-      else
-        hipLaunchKernelGGL(k_step_stragglers<double>, dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+      // (a tree topology continues them on lane groups, 8 records per wavefront, unless that was switched off)
+      constexpr bool CAN_GROUP = Topo::TREE != 0;
+      const bool groups = CAN_GROUP && so.handoff >= 0;
+      const int per_block = groups ? group::Shape<Topo>::NG : BLOCK;
+      const unsigned g2 = unsigned((io.ws_cap + per_block - 1) / per_block);  // covers every record
+      if constexpr (CAN_GROUP) {
+        if (groups) {
+          if (prec == ANM_SOLVE_F32)
+            hipLaunchKernelGGL((k_step_stragglers<float, true>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+          else
+            hipLaunchKernelGGL((k_step_stragglers<double, true>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+        }
+      }
+      if (!groups) {
+        if (prec == ANM_SOLVE_F32)
+          hipLaunchKernelGGL((k_step_stragglers<float, false>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+        else
+          hipLaunchKernelGGL((k_step_stragglers<double, false>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+      }
       e2 = hipGetLastError();
       if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_stragglers");
       const unsigned g3 = unsigned((io.ws_cap + 255) / 256);

@@ -626,13 +626,16 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
   step_begin<T, JT>(C, C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
   bool pending = false;
-  // in-wave straggler hand-over (anm_group.hpp): tree topologies, not combined with the two-launch mode
+  // in-wave straggler hand-over (anm_group.hpp): tree topologies.  In the two-launch mode the straggler launch
+  // does the continuing (on lane groups as well, op_step_stragglers); only solves that found no record slot
+  // continue here.
   constexpr bool CAN_GROUP = T::TREE != 0 && group::Shape<T>::NG * group::Slot<T>::SIZE <= 64 * (T::SDIM + 2);
   const int handoff = (CAN_GROUP && !two_phase && so.handoff >= 0 && so.handoff < so.max_iter) ? so.handoff : -1;
+  const bool overflow_to_groups = CAN_GROUP && two_phase && so.handoff >= 0 && so.handoff < so.max_iter;
   int cap = two_phase ? io.iter_cap : (handoff >= 0 ? handoff : so.max_iter);
   // One copy of the Newton loop serves both passes (a second inlined copy costs registers and code):
   // pass 0 iterates up to `cap`; in two-launch mode the environments still iterating are then handed
-  // to the straggler launch, and pass 1 only runs for those that found no record slot.
+  // to the straggler launch, and pass 1 only runs for those that found no record slot (thread mode only).
 #pragma nounroll
   for (int pass = 0; pass < 2; ++pass) {
     pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, cap);
@@ -645,12 +648,15 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
         pending = true;
       }
     }
-    if (pending) st.diff = 0.0;  // handed over: this lane's own solve ends here (its outputs are not stored)
+    if (pending) {  // handed over: this lane's own solve ends here (its outputs are not stored)
+      st.diff = 0.0;
+      st.active = false;
+    }
     cap = so.max_iter;
-    if (!ANM_WAVE_ANY(st.active && !pending)) break;  // else: record space exhausted (or a padding lane)
+    if (overflow_to_groups || !ANM_WAVE_ANY(st.active)) break;  // else: record space exhausted (or a padding lane)
   }
   if constexpr (CAN_GROUP) {
-    if (handoff >= 0 && ANM_WAVE_ANY(st.active && valid))
+    if ((handoff >= 0 || overflow_to_groups) && ANM_WAVE_ANY(st.active && valid))
       group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
   }
   step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
@@ -867,9 +873,14 @@ __device__ void op_step_general(cptr_t C, const EnvIO& io, SolverOpts so, int64_
   }
 }
 
-// second launch of the two-phase step: continue the handed-over solves (grid-stride over records)
-template <class T, class JT>
-__device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so) {
+// second launch of the two-phase step: continue the handed-over solves.
+// GROUPS (tree topologies, unless the hand-over to lane groups is switched off): a wavefront takes as many
+// records as it has lane groups (8 for ANM6) and runs them through group::continue_in_groups -- the trip of a
+// lane group is half as long as a thread's, and these solves are the ones that run ~94 more of them; the
+// records of a million environments still fill the chip 8 per wavefront.  Otherwise: 64 records per
+// wavefront, one per thread.
+template <class T, class JT, bool GROUPS>
+__device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so, double* lds) {
   constexpr int S = T::SDIM + 1;
   int* cnt = reinterpret_cast<int*>(io.ws);
   int n_rec = cnt[0];
@@ -878,20 +889,40 @@ __device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so) {
   // next step: every step leaves the counters as it found them (no host-side parity, no memset), which is
   // what makes one captured step replayable from a HIP graph any number of times.
   if (blockIdx.x == 0 && threadIdx.x == 0) cnt[1] = n_rec;
-  // Dense packing: 64 consecutive records per wavefront.  Measured alternatives (MI355X): dealing the
-  // records one per wavefront makes every iteration 2-3x slower once several sparse wavefronts share a
-  // CU (issue stalls, SQ_WAIT_INST_ANY 60 %), although each wave then only runs the sin/cos tier its
-  // own solve needs.  One record per thread, no loop: the Newton loop keeps every value in registers.
-  const int64_t j = int64_t(blockIdx.x) * 64 + threadIdx.x;
-  if (j >= n_rec) return;
   StepCtx<T> ctx;
   PFState<T> st;
   EnvWork<T> w;
   StepOut<T, 1> out;
-  double* r = io.ws + Rec<T>::HEADER + j * Rec<T>::SIZE;
-  const int64_t e = load_record<T>(r, ctx, w, st);
-  st.fresh = true;  // F and diff of the saved iterate are recomputed (same code, same inputs, same bits)
-  pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
+  int64_t j, e = 0;
+  bool mine;
+  if constexpr (GROUPS) {
+    constexpr int NG = group::Shape<T>::NG;
+    const int lane = threadIdx.x & 63;
+    j = int64_t(blockIdx.x) * NG + lane;
+    mine = lane < NG && j < n_rec;
+    if (!ANM_WAVE_ANY(mine)) return;
+  } else {
+    // Dense packing: 64 consecutive records per wavefront.  Measured alternatives (MI355X): dealing the
+    // records one per wavefront makes every thread-mode iteration 2-3x slower once several sparse wavefronts
+    // share a CU (issue stalls, SQ_WAIT_INST_ANY 60 %), although each wave then only runs the sin/cos tier its
+    // own solve needs.  One record per thread, no loop: the Newton loop keeps every value in registers.
+    j = int64_t(blockIdx.x) * 64 + threadIdx.x;
+    mine = j < n_rec;
+    if (!mine) return;
+  }
+  double* r = io.ws + Rec<T>::HEADER + (mine ? j : 0) * Rec<T>::SIZE;
+  if (mine) e = load_record<T>(r, ctx, w, st);
+  if constexpr (GROUPS) {
+    // (the first trip of newton_groups evaluates F of the saved iterate before anything else)
+    st.active = mine;
+    group::continue_in_groups<T, JT>(C, w, st, mine, so.tol, so.max_iter, lds);
+    if (!mine) return;
+    w.vr[0] = 1.0;   // the slack bus: what eval_mismatch leaves there (continue_in_groups restores the others)
+    w.vi[0] = 0.0;
+  } else {
+    st.fresh = true;  // F and diff of the saved iterate are recomputed (same code, same inputs, same bits)
+    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
+  }
   step_end<T, 1>(C, io, so, e, ctx, w, st, out);
   // The results go back into the record (r[0] keeps the environment index); the scatter launch
   // writes them to the batch arrays.  Keeping the dozen output pointers out of this kernel keeps its

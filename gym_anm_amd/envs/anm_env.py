@@ -208,16 +208,19 @@ class BatchedANMEnv(GymEnv):
         self._ws = None
         self._ws_ref = None
         if straggler_after == "auto":
-            # measured on MI355X (scripts/handoff_sweep.py, profiles/r02_*): up to 262 144 environments the in-wave
-            # lane-group hand-over (anm_solver_opts.handoff_after) is the faster cure for stragglers (65 536:
-            # 94 vs 169 us, 262 144: 189 vs 204 us); the two-launch step -- stragglers of the whole batch packed
-            # densely into a second launch -- wins once the batch is several times the 65 536 lanes of the chip
-            # (1 M: 328 vs 495 us with the reference's cap; a tie with a cap of 20)
-            big = 524288 if int(max_iter) >= 50 else 1048576
+            # measured on MI355X (scripts/handoff_sweep.py, profiles/r02_d_handoff_sweep.txt): at 65 536
+            # environments the in-wave lane-group hand-over (anm_solver_opts.handoff_after) is the faster cure for
+            # stragglers (92 vs 114 us); the two-launch step -- stragglers of the whole batch packed into a second
+            # launch, 8 per wavefront on lane groups -- wins once the batch is a multiple of the 65 536 lanes of the
+            # chip (reference cap: 131 072: 121 vs 138 us, 262 144: 146 vs 183 us, 524 288: 193 vs 287 us, 1 M: 318
+            # vs 484 us; with a cap of 20 the in-wave hand-over wins or ties up to 524 288, 1 M: 230 vs 239 us)
+            big = 131072 if int(max_iter) >= 50 else 1048576
             straggler_after = 6 if self.num_envs >= big else None
         rec = sim.backend.lib.anm_step_ws_record_doubles()
         if self._aux_index is not None and straggler_after and rec > 0 and int(straggler_after) < int(max_iter):
-            n_rec = min(self.num_envs, 1 << 18)
+            # records for 1/16 of the batch (~1.5 % of the solves are still running after 6 iterations; a solve
+            # that finds no record continues on a lane group of its own wavefront)
+            n_rec = min(self.num_envs, max(4096, self.num_envs // 16))
             self._ws_buf = torch.zeros(8 + n_rec * rec, dtype=torch.float64, device=self.device)
             self._ws = _lib.StepWs(self._ws_buf.data_ptr(), self._ws_buf.numel(), int(straggler_after), 0)
             self._ws_ref = C.byref(self._ws)

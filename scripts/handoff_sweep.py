@@ -30,7 +30,8 @@ for E in sizes:
                          ("handoff@6", dict(handoff_after=6, straggler_after=None)),
                          ("handoff@8", dict(handoff_after=8, straggler_after=None)),
                          ("handoff@10", dict(handoff_after=10, straggler_after=None)),
-                         ("two-launch@6", dict(handoff_after=None, straggler_after=6)),
+                         ("two-launch@6 threads", dict(handoff_after=None, straggler_after=6)),
+                         ("two-launch@6 groups", dict(handoff_after=6, straggler_after=6)),
                          ("auto", dict())):
             cols.append("%s %7.1f" % (name, run(E, cap, **kw)))
         print("E=%8d cap=%3d us/step:  %s" % (E, cap, "   ".join(cols)), flush=True)

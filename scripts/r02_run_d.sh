@@ -1,7 +1,9 @@
 #!/bin/bash
-# small refresh after stage c: the configurations the early-exit change touches
+# refresh after stage c: what the early-exit change and the lane-group straggler launch touch
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+( time timeout 1200 python -m pytest tests -m gpu -q ) > gpurun_out/r02_d_pytest_gpu.txt 2>&1; tail -4 gpurun_out/r02_d_pytest_gpu.txt
 ( timeout 300 python scripts/bench_case30_quick.py; timeout 200 python scripts/classes_bench.py ) 2>&1 | grep -v amdgpu > gpurun_out/r02_d_case30.txt
+timeout 500 python scripts/handoff_sweep.py 65536 131072 262144 524288 1048576 2>&1 | grep -v amdgpu > gpurun_out/r02_d_handoff_sweep.txt
 timeout 300 python bench.py --steps 200 --warmup 20 > gpurun_out/r02_d_bench.json.log 2>&1
-cat gpurun_out/r02_d_case30.txt; tail -c 300 gpurun_out/r02_d_bench.json.log
+cat gpurun_out/r02_d_case30.txt gpurun_out/r02_d_handoff_sweep.txt; grep -o '"ms_per_step": [0-9.]*\|"kernel_ms[a-z_]*": [0-9.]*' gpurun_out/r02_d_bench.json.log

@@ -554,6 +554,40 @@ def test_two_phase_step_is_bit_identical(cap_after, small_workspace):
     assert n_term > 100  # the workload did produce diverging solves
 
 
+@pytest.mark.parametrize("small_workspace", [False, True])
+def test_two_phase_step_with_lane_group_stragglers_equals_the_in_wave_hand_over(small_workspace):
+    """With the lane-group continuation on (the default), the straggler launch of the two-launch step runs its
+    records on lane groups, 8 per wavefront.  Handed over after the same number of iterations, these are the
+    very solves the one-launch step continues on lane groups of their own wavefront -- same code, same inputs:
+    bit-identical results, also when the workspace overflows (the rest then continues in-wave)."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 65536
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=11, autoreset=True, tol=1e-6, straggler_after=sa, handoff_after=6)
+            for sa in (None, 6)]  # fmt: skip
+    assert envs[0]._ws is None and envs[1]._ws is not None
+    if small_workspace:
+        rec = envs[1].simulator.backend.lib.anm_step_ws_record_doubles()
+        envs[1]._ws.n_doubles = 8 + 100 * rec
+    for env in envs:
+        env.check_actions = False
+        env.reset(seed=11)
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    lo = torch.as_tensor(envs[0].action_space.low, device=DEV)
+    hi = torch.as_tensor(envs[0].action_space.high, device=DEV)
+    n_term = 0
+    for t in range(8):
+        a = lo + (hi - lo) * torch.rand((E_, 6), generator=gen, dtype=torch.float64, device=DEV)
+        (o0, r0, t0, _, _), (o1, r1, t1, _, _) = [env.step(a) for env in envs]
+        n_term += int(t0.sum())
+        for x0, x1 in ((o0, o1), (r0, r1), (t0, t1), (envs[0].state, envs[1].state), (envs[0].e_loss, envs[1].e_loss),
+                       (envs[0].penalty, envs[1].penalty), (envs[0].simulator.soc, envs[1].simulator.soc),
+                       (envs[0].simulator.nr_iters, envs[1].simulator.nr_iters), (envs[0].timestep, envs[1].timestep),
+                       (envs[0]._reset_count, envs[1]._reset_count), (envs[0]._aux_index, envs[1]._aux_index)):  # fmt: skip
+            assert torch.equal(x0, x1), t
+    assert n_term > 100
+
+
 def test_long_run_invariants():
     """3 000 steps of 65 536 autoresetting environments under a random agent: observations stay finite
     and inside the Box, rewards inside the clipping range, every environment keeps cycling through
