@@ -207,9 +207,9 @@ def test_track_full_follows_the_steps():
         assert torch.equal(plain.pfe_converged, ~term)
 
 
-@pytest.mark.parametrize("impl", ["thread", "radial"])
+@pytest.mark.parametrize("impl", ["thread", "radial", "mesh"])
 def test_heterogeneous_networks_64_parameter_classes(impl):
-    """64 distinct networks in one batch of 4096 environments, both kernel families, against the oracle."""
+    """64 distinct networks in one batch of 4096 environments, every kernel family, against the oracle."""
     sim = pc.heterogeneous_networks(KW, impl=impl)
     assert sim.impl == impl and len(sim.variant_models) == 64
 
