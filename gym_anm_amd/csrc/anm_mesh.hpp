@@ -375,7 +375,11 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   }
   d.n_m = n_m;
   d.l_dev = d.l_m + std::max(4 * n_m, 4 * d.NBR);
-  d.lds_per_env = (d.l_dev + 2 * d.ND + 1) | 1;
+  // 16-byte aligned (blocks and vector pairs move as ds_read_b128 / ds_write_b128), and = 2 (mod 4) doubles: the
+  // environments of a wavefront execute the same descriptors, so their areas must not start on the same banks --
+  // with this size equal offsets of neighbouring environments are 4 banks (one b128 access) apart
+  d.lds_per_env = d.l_dev + 2 * d.ND + 1;
+  while (d.lds_per_env % 4 != 2) ++d.lds_per_env;
   if (d.lds_per_env >= 65536) { err = "network too large for the general lane-group kernel (LDS)"; return false; }
   for (auto& st : steps)
     for (Desc& q : st)
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
                                               SolverOpts so, int64_t n_env, ClassSel cls) {
   // a workgroup = 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet: a lane
   // group lies within one wavefront, whose LDS operations complete in program order (fences only)
-  extern __shared__ double sh_dyn[];
+  extern __shared__ __align__(16) double sh_dyn[];
   const int t = threadIdx.x;
   const int G = d.G;
   const int l = t & (G - 1);
@@ -626,8 +630,18 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
     double* p = LBLK + 4 * b;
     p[0] = a; p[1] = bb; p[2] = c; p[3] = dd;
   };
-  auto ld4 = [&](int o) { const double* p = S + o; return Blk<JT>{JT(p[0]), JT(p[1]), JT(p[2]), JT(p[3])}; };
-  auto st4 = [&](int o, const Blk<JT>& m) { double* p = S + o; p[0] = double(m.a); p[1] = double(m.b); p[2] = double(m.c); p[3] = double(m.d); };
+  // blocks and (x0, x1) pairs sit at even offsets of a 16-byte aligned area: 128-bit LDS accesses (half the bank
+  // conflicts of 64-bit ones on these 32-byte-strided gathers)
+  auto ld2 = [&](int o) { return *reinterpret_cast<const double2*>(S + o); };
+  auto st2 = [&](int o, double a, double b) { *reinterpret_cast<double2*>(S + o) = double2{a, b}; };
+  auto ld4 = [&](int o) {
+    const double2 lo = ld2(o), hi = ld2(o + 2);
+    return Blk<JT>{JT(lo.x), JT(lo.y), JT(hi.x), JT(hi.y)};
+  };
+  auto st4 = [&](int o, const Blk<JT>& m) {
+    st2(o, double(m.a), double(m.b));
+    st2(o + 2, double(m.c), double(m.d));
+  };
   // the step program (see OpKind): descriptor and type of the next step are fetched while this one runs
   const int4* prog = reinterpret_cast<const int4*>(tab + (d.off_desc - d.off_lists));
   const int* stype = tab + (d.off_stype - d.off_lists);
@@ -724,30 +738,33 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
         }
       } else if ((ty & 0xff) == ST_BACK) {
         if (kind != OP_NONE) {
-          JT a0 = JT(S[o1]), a1 = JT(S[o1 + 2]);
+          const Blk<JT> Rk = ld4(o1);
+          JT a0 = Rk.a, a1 = Rk.c;
           Blk<JT> Di = ld4(o2);
           const Blk<JT> A0 = ld4(o4), A1 = ld4(o6);
-          const JT x00 = JT(S[o5]), x01 = JT(S[o5 + 1]), x10 = JT(S[o7]), x11 = JT(S[o7 + 1]);
+          const double2 xa = ld2(o5), xb = ld2(o7);
+          const JT x00 = JT(xa.x), x01 = JT(xa.y), x10 = JT(xb.x), x11 = JT(xb.y);
           if (kind == OP_INVBACK) Di = blk_inv(Di);
           a0 = fm(-A0.b, x01, fm(-A0.a, x00, a0));
           a1 = fm(-A0.d, x01, fm(-A0.c, x00, a1));
           a0 = fm(-A1.b, x11, fm(-A1.a, x10, a0));
           a1 = fm(-A1.d, x11, fm(-A1.c, x10, a1));
-          S[o3] = double(fm(Di.a, a0, Di.b * a1));
-          S[o3 + 1] = double(fm(Di.c, a0, Di.d * a1));
+          st2(o3, double(fm(Di.a, a0, Di.b * a1)), double(fm(Di.c, a0, Di.d * a1)));
         }
       } else {
         if (kind != OP_NONE) {
-          JT a0 = JT(S[o1]), a1 = JT(S[o1 + 2]);
+          const Blk<JT> Rk = ld4(o1);
+          JT a0 = Rk.a, a1 = Rk.c;
           const Blk<JT> A0 = ld4(o2), A1 = ld4(o4), A2 = ld4(o6);
-          const JT x00 = JT(S[o3]), x01 = JT(S[o3 + 1]), x10 = JT(S[o5]), x11 = JT(S[o5 + 1]), x20 = JT(S[o7]), x21 = JT(S[o7 + 1]);
+          const double2 xa = ld2(o3), xb = ld2(o5), xc = ld2(o7);
+          const JT x00 = JT(xa.x), x01 = JT(xa.y), x10 = JT(xb.x), x11 = JT(xb.y), x20 = JT(xc.x), x21 = JT(xc.y);
           a0 = fm(-A0.b, x01, fm(-A0.a, x00, a0));
           a1 = fm(-A0.d, x01, fm(-A0.c, x00, a1));
           a0 = fm(-A1.b, x11, fm(-A1.a, x10, a0));
           a1 = fm(-A1.d, x11, fm(-A1.c, x10, a1));
           a0 = fm(-A2.b, x21, fm(-A2.a, x20, a0));
           a1 = fm(-A2.d, x21, fm(-A2.c, x20, a1));
-          S[o1] = double(a0); S[o1 + 2] = double(a1);
+          st4(o1, Blk<JT>{a0, Rk.b, a1, Rk.d});
         }
       }
       ANM_MESH_SYNC();
