@@ -196,11 +196,26 @@ struct LaneView {
 // holds, `it` iterations already done.  gvalid (uniform per group): the group holds a solve.  Every lane of
 // the wavefront must call.  On return: the final iterate, `it`, and the group's verdict in tb / tn
 // (tb != 0: ||F||inf > tol or NaN; tn != 0: F has a NaN).
-template <class T, class JT, int EARLY_EXIT_TRIPS = 0>
+// LDSX (trees without a DPP plan; xl: 10 arrays of 64 doubles private to the wavefront): the hand-overs go
+// through LDS -- a lane PUBLISHES what its parent (or its children) will need in its own slot of an array, the
+// consumer reads the slot of the lane it needs -- instead of ds_bpermute: a pair of doubles is one
+// ds_write2/ds_read2 instead of four bpermutes, and the 5 child slots x 6 values of a bushy level cost 15 reads
+// instead of 60 bpermutes.  Padding lanes never publish; their slots hold the neutral values (zeroed here, V = 1).
+template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
                                               double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
-                                              double tol, int max_iter) {
+                                              double tol, int max_iter, double* xl = nullptr) {
   const Lanes<T>& X = V.X;
+  static_assert(!LDSX || T::T_DPP == 0, "LDS hand-overs are the alternative to ds_bpermute, not to DPP moves");
+  [[maybe_unused]] const int wl = threadIdx.x & 63;
+  [[maybe_unused]] const int pl = X.psrc4 >> 2;                       // lane of the parent (or a padding lane)
+  [[maybe_unused]] int cl[T::T_MAXCH > 0 ? T::T_MAXCH : 1];           // lanes of the children (or a padding lane)
+  static_for<0, T::T_MAXCH>([&](auto Cc) { cl[Cc] = X.csrc4[Cc] >> 2; });
+  enum { XA_V = 0, XA_W = 2, XA_SC = 4, XA_LR = 8 };                  // V and the Newton step share arrays 0, 1
+  if constexpr (LDSX) {
+    static_for<XA_W, XA_LR + 2>([&](auto A) { xl[A * 64 + wl] = 0.0; });
+    ANM_WAVE_SYNC();
+  }
   const int height = V.height, depth = V.depth, nch = V.nch;
   const double ybb_r = V.ybb_r, ybb_i = V.ybb_i, ybp_r = V.ybp_r, ybp_i = V.ybp_i, ypb_r = V.ypb_r, ypb_i = V.ypb_i;
   const unsigned long long gmask = V.gmask;
@@ -224,7 +239,14 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
     [[maybe_unused]] int trip = 0;
     for (;;) {
       const double vr = vm * cs, vi = vm * sn;
-      const double vpr = X.from_parent(vr, 1.0), vpi = X.from_parent(vi, 0.0);
+      double vpr, vpi;
+      if constexpr (LDSX) {
+        xl[XA_V * 64 + wl] = vr; xl[(XA_V + 1) * 64 + wl] = vi;
+        ANM_WAVE_SYNC();
+        vpr = xl[XA_V * 64 + pl]; vpi = xl[(XA_V + 1) * 64 + pl];
+      } else {
+        vpr = X.from_parent(vr, 1.0); vpi = X.from_parent(vi, 0.0);
+      }
       // W_bb = conj(Y_bb) vm^2;  P = V_b conj(V_p):  W_bp = conj(Y_bp) P,  W_pb = conj(Y_pb) conj(P)
       const double m2 = vm * vm;
       const double wbb_r = ybb_r * m2, wbb_i = -(ybb_i * m2);
@@ -233,8 +255,17 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       const double wpb_r = fma(ypb_r, pr, -(ypb_i * pim)), wpb_i = -fma(ypb_r, pim, ypb_i * pr);
       // S_b = W_bb + W_bp + sum over the children c of W_pb(c)
       double sr = wbb_r + wbp_r, si = wbb_i + wbp_i;
+      if constexpr (LDSX) {
+        xl[XA_W * 64 + wl] = wpb_r; xl[(XA_W + 1) * 64 + wl] = wpb_i;
+        ANM_WAVE_SYNC();
+      }
       static_for<0, T::T_MAXCH>([&](auto Cc) {
-        const double cr = X.template from_child<Cc>(wpb_r), ci = X.template from_child<Cc>(wpb_i);
+        double cr, ci;
+        if constexpr (LDSX) {
+          cr = xl[XA_W * 64 + cl[Cc]]; ci = xl[(XA_W + 1) * 64 + cl[Cc]];
+        } else {
+          cr = X.template from_child<Cc>(wpb_r); ci = X.template from_child<Cc>(wpb_i);
+        }
         if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
           sr += cr;
           si += ci;
@@ -279,9 +310,16 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         JT ga[NC > 0 ? NC : 1], gbb[NC > 0 ? NC : 1], gc[NC > 0 ? NC : 1], gd[NC > 0 ? NC : 1], g0[NC > 0 ? NC : 1],
             g1[NC > 0 ? NC : 1];
         static_for<0, NC>([&](auto Cc) {
-          ga[Cc] = X.template from_child<Cc>(Sc.a); gbb[Cc] = X.template from_child<Cc>(Sc.b);
-          gc[Cc] = X.template from_child<Cc>(Sc.c); gd[Cc] = X.template from_child<Cc>(Sc.d);
-          g0[Cc] = X.template from_child<Cc>(Lr0); g1[Cc] = X.template from_child<Cc>(Lr1);
+          if constexpr (LDSX) {
+            const int c = cl[Cc];
+            ga[Cc] = JT(xl[XA_SC * 64 + c]); gbb[Cc] = JT(xl[(XA_SC + 1) * 64 + c]);
+            gc[Cc] = JT(xl[(XA_SC + 2) * 64 + c]); gd[Cc] = JT(xl[(XA_SC + 3) * 64 + c]);
+            g0[Cc] = JT(xl[XA_LR * 64 + c]); g1[Cc] = JT(xl[(XA_LR + 1) * 64 + c]);
+          } else {
+            ga[Cc] = X.template from_child<Cc>(Sc.a); gbb[Cc] = X.template from_child<Cc>(Sc.b);
+            gc[Cc] = X.template from_child<Cc>(Sc.c); gd[Cc] = X.template from_child<Cc>(Sc.d);
+            g0[Cc] = X.template from_child<Cc>(Lr0); g1[Cc] = X.template from_child<Cc>(Lr1);
+          }
         });
         if (height == h) {
           static_for<0, NC>([&](auto Cc) {
@@ -296,16 +334,26 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
             Sc = blk_mul(Lk, Jbp);
             Lr0 = fm(Lk.a, r0, Lk.b * r1);
             Lr1 = fm(Lk.c, r0, Lk.d * r1);
+            if constexpr (LDSX) {
+              xl[XA_SC * 64 + wl] = double(Sc.a); xl[(XA_SC + 1) * 64 + wl] = double(Sc.b);
+              xl[(XA_SC + 2) * 64 + wl] = double(Sc.c); xl[(XA_SC + 3) * 64 + wl] = double(Sc.d);
+              xl[XA_LR * 64 + wl] = double(Lr0); xl[(XA_LR + 1) * 64 + wl] = double(Lr1);
+            }
           }
         }
+        if constexpr (LDSX && h < T::T_MAXH) ANM_WAVE_SYNC();
       });
       // ---- back substitution by depth (Dg now holds the inverted pivots)
       static_for<0, T::T_MAXD + 1>([&](auto Dd) {
         constexpr int dd = Dd;
         JT p0 = JT(0), p1 = JT(0);
         if constexpr (dd > 0) {
-          p0 = X.from_parent(d0, JT(0));
-          p1 = X.from_parent(d1, JT(0));
+          if constexpr (LDSX) {
+            p0 = JT(xl[XA_V * 64 + pl]); p1 = JT(xl[(XA_V + 1) * 64 + pl]);
+          } else {
+            p0 = X.from_parent(d0, JT(0));
+            p1 = X.from_parent(d1, JT(0));
+          }
         }
         if (depth == dd) {
           JT a0 = r0, a1 = r1;
@@ -315,7 +363,9 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           }
           d0 = fm(Dg.a, a0, Dg.b * a1);
           d1 = fm(Dg.c, a0, Dg.d * a1);
+          if constexpr (LDSX && dd < T::T_MAXD) { xl[XA_V * 64 + wl] = double(d0); xl[(XA_V + 1) * 64 + wl] = double(d1); }
         }
+        if constexpr (LDSX && dd < T::T_MAXD) ANM_WAVE_SYNC();
       });
       // ---- update of the running groups; d1 is the relative magnitude step.  Rotation of (cos, sin) by the
       // angle step, path chosen per wavefront exactly as update_angles does (the reduction of a small step

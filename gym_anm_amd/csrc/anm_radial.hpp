@@ -425,7 +425,10 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     double gvm = 1.0, gcs = 1.0, gsn = 0.0;   // flat start (solve_load_flow.py:36-39)
     int git = 0;
     unsigned tb, tn;
-    group::newton_groups<TT, JT, 10>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn, so.tol, so.max_iter);
+    // (trees without a DPP plan hand over through the LDS arrays the table-driven loop would use)
+    static_assert(A_N >= 10, "group::newton_groups<.., LDSX> takes 10 arrays of 64 doubles");
+    group::newton_groups<TT, JT, 10, TT::T_DPP == 0>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn, so.tol,
+                                                      so.max_iter, &sh[0][0]);
     const int back4 = 4 * (gb + (isbus ? TT::T_POS[l + 1] : l));
     vm = group::bperm(gvm, back4); cs = group::bperm(gcs, back4); sn = group::bperm(gsn, back4);
     // iteration count and verdict are uniform over a group: every lane takes those of the lane playing bus 1
