@@ -61,11 +61,16 @@ constexpr int BR_SLOTS = 2;
 //   step ST_BACK  OP_BACK (pivot k)    s1 = r_k, s2 = D_k^-1, s3 = x_k, (s4, s5), (s6, s7) = (A_kj, x_j) of two later buses
 //                 OP_INVBACK           the same for a bus nothing was eliminated into: s2 = D_k itself
 //   step ST_ACC   OP_ACC  (pivot k)    s1 = r_k (-= A_kj x_j for (s2, s3), (s4, s5), (s6, s7)): buses with more than two
+//   step ST_TAIL  OP_TAIL2 (a, b)      the last two buses of the order when each is alone in its level: ONE lane
+//                                      eliminates a into b and solves both -- one step instead of the four
+//                                      (products, sums, two back substitutions) the last two levels would take.
+//                                      s1 = D_a, s2 = A_ab, s3 = A_ba, s4 = D_b, s5 = r_a, s6 = r_b (x_a, x_b: where
+//                                      the r's index says)
 // s0 = the operation (0: the lane idles in this step).  Nothing a step reads is written in the same step, and
 // D_k, A_ik, A_kj stay as they are (the factor L_ik = A_ik D_k^-1 is never stored: every product recomputes it,
 // lanes are plentiful), so the operations of a level may be dealt to the lanes in any number of rounds.
-enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_BACK, OP_INVBACK, OP_ACC };
-enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_BACK = 2, ST_ACC = 3 };
+enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_BACK, OP_INVBACK, OP_ACC, OP_TAIL2 };
+enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_BACK = 2, ST_ACC = 3, ST_TAIL = 4 };
 enum DField : int { DF_YII_RE = 0, DF_YII_IM, DF_VMIN, DF_VMAX, DF_YFT_RE, DF_YFT_IM, DF_YTF_RE, DF_YTF_IM, DF_BRC,
                     DF_BR_FIELDS = DF_BRC + 9 - DF_YFT_RE, DF_COUNT = DF_YFT_RE + 2 * DF_BR_FIELDS };
 
@@ -297,7 +302,15 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   std::vector<std::vector<int>> piv(d.n_levels);
   for (int k : order) piv[level[k]].push_back(k);
   int n_m = 0;
+  // the last two buses of the order, each alone in its level (the second-to-last is then coupled to the last only)
+  int tail_a = -1, tail_b = -1;
+  if (!getenv("ANM_MESH_NO_TAIL") && d.n_levels >= 2 && piv[d.n_levels - 1].size() == 1 && piv[d.n_levels - 2].size() == 1 &&
+      upper[piv[d.n_levels - 2][0]].size() == 1 && upper[piv[d.n_levels - 2][0]][0] == piv[d.n_levels - 1][0]) {
+    tail_a = piv[d.n_levels - 2][0];
+    tail_b = piv[d.n_levels - 1][0];
+  }
   for (int lv = 0; lv < d.n_levels; ++lv) {
+    if (tail_a >= 0 && lv >= d.n_levels - 2) continue;   // folded into the ST_TAIL step
     // destinations (block (i, j); j == NB: r_i) and, in pivot order, who contributes to them
     struct Contribution { int i, k, j; };
     std::vector<std::pair<int, int>> dsts;
@@ -349,7 +362,12 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
         for (size_t u = q; u < std::min(sums[r].size(), q + G); ++u) steps[st].push_back(sums[r][u]);
       }
   }
-  for (int lv = d.n_levels - 1; lv >= 0; --lv) {
+  if (tail_a >= 0) {
+    const int st = new_step(ST_TAIL);
+    steps[st].push_back(Desc{OP_TAIL2, oB + 4 * blk[tail_a][tail_a], oB + 4 * blk[tail_a][tail_b], oB + 4 * blk[tail_b][tail_a],
+                             oB + 4 * blk[tail_b][tail_b], oR + 4 * tail_a, oR + 4 * tail_b, 0});
+  }
+  for (int lv = d.n_levels - 1 - (tail_a >= 0 ? 2 : 0); lv >= 0; --lv) {
     // x_k = D_k^-1 (r_k - sum over the later buses j of A_kj x_j): two terms ride with the final operation, the
     // others are subtracted from r_k first, three per step, in the order of upper[k]
     size_t max_acc = 0;
@@ -735,6 +753,19 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
             Z.a -= M3.a; Z.b -= M3.b; Z.c -= M3.c; Z.d -= M3.d;
           }
           st4(o1, Z);
+        }
+      } else if ((ty & 0xff) == ST_TAIL) {
+        if (kind != OP_NONE) {
+          const Blk<JT> Dai = blk_inv(ld4(o1)), Aab = ld4(o2), Ra = ld4(o5), Rb = ld4(o6);
+          const Blk<JT> L = blk_mul(ld4(o3), Dai);
+          Blk<JT> Db = ld4(o4);
+          blk_submul(Db, L, Aab);
+          const JT rb0 = fm(-L.b, Ra.c, fm(-L.a, Ra.a, Rb.a)), rb1 = fm(-L.d, Ra.c, fm(-L.c, Ra.a, Rb.c));
+          const Blk<JT> Dbi = blk_inv(Db);
+          const JT xb0 = fm(Dbi.a, rb0, Dbi.b * rb1), xb1 = fm(Dbi.c, rb0, Dbi.d * rb1);
+          const JT a0 = fm(-Aab.b, xb1, fm(-Aab.a, xb0, Ra.a)), a1 = fm(-Aab.d, xb1, fm(-Aab.c, xb0, Ra.c));
+          st2(d.l_x + ((o6 - d.l_r) >> 1), double(xb0), double(xb1));
+          st2(d.l_x + ((o5 - d.l_r) >> 1), double(fm(Dai.a, a0, Dai.b * a1)), double(fm(Dai.c, a0, Dai.d * a1)));
         }
       } else if ((ty & 0xff) == ST_BACK) {
         if (kind != OP_NONE) {

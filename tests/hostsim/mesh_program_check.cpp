@@ -70,7 +70,8 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
       if (kind == 0) continue;
       // an operation may only ride in a step of its own type
       const int want = (kind == mesh::OP_PROD) ? mesh::ST_PROD : (kind == mesh::OP_SUM) ? mesh::ST_SUM
-                       : (kind == mesh::OP_BACK || kind == mesh::OP_INVBACK) ? mesh::ST_BACK : mesh::ST_ACC;
+                       : (kind == mesh::OP_BACK || kind == mesh::OP_INVBACK) ? mesh::ST_BACK
+                       : (kind == mesh::OP_TAIL2) ? mesh::ST_TAIL : mesh::ST_ACC;
       if (want != ty) return -5;
       if (ty == mesh::ST_PROD) {
         double D[4], Di[4], Aik[4], L[4], X[4], M[4];
@@ -79,6 +80,19 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
         if (o4 < d.l_m || o4 + 4 > d.l_m + 4 * d.n_m) return -6;
         product_written[o4] = 1;
         if (o5) for (int u = 0; u < 4; ++u) writes.push_back(W{o5 + u, Di[u]});
+      } else if (ty == mesh::ST_TAIL) {
+        double Da[4], Dai[4], Aab[4], Aba[4], Db[4], Dbi[4], L[4], M[4];
+        ld4(o1, Da); inv(Da, Dai); ld4(o2, Aab); ld4(o3, Aba); ld4(o4, Db);
+        mul(Aba, Dai, L); mul(L, Aab, M);
+        for (int u = 0; u < 4; ++u) Db[u] -= M[u];
+        const double ra0 = S[o5], ra1 = S[o5 + 2];
+        const double rb0 = S[o6] - (L[0] * ra0 + L[1] * ra1), rb1 = S[o6 + 2] - (L[2] * ra0 + L[3] * ra1);
+        inv(Db, Dbi);
+        const double xb0 = Dbi[0] * rb0 + Dbi[1] * rb1, xb1 = Dbi[2] * rb0 + Dbi[3] * rb1;
+        const double a0 = ra0 - (Aab[0] * xb0 + Aab[1] * xb1), a1 = ra1 - (Aab[2] * xb0 + Aab[3] * xb1);
+        const int xb = d.l_x + ((o6 - d.l_r) >> 1), xa = d.l_x + ((o5 - d.l_r) >> 1);
+        writes.push_back(W{xb, xb0}); writes.push_back(W{xb + 1, xb1});
+        writes.push_back(W{xa, Dai[0] * a0 + Dai[1] * a1}); writes.push_back(W{xa + 1, Dai[2] * a0 + Dai[3] * a1});
       } else if (ty == mesh::ST_SUM) {
         if (run < 1 || run > 4 || o6 > run) return -2;   // o6: how many products this lane really has
         double Z[4];
