@@ -645,7 +645,7 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
   if (impl == ANM_IMPL_RADIAL && !m->radial_ok)
     return fail("the lane-group kernel needs a radial (tree) network with at most 64 buses and devices");
   if (impl == ANM_IMPL_MESH && !m->mesh_ok)
-    return fail("the general lane-group kernel needs a network of at most 65 buses, 64 branches, 64 devices");
+    return fail("the general lane-group kernel needs a network of at most 65 buses, 128 branches, 64 devices");
   if (impl != ANM_IMPL_THREAD && impl != ANM_IMPL_RADIAL && impl != ANM_IMPL_MESH)
     return fail("anm_model_set_impl: unknown implementation");
   if (impl == ANM_IMPL_THREAD && !m->tpe_ok)

@@ -115,7 +115,7 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg);
 #define ANM_IMPL_RADIAL 1
 /*   ANM_IMPL_MESH    the same lane-group mapping for ANY topology (loops, several feeders off the slack): the
  *                    2x2-block Jacobian lives in LDS and is eliminated level by level with the static
- *                    minimum-degree order computed at anm_model_create; networks up to 65 buses / 64 branches /
+ *                    step program scheduled at anm_model_create; networks up to 65 buses / 128 branches /
  *                    64 devices (default for non-radial networks above 12 buses, and for non-radial networks
  *                    no library was compiled for). */
 #define ANM_IMPL_MESH 2
@@ -192,7 +192,11 @@ int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, cons
  * A diverging Newton solve runs to the iteration cap while the 63 other environments of its
  * wavefront finished long ago.  With a workspace the step is two launches: the first stops after
  * `iter_cap` iterations and hands the environments that are still iterating over (one record each),
- * the second continues only those, densely packed, with the same code (bit-identical results).
+ * the second continues only those, packed: on lane groups, one lane per bus and 8 records per wavefront
+ * for ANM6 (tree topologies with the hand-over of anm_solver_opts.handoff_after enabled: the very code the
+ * one-launch step continues its stragglers with, so both give bit-identical results when iter_cap ==
+ * handoff_after), else one record per thread (bit-identical to the one-launch step without hand-over).
+ * An environment that finds no free record is finished by the first launch itself.
  * buf: device memory, zero-initialised once by the caller; n_doubles >= 8 + records * record size
  * (anm_step_ws_record_doubles()).  Every step leaves the record counters at the head of the buffer as
  * it found them (the last launch of a step zeroes the count), so a captured step can be replayed from
