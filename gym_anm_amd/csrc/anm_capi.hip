@@ -580,7 +580,8 @@ int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
 static unsigned magic_div(int d) { return d > 0 ? unsigned((0x100000000ull + uint64_t(d) - 1) / uint64_t(d)) : 0u; }
 
 int anm_model_obs_fusable(const anm_model* m) {
-  return (m && m->tpe_ok && GenLds<Topo>::FULL_OK) ? 1 : 0;
+  // (only the thread-per-environment step kernel gathers; the lane-group families write state / obs = clip(state))
+  return (m && m->tpe_ok && m->impl == ANM_IMPL_THREAD && GenLds<Topo>::FULL_OK) ? 1 : 0;
 }
 
 int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const double* scale, const double* low,
@@ -650,6 +651,9 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
     return fail("anm_model_set_impl: unknown implementation");
   if (impl == ANM_IMPL_THREAD && !m->tpe_ok)
     return fail("this library was compiled for another topology: only the generic lane-group kernel is available");
+  if (impl != ANM_IMPL_THREAD && m->n_obs > 0)
+    return fail("anm_model_set_impl: a list-form observation is gathered inside the thread-per-environment step kernel "
+                "(anm_model_set_obs); clear it before switching to a lane-group kernel");
   m->impl = impl;
   return 0;
 }

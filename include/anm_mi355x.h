@@ -249,8 +249,9 @@ int anm_gather_obs_f64(int64_t num_envs, int32_t full_dim, const double* full, i
  * for i < full_dim and aux variable i - full_dim beyond it.  Only the quantity classes the list names are
  * computed (no magnitude / angle that nobody observes), nothing is dumped to memory and no second launch
  * runs.  index/scale/low/high are HOST arrays of n_obs entries (copied).  n_obs = 0 restores the "state"
- * observation obs = clip(state).  anm_model_obs_fusable: 1 when the model supports this (its electrical
- * state rows fit in LDS), else use `full` + anm_gather_obs_f64.  anm_reset_f64 is not affected. */
+ * observation obs = clip(state).  anm_model_obs_fusable: 1 when the model supports this (implementation
+ * ANM_IMPL_THREAD and its electrical state rows fit in LDS), else use `full` + anm_gather_obs_f64; while a list
+ * is set, anm_model_set_impl refuses the lane-group implementations.  anm_reset_f64 is not affected. */
 int anm_model_obs_fusable(const anm_model* m);
 int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const double* scale, const double* low,
                       const double* high);

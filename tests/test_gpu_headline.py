@@ -79,6 +79,12 @@ def test_callable_observation_and_two_aux_variables():
     pc.callable_observation_and_two_aux(KW)
 
 
+def test_reference_custom_obs_space_known_answers():
+    """tests/envs/custom_obs_space.py of the reference, on the HIP path (the 3-bus chain is served by the general
+    lane-group kernel or a compiled library, whichever the loader picks)."""
+    pc.reference_custom_obs_space(KW)
+
+
 def test_next_vars_of_the_wrong_size_is_refused():
     from gym_anm_amd import errors, networks
     from gym_anm_amd.envs.anm_env import BatchedANMEnv
@@ -147,6 +153,15 @@ def test_all_state_variables_observation(fuse):
     and by the separate gather kernel from the dump: both against the golden transitions."""
     env = pc.all_state_variables_observation(KW, fuse_observation=fuse)
     assert env._obs_fused == fuse and env.observation_N == 2 * (6 * 6 + 2 * 7 + 1 + 2 + 4 * 5) + 5 + 1
+
+
+@pytest.mark.parametrize("impl", ["radial", "mesh"])
+def test_all_state_variables_observation_lane_group_families(impl):
+    """The same list observation with the lane-group kernels of a library whose thread kernels WOULD fuse the gather:
+    only the thread-per-environment step kernel gathers, so these must take the dump + gather path (regression:
+    the fusable flag ignored the selected implementation and the observation was never gathered)."""
+    env = pc.all_state_variables_observation(lambda net: dict(KW(net), impl=impl))
+    assert env.simulator.impl == impl and not env._obs_fused
 
 
 def test_fused_list_observation_equals_the_gather_kernel_with_autoreset():

@@ -193,3 +193,7 @@ def test_callable_observation_and_two_aux_variables():
 
 def test_all_state_variables_observation():
     pc.all_state_variables_observation(_KW, n_cases=300)
+
+
+def test_reference_custom_obs_space_known_answers():
+    pc.reference_custom_obs_space(_KW)
