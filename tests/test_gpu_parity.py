@@ -334,12 +334,12 @@ def test_radial_anm6easy_episodes():
 
 
 def test_radial_equals_thread_kernels_with_autoreset():
-    """Both kernel families on the same 8192 environments for 10 steps, in-kernel autoreset on:
+    """The three kernel families on the same 8192 environments for 10 steps, in-kernel autoreset on:
     same flags, same RNG draws, values within summation-order round-off."""
     from gym_anm_amd.envs import ANM6EasyVec
 
     E_ = 8192
-    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=5, autoreset=True, impl=i) for i in ("thread", "radial")]
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=5, autoreset=True, impl=i) for i in ("thread", "radial", "mesh")]
     for env in envs:
         env.check_actions = False
         env.reset(seed=5)
@@ -349,14 +349,15 @@ def test_radial_equals_thread_kernels_with_autoreset():
     for t in range(10):
         a = lo + (hi - lo) * torch.rand((E_, 6), generator=gen, dtype=torch.float64, device=DEV)
         outs = [env.step(a) for env in envs]
-        (o0, r0, t0, _, _), (o1, r1, t1, _, _) = outs
-        assert bool((t0 == t1).all())
-        npt.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=0, atol=1e-9)
-        npt.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=1e-10, atol=1e-9)
-        ok = ~t0
-        npt.assert_array_equal(envs[0].simulator.nr_iters[ok].cpu().numpy(), envs[1].simulator.nr_iters[ok].cpu().numpy())
-        npt.assert_array_equal(envs[0]._reset_count.cpu().numpy(), envs[1]._reset_count.cpu().numpy())
-        npt.assert_array_equal(envs[0].timestep.cpu().numpy(), envs[1].timestep.cpu().numpy())
+        (o0, r0, t0, _, _) = outs[0]
+        for other, (o1, r1, t1, _, _) in zip(envs[1:], outs[1:]):
+            assert bool((t0 == t1).all())
+            npt.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=0, atol=1e-9)
+            npt.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=1e-10, atol=1e-9)
+            ok = ~t0
+            npt.assert_array_equal(envs[0].simulator.nr_iters[ok].cpu().numpy(), other.simulator.nr_iters[ok].cpu().numpy())
+            npt.assert_array_equal(envs[0]._reset_count.cpu().numpy(), other._reset_count.cpu().numpy())
+            npt.assert_array_equal(envs[0].timestep.cpu().numpy(), other.timestep.cpu().numpy())
     assert int(envs[0]._reset_count.sum()) > 0
 
 
@@ -493,9 +494,9 @@ def test_new_topology_is_compiled_on_first_use(n_bus, seed):
         npt.assert_allclose(f2[:, sl[key]], f1[:, sl[key]], rtol=0, atol=1e-9, err_msg=key)
 
 
-@pytest.mark.parametrize("impl", ["thread", "radial"])
+@pytest.mark.parametrize("impl", ["thread", "radial", "mesh"])
 def test_device_sampler_reset(impl):
-    """reset(options={"sampler": "device"}) on both kernel families: the in-kernel draws equal the host
+    """reset(options={"sampler": "device"}) on every kernel family: the in-kernel draws equal the host
     restatement of the counter-based RNG and the oracle's reset of that state."""
     import anm_oracle as O
     from gym_anm_amd import networks, rng
@@ -642,7 +643,7 @@ def test_long_run_invariants():
             np.testing.assert_allclose(float(rew[i]), rr, rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("impl", ["thread", "radial"])
+@pytest.mark.parametrize("impl", ["thread", "radial", "mesh"])
 def test_results_do_not_depend_on_batch_size_or_neighbours(impl):
     """Environment e gets bit-identical results whatever the batch it is stepped in (1, 63, 65, 130 or
     256 environments: ragged last wavefront, different wave neighbours, diverging neighbours or not)."""
