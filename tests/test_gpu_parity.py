@@ -555,8 +555,8 @@ def test_two_phase_step_is_bit_identical(cap_after, small_workspace):
     assert n_term > 100  # the workload did produce diverging solves
 
 
-@pytest.mark.parametrize("small_workspace", [False, True])
-def test_two_phase_step_with_lane_group_stragglers_equals_the_in_wave_hand_over(small_workspace):
+@pytest.mark.parametrize("small_workspace,precision", [(False, "f64"), (True, "f64"), (False, "f32")])
+def test_two_phase_step_with_lane_group_stragglers_equals_the_in_wave_hand_over(small_workspace, precision):
     """With the lane-group continuation on (the default), the straggler launch of the two-launch step runs its
     records on lane groups, 8 per wavefront.  Handed over after the same number of iterations, these are the
     very solves the one-launch step continues on lane groups of their own wavefront -- same code, same inputs:
@@ -564,8 +564,8 @@ def test_two_phase_step_with_lane_group_stragglers_equals_the_in_wave_hand_over(
     from gym_anm_amd.envs import ANM6EasyVec
 
     E_ = 65536
-    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=11, autoreset=True, tol=1e-6, straggler_after=sa, handoff_after=6)
-            for sa in (None, 6)]  # fmt: skip
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=11, autoreset=True, tol=1e-6, straggler_after=sa, handoff_after=6,
+                        precision=precision) for sa in (None, 6)]  # fmt: skip
     assert envs[0]._ws is None and envs[1]._ws is not None
     if small_workspace:
         rec = envs[1].simulator.backend.lib.anm_step_ws_record_doubles()
