@@ -75,8 +75,9 @@ def test_two_devices_shard_like_one():
             assert torch.equal(tk.cpu(), term[k * H : (k + 1) * H].cpu())
 
 
-def test_callable_observation_and_two_aux_variables():
-    pc.callable_observation_and_two_aux(KW)
+@pytest.mark.parametrize("impl", ["thread", "radial", "mesh"])
+def test_callable_observation_and_two_aux_variables(impl):
+    pc.callable_observation_and_two_aux(lambda net: dict(KW(net), impl=impl))
 
 
 def test_reference_custom_obs_space_known_answers():
@@ -197,14 +198,15 @@ def test_fused_list_observation_equals_the_gather_kernel_with_autoreset():
     assert n_term > 20 and int(fused._reset_count.sum()) > 20
 
 
-def test_track_full_follows_the_steps():
+@pytest.mark.parametrize("impl", ["thread", "radial", "mesh"])
+def test_track_full_follows_the_steps(impl):
     """track_full=True: simulator.state / pfe_converged are refreshed by every step (the reference's
     Simulator does that on every transition, simulator.py:529-537)."""
     from gym_anm_amd.envs import ANM6EasyVec
 
     E_ = 512
-    env = ANM6EasyVec(num_envs=E_, device=DEV, seed=2, track_full=True)
-    plain = ANM6EasyVec(num_envs=E_, device=DEV, seed=2)
+    env = ANM6EasyVec(num_envs=E_, device=DEV, seed=2, track_full=True, impl=impl)
+    plain = ANM6EasyVec(num_envs=E_, device=DEV, seed=2, impl=impl)
     for e_ in (env, plain):
         e_.check_actions = False
         e_.reset(seed=2)
