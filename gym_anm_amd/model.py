@@ -127,6 +127,10 @@ class NetworkModel:
                 raise E.BusSpecError("The VMIN value for bus %d should be >= 0" % bid)
             if typ != 0 and vmax < vmin:
                 raise E.BusSpecError("Bus %d has VMAX < VMIN" % bid)
+            if _missing(vmin):
+                # bus.py:93-95 lets a slack bus through without VMIN; the reference then fails with a TypeError in its
+                # first transition (the voltage penalty of simulator.py:665-669 compares with None): refused here
+                raise E.BusSpecError("The VMIN value for slack bus %d is missing" % bid)
             parsed.append((bid, typ, float(base_kv), float(vmax), float(vmin)))
         parsed.sort(key=lambda t: t[0])
         self.bus_ids = [p[0] for p in parsed]
@@ -148,12 +152,15 @@ class NetworkModel:
                 raise E.BranchSpecError("The T_BUS value of the branch is {} but should be in {}.".format(t, self.bus_ids))
             f, t = int(f), int(t)
 
+            # Values keep the type they came with (a Python float from an object array -- any network file with a
+            # None in it -- or a NumPy scalar): 1 / (r + jx) is then the same complex division as in branch.py:146
+            # (Python's and NumPy's differ in the last bit for some operands).
             def nonneg(v, name, default):
                 if _missing(v):
-                    return np.float64(default)
+                    return default
                 if v < 0:
                     raise E.BranchSpecError("The %s value for branch (%d, %d) should be >= 0." % (name, f, t))
-                return np.float64(v)
+                return v
 
             rr, xx, bb = nonneg(r[2], "BR_R", 0.0), nonneg(r[3], "BR_X", 0.0), nonneg(r[4], "BR_B", 0.0)
             if rr == 0 and xx == 0:
@@ -163,20 +170,20 @@ class NetworkModel:
                 )
             rt = np.inf if _missing(r[5]) else nonneg(r[5], "RATE", 0.0) / self.baseMVA
             if _missing(r[6]):
-                a = np.float64(1.0)
+                a = 1.0
             elif r[6] <= 0:
                 raise E.BranchSpecError(
                     "The TAP value for branch (%d, %d) should be > 0. Use TAP=1 and SHIFT=0 to model"
                     "the absence of an off-nominal transformer." % (f, t)
                 )
             else:
-                a = np.float64(r[6])
+                a = r[6]
             if _missing(r[7]):
-                sh = np.float64(0.0)
+                sh = 0.0
             elif r[7] < 0 or r[7] > 360:
                 raise E.BranchSpecError("The BR_SHIFT value for branch (%d, %d) should be in [0, 360]." % (f, t))
             else:
-                sh = np.float64(r[7]) * np.pi / 180
+                sh = r[7] * np.pi / 180
             f_l.append(f)
             t_l.append(t)
             ser.append(1.0 / (rr + 1.0j * xx))
@@ -186,6 +193,9 @@ class NetworkModel:
         self.N_branch = len(f_l)
         self.branch_ids = list(zip(f_l, t_l))
         self.br_f_id, self.br_t_id = f_l, t_l
+        # (the scalars as the reference holds them -- Python or NumPy complex -- for _build_ybus: complex / float is
+        # not the same rounding in the two)
+        self._br_scalars = list(zip(ser, shu, tap))
         self.br_series = np.array(ser, dtype=np.complex128)
         self.br_shunt = np.array(shu, dtype=np.complex128)
         self.br_tap = np.array(tap, dtype=np.complex128)
@@ -196,6 +206,11 @@ class NetworkModel:
         base = self.baseMVA
         devs = []
         for r in rows:
+            # simulator.py:160-174 dispatches on int(DEV_TYPE) before any device is built: an unknown integer type
+            # is a NotImplementedError there, ahead of every other check of the row
+            t0 = r[DEV_H["DEV_TYPE"]]
+            if not _missing(t0) and int(t0) not in (-1, 0, 1, 2, 3):
+                raise NotImplementedError
             dev_id = r[DEV_H["DEV_ID"]]
             if _missing(dev_id):
                 raise E.DeviceSpecError("The device ID cannot be None.")
@@ -394,7 +409,7 @@ class NetworkModel:
         Y = np.zeros((n, n), dtype=np.complex128)
         for k in range(self.N_branch):
             f, t = self.br_f[k], self.br_t[k]
-            ys, sh, tap = self.br_series[k], self.br_shunt[k], self.br_tap[k]
+            ys, sh, tap = self._br_scalars[k]
             Y[f, t] = -ys / np.conjugate(tap)
             Y[t, f] = -ys / tap
             Y[f, f] += (ys + sh) / (np.abs(tap) ** 2)

@@ -125,7 +125,8 @@ def test_network_level_errors():
         ([1, 1, 3, _N, 50, -50, 50, -50, _N, _N, _N, _N, 100, 0, 1.5], E.StorageSpecError),  # EFF > 1
         ([1, 1, 3, _N, 50, 10, 50, -50, _N, _N, _N, _N, 100, 0, 0.9], E.StorageSpecError),  # PMIN > 0
         ([1, 5, -1, 0.2, 0, -10, _N, _N, _N, _N, _N, _N, _N, _N, _N], E.DeviceSpecError),  # unknown bus
-        ([1, 1, 7, 0.2, 0, -10, _N, _N, _N, _N, _N, _N, _N, _N, _N], E.DeviceSpecError),  # unknown type
+        ([1, 1, 7, 0.2, 0, -10, _N, _N, _N, _N, _N, _N, _N, _N, _N], NotImplementedError),  # unknown type (simulator.py:173-174)
+        ([1, 1, 1.5, 0.2, 30, 0, 30, -30, _N, _N, _N, _N, _N, _N, _N], E.DeviceSpecError),  # non-integer type (devices.py:85-88)
     ],
 )
 def test_device_spec_errors(row, err):
@@ -176,6 +177,43 @@ def _reference_available():
         return False
 
 
+def _assert_same_constants(m, ref):
+    from gym_anm.simulator.components import Generator, StorageUnit
+
+    def eq(x, y):  # bit-equal, NaN == NaN (what a degenerate but accepted spec yields on both sides)
+        return x == y or (x != x and y != y)
+
+    npt.assert_array_equal(m.Y_bus, ref.Y_bus.toarray())
+    assert m.bus_ids == list(ref.buses.keys()) and m.dev_ids == list(ref.devices.keys())
+    assert m.branch_ids == list(ref.branches.keys())
+    for k, d in enumerate(ref.devices.values()):
+        for a, b in ((m.dev_p_min[k], d.p_min), (m.dev_p_max[k], d.p_max), (m.dev_q_min[k], d.q_min), (m.dev_q_max[k], d.q_max)):
+            assert eq(a, b)
+        if isinstance(d, (Generator, StorageUnit)):
+            assert eq(m.dev_tau[k, 0], d.tau_1) and eq(m.dev_tau[k, 1], d.tau_2)
+            assert eq(m.dev_rho[k, 0], d.rho_1) and eq(m.dev_rho[k, 1], d.rho_2)
+        if isinstance(d, StorageUnit):
+            assert eq(m.dev_tau[k, 2], d.tau_3) and eq(m.dev_tau[k, 3], d.tau_4)
+            assert eq(m.dev_rho[k, 2], d.rho_3) and eq(m.dev_rho[k, 3], d.rho_4)
+            assert (m.dev_soc_min[k], m.dev_soc_max[k], m.dev_eff[k]) == (d.soc_min, d.soc_max, d.eff)
+    for k, b in enumerate(ref.branches.values()):
+        assert m.br_series[k] == b.series and m.br_shunt[k] == b.shunt and m.br_tap[k] == b.tap and m.br_rate[k] == b.rate
+    # nested bounds dictionaries
+    rb, mb = ref.state_bounds, m.state_bounds()
+    assert set(rb) == set(mb)
+    for q in rb:
+        assert list(rb[q].keys()) == list(mb[q].keys()), q
+        for i in rb[q]:
+            for unit, (lo, hi) in rb[q][i].items():
+                assert eq(mb[q][i][unit][0], lo) and eq(mb[q][i][unit][1], hi), (q, i, unit)
+    P_gen, Q_gen, P_des, Q_des = ref.get_action_space()
+    lo, hi = m.action_bounds()
+    ref_lo = [v[0] for x in (P_gen, Q_gen, P_des, Q_des) for _, v in sorted(x.items())]
+    ref_hi = [v[1] for x in (P_gen, Q_gen, P_des, Q_des) for _, v in sorted(x.items())]
+    npt.assert_array_equal(lo, ref_lo)
+    npt.assert_array_equal(hi, ref_hi)
+
+
 @pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
 @pytest.mark.parametrize("which", ["anm6", "basics", "3bus_tx", "case30", "2bus"])
 def test_constants_bit_identical_to_reference(which):
@@ -194,32 +232,75 @@ def test_constants_bit_identical_to_reference(which):
     }[which]
     ref = Simulator(net, 0.25, 100)
     m = NetworkModel(net, 0.25, 100, require_solvable=False)
-    npt.assert_array_equal(m.Y_bus, ref.Y_bus.toarray())
-    assert m.bus_ids == list(ref.buses.keys()) and m.dev_ids == list(ref.devices.keys())
-    assert m.branch_ids == list(ref.branches.keys())
-    for k, d in enumerate(ref.devices.values()):
-        for a, b in ((m.dev_p_min[k], d.p_min), (m.dev_p_max[k], d.p_max), (m.dev_q_min[k], d.q_min), (m.dev_q_max[k], d.q_max)):
-            assert a == b
-        if isinstance(d, (Generator, StorageUnit)):
-            assert m.dev_tau[k, 0] == d.tau_1 and m.dev_tau[k, 1] == d.tau_2
-            assert m.dev_rho[k, 0] == d.rho_1 and m.dev_rho[k, 1] == d.rho_2
-        if isinstance(d, StorageUnit):
-            assert m.dev_tau[k, 2] == d.tau_3 and m.dev_tau[k, 3] == d.tau_4
-            assert m.dev_rho[k, 2] == d.rho_3 and m.dev_rho[k, 3] == d.rho_4
-            assert (m.dev_soc_min[k], m.dev_soc_max[k], m.dev_eff[k]) == (d.soc_min, d.soc_max, d.eff)
-    for k, b in enumerate(ref.branches.values()):
-        assert m.br_series[k] == b.series and m.br_shunt[k] == b.shunt and m.br_tap[k] == b.tap and m.br_rate[k] == b.rate
-    # nested bounds dictionaries
-    rb, mb = ref.state_bounds, m.state_bounds()
-    assert set(rb) == set(mb)
-    for q in rb:
-        assert list(rb[q].keys()) == list(mb[q].keys()), q
-        for i in rb[q]:
-            for unit, (lo, hi) in rb[q][i].items():
-                assert mb[q][i][unit] == (lo, hi), (q, i, unit)
-    P_gen, Q_gen, P_des, Q_des = ref.get_action_space()
-    lo, hi = m.action_bounds()
-    ref_lo = [v[0] for x in (P_gen, Q_gen, P_des, Q_des) for _, v in sorted(x.items())]
-    ref_hi = [v[1] for x in (P_gen, Q_gen, P_des, Q_des) for _, v in sorted(x.items())]
-    npt.assert_array_equal(lo, ref_lo)
-    npt.assert_array_equal(hi, ref_hi)
+    _assert_same_constants(m, ref)
+
+
+BUILTIN_CRASHES = ("TypeError", "KeyError", "IndexError", "ValueError", "AttributeError", "ZeroDivisionError", "UnboundLocalError")
+
+
+def _mutations(rng, n):
+    """Malformed (and a few still-valid) variants of the 3-bus / 5-device basics network: one random field of one
+    random row replaced by a value of a random kind (missing, zero, negative, huge, swapped sign, duplicate id)."""
+    import copy
+
+    base = basics_network()
+    for _ in range(n):
+        net = copy.deepcopy({k: (np.array(v, dtype=object) if isinstance(v, np.ndarray) else v) for k, v in base.items()})
+        what = rng.choice(["bus", "branch", "device", "device", "device", "baseMVA", "drop"])
+        if what == "baseMVA":
+            net["baseMVA"] = rng.choice([0, -1, 10, None])
+        elif what == "drop":
+            tab = rng.choice(["bus", "branch", "device"])
+            r = rng.integers(len(net[tab]))
+            net[tab] = np.delete(net[tab], r, axis=0)
+        else:
+            tab = net[what]
+            r, c = rng.integers(tab.shape[0]), rng.integers(tab.shape[1])
+            old = tab[r, c]
+            kind = rng.choice(["none", "zero", "neg", "big", "flip", "dup", "small"])
+            tab[r, c] = {"none": None, "zero": 0, "neg": -abs(old) - 1 if old is not None else -1, "big": 1e4,
+                         "flip": (-old if old is not None else 1), "dup": tab[(r + 1) % tab.shape[0], c],
+                         "small": 1e-3}[kind]
+        yield net
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+def test_front_end_agrees_with_the_reference_on_mutated_networks():
+    """Differential test of the network-dict front end: 400 random single-field mutations of a
+    valid network go through the reference's Simulator and through NetworkModel; both must accept or both must
+    raise, with the same exception class (check_network.py:7-64, components/*.py); accepted networks give
+    bit-identical Y_bus, device limits, tau / rho, storage constants, branch constants, state bounds and action box."""
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm.simulator import Simulator
+
+    rng = np.random.default_rng(12)
+    n_ok = n_err = 0
+    for net in _mutations(rng, 400):
+        ref_exc = got_exc = None
+        try:
+            ref = Simulator(net, 0.25, 100)
+        except Exception as ex:  # noqa: BLE001
+            ref_exc = type(ex).__name__
+        try:
+            m = NetworkModel(net, 0.25, 100, require_solvable=False)
+        except Exception as ex:  # noqa: BLE001
+            got_exc = type(ex).__name__
+        shown = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in net.items()}
+        if ref_exc in BUILTIN_CRASHES:
+            # the reference trips over the garbage before any of its checks (a TypeError from comparing None, an
+            # IndexError from a dropped row ...): no error class to agree on, but the network must not be accepted
+            assert got_exc is not None, (ref_exc, shown)
+            n_err += 1
+            continue
+        if ref_exc is None and got_exc == "BusSpecError" and any(r[1] == 0 and r[4] is None for r in net["bus"]):
+            n_err += 1  # deliberate: a slack bus without VMIN passes the reference's constructor and crashes its first step
+            continue
+        assert ref_exc == got_exc, (ref_exc, got_exc, shown)
+        if ref_exc is None:
+            n_ok += 1
+            _assert_same_constants(m, ref)
+        else:
+            n_err += 1
+    assert n_ok > 40 and n_err > 100, (n_ok, n_err)
