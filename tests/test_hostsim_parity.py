@@ -197,3 +197,50 @@ def test_all_state_variables_observation():
 
 def test_reference_custom_obs_space_known_answers():
     pc.reference_custom_obs_space(_KW)
+
+
+def _reference_available():
+    try:
+        import ref_harness
+
+        return ref_harness.reference_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+def test_observation_spaces_of_random_lists_equal_the_reference():
+    """Differential test of the observation-spec compiler's host side (anm_env.py:193-233, 497-521): 60 random
+    list-form observations (random quantities, 'all' or random ids, every unit) on ANM6 -- same expanded
+    obs_values and bit-identical Box bounds as the reference's ANMEnv.  Dev container only."""
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm.envs import ANMEnv
+    import numpy.testing as npt
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+    from gym_anm_amd.model import STATE_VARIABLES
+
+    net = networks.anm6_network()
+    ids = {"bus": [0, 1, 2, 3, 4, 5], "dev": [0, 1, 2, 3, 4, 5, 6], "des": [6], "gen": [2, 4],
+           "branch": [(0, 1), (1, 2), (1, 3), (2, 4), (2, 5)]}
+    rng = np.random.default_rng(3)
+    keys = [k for k in STATE_VARIABLES if k != "aux"]
+    for case in range(60):
+        spec = []
+        for key in rng.choice(keys, size=rng.integers(1, 6), replace=False):
+            units = STATE_VARIABLES[key]
+            unit = units[rng.integers(len(units))] if isinstance(units, tuple) else units
+            pool = ids[key.split("_")[0]]
+            if rng.uniform() < 0.5:
+                nodes = "all"
+            else:
+                pick = sorted(rng.choice(len(pool), size=rng.integers(1, len(pool) + 1), replace=False))
+                nodes = [pool[i] for i in pick]
+            spec.append((str(key), nodes, str(unit)))
+        ref = ANMEnv(net, [tuple(s) for s in spec], 0, 0.25, 0.995, 100, None, (None, None), None)
+        env = BatchedANMEnv(net, [tuple(s) for s in spec], 0, 0.25, 0.995, 100, num_envs=2, **_KW(net))
+        assert env.obs_values == ref.obs_values, (case, spec)
+        npt.assert_array_equal(env.observation_space.low, ref.observation_space.low, err_msg=str(spec))
+        npt.assert_array_equal(env.observation_space.high, ref.observation_space.high, err_msg=str(spec))

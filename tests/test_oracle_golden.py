@@ -7,6 +7,7 @@ Sources of truth, in order:
    tests/simulator/test_devices.py:74-97, 269-295, 456-492, 523-562 (device maps).
 """
 import os
+import sys
 
 import numpy as np
 import numpy.testing as npt
@@ -255,3 +256,42 @@ def test_known_reward():
     e, pen = O.compute_reward(n, dev_p, p_pot, np.array([1.2, 1.0, 0.8]), np.array([30, 40]) / base)
     npt.assert_allclose(e, 40 * dt / base, rtol=1e-12)
     npt.assert_allclose(pen, lamb * dt * (0.2 + 30 / base), rtol=1e-12)
+
+
+def _reference_available():
+    try:
+        import ref_harness
+
+        return ref_harness.reference_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("kind,n_bus,seed,n_chords", [("mesh", 4, 31, 1), ("mesh", 7, 32, 2), ("mesh", 11, 33, 4), ("mesh", 16, 34, 3),
+                                                      ("radial", 9, 35, 0), ("radial", 18, 36, 0), ("mesh", 30, 37, 6)])
+def test_oracle_against_the_live_reference_on_random_networks(kind, n_bus, seed, n_chords):
+    """Beyond the committed golden vectors: the oracle and the UNMODIFIED reference, run side by side on random
+    networks nobody recorded (loops, line charging, a phase shifter; feeders) -- same flags and iteration counts,
+    electrical state, SoC and reward to 1e-9.  Dev container only (the reference does not travel)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import make_golden as MG
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if kind == "mesh" else networks.synthetic_radial_network(n_bus, seed)
+    P_load, P_pot, P_set, Q_set, soc0 = MG.random_inputs(net, 0.25, 100, 24, seed, wild_frac=0.15)
+    g = MG.run_transitions(net, 0.25, 100, P_load, P_pot, P_set, Q_set, soc0)
+    n = O.parse_network(net, 0.25, 100)
+    n_conv = 0
+    for m in range(len(g["n_iter"])):
+        out = O.transition(n, P_load[m], P_pot[m], P_set[m], Q_set[m], soc0[m], sparse=(m % 2 == 0))
+        assert out["converged"] == bool(g["converged"][m]), m
+        npt.assert_allclose(out["soc_after"], g["soc_after"][m], rtol=0, atol=1e-13)
+        npt.assert_allclose(np.asarray(out["dev_p"])[1:], g["dev_p"][m][1:], rtol=0, atol=1e-12)   # (slack: from the solve)
+        if not out["converged"]:
+            continue
+        n_conv += 1
+        assert out["n_iter"] == int(g["n_iter"][m]), m
+        for k in ["V", "I", "dev_p", "dev_q", "br_p_from", "br_q_from", "br_s"]:
+            npt.assert_allclose(np.asarray(out[k]), g[k][m], rtol=1e-9, atol=1e-10, err_msg="%s[%d]" % (k, m))
+        npt.assert_allclose(out["reward"], g["reward"][m], rtol=1e-9, atol=1e-9)
+    assert n_conv >= 12
