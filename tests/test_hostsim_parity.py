@@ -244,3 +244,59 @@ def test_observation_spaces_of_random_lists_equal_the_reference():
         assert env.obs_values == ref.obs_values, (case, spec)
         npt.assert_array_equal(env.observation_space.low, ref.observation_space.low, err_msg=str(spec))
         npt.assert_array_equal(env.observation_space.high, ref.observation_space.high, err_msg=str(spec))
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("seed", [1, 3, 4])
+def test_list_observation_episode_equals_the_live_reference(seed):
+    """ANM6Easy's dynamics with a LIST observation (the committed golden episodes use "state"): the reference's
+    environment and the batched one (one environment, host double), same seed and actions, 150 steps with resets --
+    observations, rewards and terminations step by step.  Dev container only."""
+    import numpy.testing as npt
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm.envs import ANM6Easy
+    from gym_anm.envs.anm6_env.anm6 import ANM6
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs.anm6 import ANM6Vec, anm6easy_series, random_date
+
+    observation = [("bus_v_magn", "all", "pu"), ("branch_s", [(1, 2), (2, 4)], "MVA"), ("des_soc", "all", "MWh"),
+                   ("dev_q", [2, 4, 6], "MVAr"), ("bus_v_ang", [3, 5], "degree"), ("gen_p_max", "all", "MW"), ("aux", "all")]
+
+    class RefTask(ANM6Easy):
+        def __init__(self):
+            ANM6.__init__(self, observation, 1, 0.25, 0.995, 100, np.array([[0, 95]]), (1, 100))
+            from gym_anm.envs.anm6_env.anm6_easy import _get_gen_time_series, _get_load_time_series
+
+            self.P_loads, self.P_maxs = _get_load_time_series(), _get_gen_time_series()
+
+    class Task(ANM6EasyVec):
+        def __init__(self, **kw):
+            self.P_loads, self.P_maxs = anm6easy_series()[:3], anm6easy_series()[3:]
+            ANM6Vec.__init__(self, observation, 1, 0.25, 0.995, 100, aux_bounds=np.array([[0, 95]]), costs_clipping=(1, 100),
+                             series=anm6easy_series(), **kw)
+
+    ref = RefTask()
+    env = Task(num_envs=1, seed=seed, **_KW(networks.anm6_network()))
+    o_ref, _ = ref.reset(seed=seed)
+    o, _ = env.reset(seed=seed)
+    random_date(env.np_random, 2020)  # ANM6.reset draws the rendering date from np_random (anm6.py:138): the batched
+    npt.assert_allclose(o[0].cpu().numpy(), o_ref, rtol=0, atol=1e-9)  # class leaves that to its NumPy-facing wrapper
+    rng = np.random.default_rng(50 + seed)
+    n_term = 0
+    for t in range(150):
+        a = rng.uniform(ref.action_space.low, ref.action_space.high)
+        if t % 3:
+            a[2:] *= 0.3
+        o_ref, r_ref, term_ref, _, _ = ref.step(a)
+        o, r, term, _, _ = env.step(torch.as_tensor(a[None, :]))
+        assert bool(term[0]) == bool(term_ref), t
+        npt.assert_allclose(o[0].cpu().numpy(), o_ref, rtol=0, atol=1e-7, err_msg="step %d" % t)
+        npt.assert_allclose(float(r[0]), r_ref, rtol=1e-9, atol=1e-8)
+        if term_ref:
+            n_term += 1
+            o_ref, _ = ref.reset()
+            o, _ = env.reset()
+            random_date(env.np_random, 2020)
+            npt.assert_allclose(o[0].cpu().numpy(), o_ref, rtol=0, atol=1e-9)
