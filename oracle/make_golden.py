@@ -185,6 +185,12 @@ def gen_transition_fixture(name, network, delta_t, lamb, M, seed, wild_frac=0.2,
 
 
 def gen_reset_fixture(name, network, delta_t, lamb, M, seed):
+    res = run_resets(network, delta_t, lamb, M, seed)
+    np.savez_compressed(os.path.join(GOLDEN, "reset_%s.npz" % name), **res)
+    print("reset_%-12s M=%d converged=%d" % (name, M, int(res["converged"].sum())))
+
+
+def run_resets(network, delta_t, lamb, M, seed):
     """``Simulator.reset(init_state)``: init_state = [P_dev MW, Q_dev MVAr, soc MWh, P_max MW, aux]."""
     sim = Simulator(network, delta_t, lamb)
     base = sim.baseMVA
@@ -224,8 +230,7 @@ def gen_reset_fixture(name, network, delta_t, lamb, M, seed):
         out["converged"].append(bool(conv))
     res = {k: np.array(v) for k, v in out.items()}
     res.update(init_state=S0, delta_t=delta_t, lamb=lamb)
-    np.savez_compressed(os.path.join(GOLDEN, "reset_%s.npz" % name), **res)
-    print("reset_%-12s M=%d converged=%d" % (name, M, int(res["converged"].sum())))
+    return res
 
 
 def gen_episode_fixture(seeds, T):

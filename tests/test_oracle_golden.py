@@ -295,3 +295,26 @@ def test_oracle_against_the_live_reference_on_random_networks(kind, n_bus, seed,
             npt.assert_allclose(np.asarray(out[k]), g[k][m], rtol=1e-9, atol=1e-10, err_msg="%s[%d]" % (k, m))
         npt.assert_allclose(out["reward"], g["reward"][m], rtol=1e-9, atol=1e-9)
     assert n_conv >= 12
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("kind,n_bus,seed,n_chords", [("mesh", 6, 41, 2), ("radial", 12, 42, 0), ("mesh", 20, 43, 5)])
+def test_oracle_reset_against_the_live_reference_on_random_networks(kind, n_bus, seed, n_chords):
+    """Simulator.reset(init_state) (simulator.py:225-293: SoC pre-set, one transition, SoC overwrite) -- oracle and
+    live reference side by side on random networks and initial states, infeasible ones included."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import make_golden as MG
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if kind == "mesh" else networks.synthetic_radial_network(n_bus, seed)
+    g = MG.run_resets(net, 0.25, 100, 24, seed)
+    n = O.parse_network(net, 0.25, 100)
+    n_conv = 0
+    for m in range(len(g["n_iter"])):
+        out = O.sim_reset(n, g["init_state"][m], sparse=False)
+        assert out["converged"] == bool(g["converged"][m]), m
+        npt.assert_allclose(out["soc_after"], g["soc_after"][m], rtol=0, atol=1e-13)
+        if out["converged"]:
+            n_conv += 1
+            for k in ["dev_p", "dev_q", "V", "br_s"]:
+                npt.assert_allclose(np.asarray(out[k]), g[k][m], rtol=1e-9, atol=1e-10, err_msg="%s[%d]" % (k, m))
+    assert n_conv >= 8
