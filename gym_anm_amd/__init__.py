@@ -6,6 +6,25 @@ missing / unloadable extension raises (there is no CPU fallback in the product p
 
 __version__ = "0.1.0"
 
+_TOP_LEVEL = {  # the names gym_anm exports at top level (gym_anm/__init__.py:5-6), resolved on first use
+    "ANMEnv": ("gym_anm_amd.envs", "ANMEnv"),
+    "MPCAgentPerfect": ("gym_anm_amd.agents", "MPCAgentPerfect"),
+    "MPCAgentConstant": ("gym_anm_amd.agents", "MPCAgentConstant"),
+}
+
+
+def __getattr__(name):
+    if name in _TOP_LEVEL:
+        import importlib
+
+        mod, attr = _TOP_LEVEL[name]
+        return getattr(importlib.import_module(mod), attr)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
+
+
+def __dir__():
+    return sorted(list(globals()) + list(_TOP_LEVEL))
+
 
 def _register():
     """``gym.make("ANM6Easy-v0")`` like the reference (gym_anm/__init__.py:8-11), when gymnasium is

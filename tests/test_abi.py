@@ -87,3 +87,14 @@ def test_build_is_keyed_by_content_not_by_file_times(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     assert open(stamp).read() == good and os.path.getmtime(lib) >= t0 - 1  # rebuilt once, stamp restored
     assert not [f for f in os.listdir(os.path.dirname(lib)) if f.endswith(".tmp")]
+
+
+def test_top_level_names_of_the_reference_package():
+    """gym_anm/__init__.py:5-6 exports ANMEnv and the two MPC agents at top level: so does this package (lazily)."""
+    import gym_anm_amd
+    from gym_anm_amd import ANMEnv, MPCAgentConstant, MPCAgentPerfect
+    from gym_anm_amd.agents import mpc
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    assert ANMEnv is BatchedANMEnv and MPCAgentPerfect is mpc.MPCAgentPerfect and MPCAgentConstant is mpc.MPCAgentConstant
+    assert {"ANMEnv", "MPCAgentPerfect", "MPCAgentConstant"} <= set(dir(gym_anm_amd))
