@@ -750,7 +750,9 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
                         EnvIO& io) {
   if (!m) return fail("anm_step_f64: null model");
   if (!m->env_set) return fail("anm_step_f64: call anm_model_set_env first");
-  if (!action || !state || !terminated || !obs || !reward || !e_loss || !penalty)
+  // (a network without set-point devices has an empty action vector: examples/simple_env.py of the reference)
+  const int action_dim = 2 * (m->tpe_ok ? Topo::NSET : (m->radial_ok ? m->plan.d.NSET : m->mplan.d.NSET));
+  if ((!action && action_dim > 0) || !state || !terminated || !obs || !reward || !e_loss || !penalty)
     return fail("anm_step_f64: null argument");
   if ((m->tpe_ok ? Topo::NDES : (m->radial_ok ? m->plan.d.NDES : m->mplan.d.NDES)) > 0 && !soc) return fail("anm_step_f64: null soc");
   const bool series = exo == nullptr;

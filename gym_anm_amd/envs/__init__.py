@@ -2,6 +2,5 @@
 
 from .anm_env import BatchedANMEnv
 from .anm6 import ANM6Vec, ANM6EasyVec, ANM6Easy
+from .single import ANM6, ANMEnv
 from .vector import NumpyVectorEnv
-
-ANMEnv = BatchedANMEnv

@@ -94,7 +94,7 @@ def test_top_level_names_of_the_reference_package():
     import gym_anm_amd
     from gym_anm_amd import ANMEnv, MPCAgentConstant, MPCAgentPerfect
     from gym_anm_amd.agents import mpc
-    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+    from gym_anm_amd.envs.single import ANMEnv as Single
 
-    assert ANMEnv is BatchedANMEnv and MPCAgentPerfect is mpc.MPCAgentPerfect and MPCAgentConstant is mpc.MPCAgentConstant
+    assert ANMEnv is Single and MPCAgentPerfect is mpc.MPCAgentPerfect and MPCAgentConstant is mpc.MPCAgentConstant
     assert {"ANMEnv", "MPCAgentPerfect", "MPCAgentConstant"} <= set(dir(gym_anm_amd))

@@ -86,6 +86,12 @@ def test_reference_custom_obs_space_known_answers():
     pc.reference_custom_obs_space(KW)
 
 
+def test_reference_example_simple_env_on_the_gpu():
+    """examples/simple_env.py of the reference through `gym_anm_amd.ANMEnv` (NumPy-facing, one environment) on the HIP path."""
+    env = pc.reference_example_simple_env(KW)
+    assert env.simulator.backend.device_type == "cuda"
+
+
 def test_next_vars_of_the_wrong_size_is_refused():
     from gym_anm_amd import errors, networks
     from gym_anm_amd.envs.anm_env import BatchedANMEnv

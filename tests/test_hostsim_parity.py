@@ -300,3 +300,125 @@ def test_list_observation_episode_equals_the_live_reference(seed):
             o, _ = env.reset()
             random_date(env.np_random, 2020)
             npt.assert_allclose(o[0].cpu().numpy(), o_ref, rtol=0, atol=1e-9)
+
+
+def _simple_env_classes(kw):
+    """The reference's examples/simple_env.py (2-bus grid, random loads, one useless aux variable), written against
+    `ANMEnv` twice: the reference's class and this package's NumPy-facing single-environment class."""
+    from gym_anm_amd import ANMEnv as Ours
+
+    network = {
+        "baseMVA": 100,
+        "bus": np.array([[0, 0, 132, 1.0, 1.0], [1, 1, 33, 1.1, 0.9]]),
+        "device": np.array([[0, 0, 0, None, 200, -200, 200, -200, None, None, None, None, None, None, None],
+                            [1, 1, -1, 0.2, 0, -10, None, None, None, None, None, None, None, None, None]]),
+        "branch": np.array([[0, 1, 0.01, 0.1, 0.0, 3, 1, 0]]),
+    }
+
+    def make(base, extra):
+        class SimpleEnvironment(base):
+            def __init__(self):
+                super().__init__(network, "state", 1, 0.25, 0.9, 100, np.array([[0, 10]]), (1, 100), 1, **extra)
+
+            def init_state(self):
+                n_dev, n_des, n_gen = self.simulator.N_device, self.simulator.N_des, self.simulator.N_non_slack_gen
+                return np.random.rand(2 * n_dev + n_des + n_gen + self.K)
+
+            def next_vars(self, s_t):
+                P_load = -10 * np.random.rand(1)[0]
+                aux = np.random.randint(0, 10)
+                return np.array([P_load, aux])
+
+        return SimpleEnvironment
+
+    return make, Ours, kw(network)
+
+
+def test_reference_example_simple_env_runs_unmodified():
+    """`class SimpleEnvironment(ANMEnv)` of examples/simple_env.py, body unchanged: 1-D states, 1-D next_vars, 1-D
+    NumPy observations, float rewards, Python bools."""
+    make, Ours, extra = _simple_env_classes(_KW)
+    env = make(Ours, extra)()
+    np.random.seed(5)
+    o, info = env.reset()
+    assert isinstance(o, np.ndarray) and o.shape == (5,) and info == {}
+    for t in range(10):
+        a = env.action_space.sample()
+        o, r, terminated, truncated, info = env.step(a)
+        assert isinstance(o, np.ndarray) and o.shape == (5,) and isinstance(r, float) and isinstance(terminated, bool)
+        assert truncated is False and env.observation_space.contains(o)
+    assert env.state.shape == (5,) and env.timestep == 10
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+def test_reference_example_simple_env_equals_the_live_reference():
+    """... and it walks the same trajectory as the reference's class under the same global NumPy seed."""
+    import numpy.testing as npt
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm import ANMEnv as Ref
+
+    make, Ours, extra = _simple_env_classes(_KW)
+    traj = []
+    for base, ex in ((Ref, {}), (Ours, extra)):
+        env = make(base, ex)()
+        np.random.seed(11)
+        o, _ = env.reset()
+        rows = [np.concatenate((o, [0.0, 0.0]))]
+        for t in range(40):
+            o, r, term, _, _ = env.step(env.action_space.sample())
+            rows.append(np.concatenate((o, [r, float(term)])))
+        traj.append(np.array(rows))
+    npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+def test_reference_example_custom_anm6_equals_the_live_reference():
+    """`class CustomANM6Environment(ANM6)` of examples/custom_anm6.py (random loads and generation potentials within
+    their limits, time-of-day aux variable), body unchanged, on `gym_anm.envs.ANM6` and on this package's `ANM6`:
+    same trajectory under the same global NumPy seed (random agent from a seeded generator)."""
+    import numpy.testing as npt
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm.envs import ANM6 as Ref
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import ANM6 as Ours
+
+    def make(base, extra):
+        class CustomANM6Environment(base):
+            def __init__(self):
+                super().__init__("state", 1, 0.25, 0.9, 100, np.array([[0, 10]]), (1, 100), 1, **extra)
+
+            def init_state(self):
+                n_dev, n_des, n_gen = self.simulator.N_device, self.simulator.N_des, self.simulator.N_non_slack_gen
+                s = np.random.rand(2 * n_dev + n_des + n_gen)
+                return np.hstack((s, 0))
+
+            def next_vars(self, s_t):
+                next_var = [-10 * np.random.rand(1)[0], 30 * np.random.rand(1)[0], -30 * np.random.rand(1)[0],
+                            50 * np.random.rand(1)[0], -30 * np.random.rand(1)[0]]
+                next_var.append(int((s_t[-1] + 1) % (24 / self.delta_t)))
+                return np.array(next_var)
+
+        return CustomANM6Environment
+
+    traj = []
+    for base, ex in ((Ref, {}), (Ours, _KW(networks.anm6_network()))):
+        env = make(base, ex)()
+        np.random.seed(3)
+        o, _ = env.reset()
+        rng = np.random.default_rng(9)
+        rows = [np.concatenate((o, [0.0, 0.0]))]
+        for t in range(60):
+            a = rng.uniform(env.action_space.low, env.action_space.high)
+            a[2:] *= 0.2
+            o, r, term, _, _ = env.step(a)
+            rows.append(np.concatenate((o, [r, float(term)])))
+            if term:
+                o, _ = env.reset()
+                rows.append(np.concatenate((o, [0.0, 0.0])))
+        traj.append(np.array(rows))
+    assert traj[0].shape == traj[1].shape
+    npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-7)
