@@ -289,6 +289,11 @@ class MPCAgent:
         return x
 
     def act(self, env):
+        """``env``: a batched environment -> ``[num_envs, action_dim]`` tensor; or one of the NumPy-facing
+        single-environment classes (``ANMEnv``, ``ANM6``, ``ANM6Easy``) -> 1-D NumPy action, as in the reference's
+        ``examples/mpc_*.py``."""
+        if hasattr(env, "vec"):
+            return self.act(env.vec)[0].cpu().numpy()
         pl, pg = self.forecast(env)
         x = self.solve(pl, pg, self._soc(env))
         pr = self.program

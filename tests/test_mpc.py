@@ -173,3 +173,26 @@ def test_mpc_perfect_closed_loop_gpu():
         _, r, term, _, _ = env.step(ag.act(env))
         tot += r
     assert not bool(env.terminated.any()) and float(tot.mean()) / 10 > -5.0
+
+
+def test_reference_example_mpc_constant_pattern_on_the_host_double():
+    """examples/mpc_constant.py of the reference: `agent = MPCAgentConstant(env.simulator, env.action_space, env.gamma,
+    safety_margin=0.96, planning_steps=N); a = agent.act(env); env.step(a)` on the NumPy-facing ANM6Easy."""
+    from hostsim_backend import hostsim_backend
+
+    from gym_anm_amd import MPCAgentConstant as TopLevel
+    from gym_anm_amd.envs import ANM6Easy
+
+    assert TopLevel is MPCAgentConstant
+    net = networks.anm6_network()
+    env = ANM6Easy(device="cpu", _backend=hostsim_backend(NetworkModel(net, 0.25, 100).topology()))
+    o, _ = env.reset(seed=3)
+    agent = MPCAgentConstant(env.simulator, env.action_space, env.gamma, safety_margin=0.96, planning_steps=1)
+    total = 0.0
+    for t in range(4):
+        a = agent.act(env)
+        assert isinstance(a, np.ndarray) and a.shape == (6,) and env.action_space.contains(a)
+        o, r, terminated, _, _ = env.step(a)
+        assert not terminated and isinstance(r, float)
+        total += r
+    assert total > -20.0  # the random agent loses ~175 per step on this task; the MPC policy a fraction of one
