@@ -422,3 +422,59 @@ def test_reference_example_custom_anm6_equals_the_live_reference():
         traj.append(np.array(rows))
     assert traj[0].shape == traj[1].shape
     npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+def test_new_env_template_with_callable_observation_and_own_bounds_equals_the_live_reference():
+    """examples/new_env_template.py filled in with the optional pieces: a CALLABLE observation (anm_env.py:511-514)
+    and an overridden observation_bounds() (anm_env.py:193-233) on the 3-bus loop -- the reference's ANMEnv and this
+    package's, same global NumPy seed."""
+    import numpy.testing as npt
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm import ANMEnv as Ref
+    from gym_anm_amd import ANMEnv as Ours
+    from gym_anm_amd import networks
+    from gym_anm_amd.spaces import Box
+
+    net = networks.three_bus_loop_network(base_mva=10, gen_max=100.0)
+
+    def make(base, extra, box):
+        class CustomEnvironment(base):
+            def __init__(self):
+                obs = lambda s: np.array([s[1] + s[2], s[-1] ** 2, np.tanh(s[0])])  # noqa: E731
+                super().__init__(net, obs, 2, 0.5, 0.95, 100, np.array([[0, 50], [-1, 1]]), (10, 200), 4, **extra)
+
+            def init_state(self):
+                s = np.random.rand(self.state_N)
+                s[-2:] = [3.0, 0.5]
+                return s
+
+            def next_vars(self, s_t):
+                return np.array([-3 * np.random.rand(), 40 * np.random.rand(), 60 * np.random.rand(), (s_t[-2] + 1) % 50, -s_t[-1]])
+
+            def observation_bounds(self):
+                return box(low=np.array([-50.0, 0.0, -1.0]), high=np.array([150.0, 1.0, 1.0]))
+
+        return CustomEnvironment
+
+    import gymnasium  # the harness's stand-in in the dev container
+
+    traj = []
+    for base, ex, box in ((Ref, {}, gymnasium.spaces.Box), (Ours, _KW(net), Box)):
+        env = make(base, ex, box)()
+        np.random.seed(21)
+        o, _ = env.reset()
+        npt.assert_array_equal(env.observation_space.high, [150.0, 1.0, 1.0])
+        rng = np.random.default_rng(2)
+        rows = [np.concatenate((o, [0.0, 0.0]))]
+        for t in range(40):
+            a = rng.uniform(env.action_space.low, env.action_space.high) * 0.2
+            o, r, term, _, _ = env.step(a)
+            rows.append(np.concatenate((o, [r, float(term)])))
+            if term:
+                break
+        traj.append(np.array(rows))
+    assert traj[0].shape == traj[1].shape and len(traj[0]) > 5
+    npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-8)
