@@ -71,6 +71,77 @@ class StateView:
         return self.full[:, off : off + n] * sc
 
 
+class _Component:
+    """Read-only stand-in for one of the reference's component objects (``Simulator.devices[i]`` / ``.buses[i]`` /
+    ``.branches[(i, j)]``, components/*.py): the constants of the spec as attributes of the reference's names (p.u.),
+    and the quantities a transition changes (``p``, ``q``, ``soc``, ``p_pot``, ``v``, ``i``, ``p_from`` ...) as
+    ``tensor[num_envs]`` read from the simulator's electrical state."""
+
+    def __init__(self, sim, const, dyn):
+        object.__setattr__(self, "_sim", sim)
+        object.__setattr__(self, "_const", const)
+        object.__setattr__(self, "_dyn", dyn)
+
+    def __getattr__(self, name):
+        c = object.__getattribute__(self, "_const")
+        if name in c:
+            return c[name]
+        d = object.__getattribute__(self, "_dyn")
+        if name in d:
+            return d[name](object.__getattribute__(self, "_sim"))
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        raise AttributeError("components of the batched simulator are read-only views (the state lives on the GPU)")
+
+    def __dir__(self):
+        return sorted(list(self._const) + list(self._dyn))
+
+
+def _component_views(sim):
+    from collections import OrderedDict
+
+    from .model import CLASSICAL, LOAD, RENEWABLE, SLACK, STORAGE
+
+    m = sim.model
+    F = lambda key, j: (lambda s: s.full[:, s.full_offsets[key] + j])  # noqa: E731
+    buses = OrderedDict()
+    for j, i in enumerate(m.bus_ids):
+        const = dict(id=i, type=0 if m.bus_is_slack[j] else 1, is_slack=bool(m.bus_is_slack[j]), baseKV=float(m.bus_baseKV[j]),
+                     v_max=float(m.bus_vmax[j]), v_min=float(m.bus_vmin[j]), p_min=float(m.bus_p_min[j]), p_max=float(m.bus_p_max[j]),
+                     q_min=float(m.bus_q_min[j]), q_max=float(m.bus_q_max[j]))  # fmt: skip
+        dyn = dict(p=F("bus_p", j), q=F("bus_q", j),
+                   v=lambda s, j=j: torch.polar(s.full[:, s.full_offsets["bus_v_magn"] + j], s.full[:, s.full_offsets["bus_v_ang"] + j]),
+                   i=lambda s, j=j: torch.polar(s.full[:, s.full_offsets["bus_i_magn"] + j], s.full[:, s.full_offsets["bus_i_ang"] + j]))
+        buses[i] = _Component(sim, const, dyn)
+    devices = OrderedDict()
+    for k, i in enumerate(m.dev_ids):
+        t = int(m.dev_type[k])
+        const = dict(dev_id=i, bus_id=m.dev_bus_id[k], type=t, is_slack=(t == SLACK), p_min=float(m.dev_p_min[k]),
+                     p_max=float(m.dev_p_max[k]), q_min=float(m.dev_q_min[k]), q_max=float(m.dev_q_max[k]))  # fmt: skip
+        dyn = dict(p=F("dev_p", k), q=F("dev_q", k))
+        if t == LOAD:
+            const["qp_ratio"] = float(m.dev_qp[k])
+        if t in (SLACK, CLASSICAL, RENEWABLE, STORAGE):
+            const.update(tau_1=float(m.dev_tau[k, 0]), tau_2=float(m.dev_tau[k, 1]), rho_1=float(m.dev_rho[k, 0]), rho_2=float(m.dev_rho[k, 1]))
+        if t in (CLASSICAL, RENEWABLE):
+            dyn["p_pot"] = F("gen_p_max", m.gen_idx.index(k))
+        if t == STORAGE:
+            j = m.des_idx.index(k)
+            const.update(tau_3=float(m.dev_tau[k, 2]), tau_4=float(m.dev_tau[k, 3]), rho_3=float(m.dev_rho[k, 2]), rho_4=float(m.dev_rho[k, 3]),
+                         soc_min=float(m.dev_soc_min[k]), soc_max=float(m.dev_soc_max[k]), eff=float(m.dev_eff[k]))  # fmt: skip
+            dyn["soc"] = lambda s, j=j: s.soc[:, j]
+        devices[i] = _Component(sim, const, dyn)
+    branches = OrderedDict()
+    for j, (f, t) in enumerate(m.branch_ids):
+        tap = complex(m.br_tap[j])
+        const = dict(f_bus=f, t_bus=t, series=complex(m.br_series[j]), shunt=complex(m.br_shunt[j]), tap=tap, tap_magn=abs(tap),
+                     shift=float(np.angle(tap)), rate=float(m.br_rate[j]))  # fmt: skip
+        dyn = dict(p_from=F("branch_p", j), q_from=F("branch_q", j), s_apparent_max=F("branch_s", j))
+        branches[(f, t)] = _Component(sim, const, dyn)
+    return buses, devices, branches
+
+
 class BatchedSimulator:
     def __init__(self, network, delta_t, lamb, num_envs=1, device="cuda", tol=1e-5, max_iter=100,
                  precision="f64", impl=None, handoff_after="auto", variants=None, env_variant=None,
@@ -157,6 +228,8 @@ class BatchedSimulator:
         self.penalty = torch.zeros(E_, **f64)
         self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
         self.nr_iters = torch.zeros(E_, dtype=torch.int32, device=self.device)
+        # the reference's component dictionaries (simulator.py:148-179), as read-only views
+        self.buses, self.devices, self.branches = _component_views(self)
 
     # ------------------------------------------------------------------------------------------
     def _device_ctx(self):

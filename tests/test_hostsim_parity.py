@@ -478,3 +478,72 @@ def test_new_env_template_with_callable_observation_and_own_bounds_equals_the_li
         traj.append(np.array(rows))
     assert traj[0].shape == traj[1].shape and len(traj[0]) > 5
     npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-8)
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+def test_the_references_anm6easy_methods_run_on_this_packages_anm6_base():
+    """The reference's OWN task code -- `ANM6Easy.init_state` and `ANM6Easy.next_vars`, the unmodified function objects
+    imported from /root/reference -- grafted onto this package's `ANM6` base class: they read `self.np_random`,
+    `self.simulator.devices[i].qp_ratio / q_min / q_max / soc_min / soc_max`, `self.K`, `self.delta_t`, and the
+    environment walks the trajectory of the reference's ANM6Easy."""
+    import numpy.testing as npt
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm.envs import ANM6Easy as Ref
+    from gym_anm.envs.anm6_env import anm6_easy as RE
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import ANM6 as OursANM6
+
+    extra = _KW(networks.anm6_network())
+
+    def init(self):
+        OursANM6.__init__(self, "state", 1, 0.25, 0.995, 100, np.array([[0, 95]]), (1, 100), **extra)
+        self.P_loads, self.P_maxs = RE._get_load_time_series(), RE._get_gen_time_series()
+
+    Grafted = type("ANM6EasyOnThisPackage", (OursANM6,), {"__init__": init, "init_state": RE.ANM6Easy.init_state,
+                                                          "next_vars": RE.ANM6Easy.next_vars})
+    traj = []
+    for cls in (Ref, Grafted):
+        env = cls()
+        o, _ = env.reset(seed=6)
+        rng = np.random.default_rng(8)
+        rows = [np.concatenate((o, [0.0, 0.0]))]
+        for t in range(80):
+            a = rng.uniform(env.action_space.low, env.action_space.high)
+            if t % 4:
+                a[2:] *= 0.25
+            o, r, term, _, _ = env.step(a)
+            rows.append(np.concatenate((o, [r, float(term)])))
+            if term:
+                o, _ = env.reset()
+                rows.append(np.concatenate((o, [0.0, 0.0])))
+        traj.append(np.array(rows))
+    assert traj[0].shape == traj[1].shape
+    npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-7)
+
+
+def test_component_views_of_the_simulator():
+    """`simulator.devices[i]`, `.buses[i]`, `.branches[(i, j)]` (simulator.py:148-179): constants under the reference's
+    attribute names, dynamic quantities as tensors over the batch; read-only."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    net = networks.anm6_network()
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=4, **_KW(net))
+    assert list(sim.devices) == [0, 1, 2, 3, 4, 5, 6] and list(sim.buses) == [0, 1, 2, 3, 4, 5]
+    assert list(sim.branches) == [(0, 1), (1, 2), (1, 3), (2, 4), (2, 5)]
+    d6, d1, d0 = sim.devices[6], sim.devices[1], sim.devices[0]
+    assert (d6.soc_min, d6.soc_max, d6.eff, d6.p_min, d6.p_max) == (0.0, 1.0, 0.9, -0.5, 0.5)
+    assert d1.qp_ratio == 0.2 and d1.type == -1 and d0.is_slack and not d6.is_slack and d6.bus_id == 5
+    assert sim.branches[(0, 1)].rate == 0.32 and sim.buses[1].v_max == 1.1 and sim.buses[0].is_slack
+    sim.soc[:] = 0.5
+    sim.transition({1: -5.0, 3: -20.0, 5: -25.0}, {2: 30.0, 4: 40.0}, {2: 30.0, 4: 50.0, 6: 10.0}, {2: 5.0, 4: -20.0, 6: 30.0})
+    # SURVEY 8(c)'s hand-checked case
+    assert abs(float(d6.soc[0]) - 0.4722222222222222) < 1e-12 and abs(float(sim.devices[2].p[0]) - 0.3) < 1e-12
+    assert abs(float(sim.buses[1].v.abs()[0]) - 1.006185017186) < 1e-9 and abs(float(sim.devices[4].p_pot[0]) - 0.4) < 1e-12
+    assert abs(float(sim.branches[(0, 1)].s_apparent_max[0]) + 0.295959430807) < 1e-9
+    with pytest.raises(AttributeError):
+        d6.soc = 0.3
+    with pytest.raises(AttributeError):
+        d1.soc_min
