@@ -127,6 +127,7 @@ class ANM6Easy:
     metadata = {"render_modes": []}
 
     def __init__(self, device="cuda", **kw):
+        kw.setdefault("track_full", True)  # `simulator.state` follows every step, as in the reference
         self.vec = ANM6EasyVec(num_envs=1, device=device, **kw)
         v = self.vec
         self.action_space, self.observation_space = v.action_space, v.observation_space

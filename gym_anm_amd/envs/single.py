@@ -51,6 +51,7 @@ class ANMEnv:
         # the attributes a constructor hook of the user (observation_bounds) may read exist before the batched
         # environment calls it
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
+        kw.setdefault("track_full", True)  # `simulator.state` / `.devices[i].p` follow every step, as in the reference
         self.vec = _Vec(network, batched_obs if obs_fn is not None else observation, K, delta_t, gamma, lamb, aux_bounds,
                         costs_clipping, seed, num_envs=1, device=device, **kw)
         v = self.vec

@@ -547,3 +547,25 @@ def test_component_views_of_the_simulator():
         d6.soc = 0.3
     with pytest.raises(AttributeError):
         d1.soc_min
+
+
+def test_single_environment_simulator_state_follows_the_steps():
+    """In the reference `env.simulator.state` / `.devices[i].p` are current after every step (simulator.py:529-537);
+    the NumPy-facing classes track the electrical state by default."""
+    from hostsim_backend import hostsim_backend
+
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import ANM6Easy
+
+    net = networks.anm6_network()
+    env = ANM6Easy(device="cpu", _backend=hostsim_backend(NetworkModel(net, 0.25, 100).topology()))
+    env.reset(seed=1)
+    for t in range(3):
+        a = 0.5 * (env.action_space.low + env.action_space.high)
+        o, r, term, _, _ = env.step(a)
+        assert not term
+        st = env.simulator.state
+        for k, dev in enumerate(range(7)):
+            assert abs(float(st["dev_p"]["MW"][dev][0]) - o[k]) < 1e-9          # the observation IS the state here
+            assert abs(float(env.simulator.devices[dev].p[0]) * 100.0 - o[k]) < 1e-9
+        assert abs(float(env.simulator.devices[6].soc[0]) * 100.0 - o[14]) < 1e-9
