@@ -40,7 +40,10 @@ class ANMEnv:
 
             def observation_bounds(self):
                 if user_bounds:
-                    outer.obs_values = self.obs_values  # what the reference's hook may look at
+                    # what the reference's hook may look at exists at this point of its constructor (anm_env.py:124-139)
+                    for name in ("simulator", "obs_values", "state_values", "state_N", "action_space"):
+                        if hasattr(self, name):
+                            setattr(outer, name, getattr(self, name))
                     return outer.observation_bounds()
                 return BatchedANMEnv.observation_bounds(self)
 
