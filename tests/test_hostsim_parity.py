@@ -569,3 +569,62 @@ def test_single_environment_simulator_state_follows_the_steps():
             assert abs(float(st["dev_p"]["MW"][dev][0]) - o[k]) < 1e-9          # the observation IS the state here
             assert abs(float(env.simulator.devices[dev].p[0]) * 100.0 - o[k]) < 1e-9
         assert abs(float(env.simulator.devices[6].soc[0]) * 100.0 - o[14]) < 1e-9
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("kind,n_bus,seed,n_chords", [("mesh", 5, 51, 2), ("radial", 8, 52, 0), ("mesh", 9, 53, 3)])
+def test_random_task_on_a_random_network_equals_the_live_reference(kind, n_bus, seed, n_chords):
+    """A task nobody wrote down: random network (several loads, generators, storage units), "state" observation,
+    K = 1, exogenous variables drawn from NumPy's global stream within the devices' limits, random agent --
+    the reference's ANMEnv and this package's, 60 steps with resets, same trajectory (state layout, device
+    ordering, SoC bookkeeping of several storage units, clipping, terminal handling)."""
+    import numpy.testing as npt
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm import ANMEnv as Ref
+    from gym_anm_amd import ANMEnv as Ours
+    from gym_anm_amd import networks
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if kind == "mesh" else networks.synthetic_radial_network(n_bus, seed)
+    m = NetworkModel(net, 0.25, 100)
+    b = m.baseMVA
+    load_lo = m.dev_p_min[m.load_idx] * b
+    gen_hi = m.dev_p_max[m.gen_idx] * b
+
+    def make(base, extra):
+        class Task(base):
+            def __init__(self):
+                super().__init__(net, "state", 1, 0.25, 0.99, 100, np.array([[0, 23]]), (1, 100), 0, **extra)
+
+            def init_state(self):
+                s = np.zeros(self.state_N)
+                D = self.simulator.N_device
+                s[:D] = np.random.uniform(-1, 1, D)
+                s[D : 2 * D] = np.random.uniform(-0.5, 0.5, D)
+                s[2 * D : 2 * D + self.simulator.N_des] = np.random.uniform(5, 20, self.simulator.N_des)
+                s[2 * D + self.simulator.N_des : -1] = np.random.uniform(0, 5, self.simulator.N_non_slack_gen)
+                return s
+
+            def next_vars(self, s_t):
+                return np.concatenate((np.random.uniform(0.5 * load_lo, 0.0), np.random.uniform(0.0, 0.6 * gen_hi), [(s_t[-1] + 1) % 24]))
+
+        return Task
+
+    traj = []
+    for base, ex in ((Ref, {}), (Ours, _KW(net))):
+        env = make(base, ex)()
+        np.random.seed(100 + seed)
+        o, _ = env.reset()
+        rng = np.random.default_rng(seed)
+        rows = [np.concatenate((o, [0.0, 0.0]))]
+        for t in range(60):
+            a = rng.uniform(env.action_space.low, env.action_space.high) * 0.3
+            o, r, term, _, _ = env.step(a)
+            rows.append(np.concatenate((o, [r, float(term)])))
+            if term:
+                o, _ = env.reset()
+                rows.append(np.concatenate((o, [0.0, 0.0])))
+        traj.append(np.array(rows))
+    assert traj[0].shape == traj[1].shape
+    npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-7)
