@@ -628,3 +628,62 @@ def test_random_task_on_a_random_network_equals_the_live_reference(kind, n_bus, 
         traj.append(np.array(rows))
     assert traj[0].shape == traj[1].shape
     npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("kind,n_bus,seed,n_chords", [("mesh", 6, 61, 2), ("radial", 10, 62, 0)])
+def test_the_whole_state_dictionary_equals_the_live_reference(kind, n_bus, seed, n_chords):
+    """`Simulator.transition(...)` with the reference's dict arguments on a random network with mixed base voltages,
+    then EVERY entry of `simulator.state[quantity][unit][id]` (simulator.py:551-636: all quantities, all units,
+    kV / kA conversions per bus) against the reference's dictionary."""
+    import numpy.testing as npt
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm.simulator import Simulator
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if kind == "mesh" else networks.synthetic_radial_network(n_bus, seed)
+    net = dict(net, bus=np.array(net["bus"], dtype=float).copy())
+    net["bus"][1:, 2] = [33.0 if i % 2 else 11.0 for i in range(1, n_bus)]       # mixed base voltages
+    ref = Simulator(net, 0.25, 100)
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=2, **_KW(net))
+    m = sim.model
+    rng = np.random.default_rng(seed)
+    b = m.baseMVA
+    loads = [m.dev_ids[k] for k in m.load_idx]
+    gens = [m.dev_ids[k] for k in m.gen_idx]
+    setp = [m.dev_ids[k] for k in m.setp_idx]
+    n_checked = 0
+    for trial in range(6):
+        P_load = {i: float(rng.uniform(0.6 * m.dev_p_min[m.dev_ids.index(i)] * b, 0.0)) for i in loads}
+        P_pot = {i: float(rng.uniform(0.0, m.dev_p_max[m.dev_ids.index(i)] * b)) for i in gens}
+        P_set = {i: float(rng.uniform(0.3 * m.dev_p_min[m.dev_ids.index(i)] * b, 0.3 * m.dev_p_max[m.dev_ids.index(i)] * b)) for i in setp}
+        Q_set = {i: float(rng.uniform(0.3 * m.dev_q_min[m.dev_ids.index(i)] * b, 0.3 * m.dev_q_max[m.dev_ids.index(i)] * b)) for i in setp}
+        soc = rng.uniform(0.2, 0.8, m.N_des) * np.array([m.dev_soc_max[k] for k in m.des_idx])
+        for j, k in enumerate(m.des_idx):
+            ref.devices[m.dev_ids[k]].soc = float(soc[j])
+        sim.soc[:] = torch.as_tensor(soc)
+        _, r_ref, e_ref, p_ref, conv_ref = ref.transition(P_load, P_pot, P_set, Q_set)
+        st, r, e, p, conv = sim.transition(P_load, P_pot, P_set, Q_set)
+        assert bool(conv[0]) == bool(conv_ref)
+        if not conv_ref:
+            continue
+        npt.assert_allclose([float(r[0]), float(e[0]), float(p[0])], [r_ref, e_ref, p_ref], rtol=1e-9, atol=1e-9)
+        assert set(st.keys()) == set(ref.state.keys())
+        for key in ref.state:
+            ours = st[key]
+            assert set(ours.keys()) == set(ref.state[key].keys()), key
+            for unit, per_id in ref.state[key].items():
+                assert list(ours[unit].keys()) == list(per_id.keys()), (key, unit)
+                for i, v in per_id.items():
+                    atol = 1e-9
+                    if key.endswith("_ang"):  # the angle of a small phasor is ill-conditioned: 1e-9 on the phasor itself
+                        mag = abs(ref.state[key.replace("_ang", "_magn")]["pu"][i])
+                        if mag < 1e-9:   # a bus nothing is injected at: the angle of rounding noise
+                            continue
+                        atol = min(1e-4, 1e-9 / mag) * (180.0 / np.pi if unit == "degree" else 1.0)
+                    npt.assert_allclose(float(ours[unit][i][0]), v, rtol=1e-9, atol=atol, err_msg="%s %s %s" % (key, unit, i))
+                    n_checked += 1
+    assert n_checked > 500
