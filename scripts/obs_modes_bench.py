@@ -22,11 +22,13 @@ class ListObs(ANM6EasyVec):
 dev = torch.device("cuda", 0)
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for cap in (20, 100):
-    for mode in ("state", "list", "list-unfused", "state+dump"):
+    for mode in ("state", "list", "list-soc-aux", "list-unfused", "state+dump"):
         kw = dict(num_envs=E, device=dev, seed=1, tol=1e-6, max_iter=cap, autoreset=True)
         if mode.startswith("list"):
             obs = [("bus_v_magn", "all", "pu"), ("branch_s", "all", "MVA"), ("des_soc", "all", "MWh"), ("aux", "all", None)]
-            env = ListObs(obs, fuse_observation=(mode == "list"), **kw)
+            if mode == "list-soc-aux":  # nothing electrical: what the general step kernel costs by itself
+                obs = obs[2:]
+            env = ListObs(obs, fuse_observation=(mode != "list-unfused"), **kw)
         else:
             env = ANM6EasyVec(track_full=(mode == "state+dump"), **kw)
         env.check_actions = False
