@@ -1,22 +1,25 @@
 // anm_mesh.hpp -- lane-group kernel for ANY network topology (loops, parallel feeders, transformers) of up
-// to 64 buses / branches / devices: the general-sparsity sibling of anm_radial.hpp.
+// to 65 buses, 128 branches, 64 devices: the general-sparsity sibling of anm_radial.hpp.
 //
 // The thread-per-environment kernels keep a whole environment in one thread's registers; that stops
 // working around a dozen buses (a meshed 30-bus network: 512 registers + scratch per lane, 2.8 ms per
 // 16 384 transitions).  The radial kernel spreads an environment over a lane group but relies on the
 // network being a tree.  Here the same lane group works on a general sparse Jacobian:
-//     lane l  <->  bus l + 1,  branch l,  device l           (three roles at once, as in anm_radial.hpp)
+//     lane l  <->  bus l + 1,  device l,  branches l and G + l      (the group size follows the buses)
 // Per Newton iteration
-//   bus lanes publish V; BRANCH lanes form the products W_ft = V_f conj(Y_ft V_t), W_tf of their branch and
-//   with them the two off-diagonal 2x2 Jacobian blocks of the branch; bus lanes sum their row of W (mismatch,
-//   diagonal block); the group-wide inf-norm is a shuffle butterfly;
-//   the block matrix lives in LDS ([blocks][4] doubles per environment) and is eliminated with the static,
-//   fill-minimising order computed once per network on the host (build_plan: minimum degree), LEVEL by level:
-//   pivots of one level are pairwise non-adjacent, so they invert their diagonal blocks together, then every
-//   lane applies the updates of its own row (task list: pivot, its block L_ik, the (destination, source)
-//   block pairs); back substitution walks the levels in reverse.
-// A workgroup is one wavefront whose LDS operations complete in program order, so the hand-overs between
-// the phases need compiler fences only.  Nothing is compiled per topology: integer tables drive one generic
+//   bus roles publish V; BRANCH roles form the products W_ft = V_f conj(Y_ft V_t), W_tf of their branch and
+//   with them the two off-diagonal 2x2 Jacobian blocks of the branch; bus roles sum their row of W (mismatch,
+//   diagonal block); the group-wide stop test is two lane masks;
+//   the block matrix lives in LDS ([blocks][4] doubles per environment, the right-hand side as one more block
+//   column) and is factorised by a PROGRAM OF STEPS that build_plan schedules once per network on the host
+//   (order: rounds of pairwise non-adjacent pivots of near-minimal degree; see StepType / OpKind below): in a
+//   step every lane carries out at most one small operation named by its descriptor, operations go to
+//   whatever lanes are free, a fence separates the steps; per level one step of products
+//   M = A_ik D_k^-1 A_kj and one of sums A_ij -= sum M, then one back-substitution step per level (the last
+//   two buses as one dense step).  tests/hostsim/mesh_program_check.cpp executes the schedule on the host.
+// A workgroup is 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet; a lane
+// group lies within one wavefront, whose LDS operations complete in program order, so the hand-overs between
+// the steps need compiler fences only.  Nothing is compiled per topology: integer tables drive one generic
 // kernel (the reference solves whatever network it is given: solve_load_flow.py:123-164, 220 -- SciPy's
 // sparse LU on the same matrix).  Same reference semantics and the same formulation (W products, magnitude
 // columns scaled by |V|, (cos, sin) state, rotated stop test) as anm_device.hpp; see the citations there.
