@@ -9,9 +9,9 @@
 //     lane l of the group  <->  bus l + 1  (and the branch joining it to its parent bus),
 // so that one trip costs the wavefront ~1/3 of the instructions: every lane forms the three W products
 // of its own tree edge, the tree is eliminated by height (all leaves at once, then their parents, ...)
-// and back-substituted by depth.  All hand-overs between lanes are register-to-register
-// (`ds_bpermute_b32`: the LDS crossbar without touching LDS memory); nothing is stored anywhere inside the
-// loop.  Everything structural (parent, children, height, depth of each bus, position of its admittances
+// and back-substituted by depth.  Hand-overs between lanes are register-to-register where the tree allows
+// it (DPP row shifts, else `ds_bpermute_b32`: nothing is stored anywhere inside the loop) or go through LDS
+// slots (the radial kernel's larger trees, see LDSX below).  Everything structural (parent, children, height, depth of each bus, position of its admittances
 // in the constant buffer) is a constexpr table of the Topo descriptor (codegen.py: tree_tables), so the
 // level loops are unrolled and a level only pulls as many child slots as a bus of that height can have.
 //
@@ -32,8 +32,8 @@ namespace group {
 enum : int { FCMP_UNO = 8, FCMP_UGT = 10, ICMP_NE = 33, ICMP_SLT = 40 };
 
 // ---------------------------------------------------------------------------------------------
-// Hand-overs between the lanes of a group.  Two implementations behind one interface, chosen per topology
-// by codegen.dpp_plan:
+// Hand-overs between the lanes of a group.  Two register-to-register implementations behind one interface,
+// chosen per topology by codegen.dpp_plan (a third one, through LDS slots, lives in newton_groups<.., LDSX>):
 //   * DPP row shifts (v_mov_b32_dpp row_shl/row_shr + bank mask): no latency to wait for, when the tree has
 //     a lane layout in which every hand-over class is at most two whole-row shifts;
 //   * ds_bpermute_b32 (the LDS crossbar, no LDS memory): any tree, ~100 cycles of latency per hand-over.
