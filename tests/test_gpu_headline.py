@@ -261,6 +261,13 @@ def test_mesh_transition_golden(name):
     assert sim.impl == "mesh"
 
 
+@pytest.mark.parametrize("name", ["anm6", "3bus", "case30"])
+def test_mesh_transition_golden_f32_jacobian(name):
+    """The fp32 Jacobian / factorisation mode of the general lane-group kernel (mismatch, stop test and update stay
+    fp64): same flags, electrical state within 2e-6 p.u. of the golden vectors."""
+    pc.check_transition_against_golden(name, pc.golden_nets()[name], DEV, precision="f32", atol=2e-6, check_iters=False, impl="mesh")
+
+
 def test_mesh_anm6easy_episodes():
     from gym_anm_amd.envs import ANM6EasyVec
 
