@@ -40,7 +40,7 @@ def test_headline_config_oracle_replay(handoff):
     assert n >= 256 and n_term >= 32 and n_reset >= 32
 
 
-@pytest.mark.parametrize("name,impl", [("anm6", "thread"), ("anm6", "radial"), ("3bus", "thread")])
+@pytest.mark.parametrize("name,impl", [("anm6", "thread"), ("anm6", "radial"), ("anm6", "mesh"), ("3bus", "thread"), ("3bus", "mesh")])
 def test_reset_golden_simulator_and_env(name, impl):
     env = pc.reset_golden(name, KW, impl)
     assert env.simulator.backend.path.endswith(".so") and "gym_anm_amd/_build/libanm_" in env.simulator.backend.path
