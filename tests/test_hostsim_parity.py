@@ -611,9 +611,11 @@ def test_random_task_on_a_random_network_equals_the_live_reference(kind, n_bus, 
 
         return Task
 
-    traj = []
+    traj, spaces_ = [], []
     for base, ex in ((Ref, {}), (Ours, _KW(net))):
         env = make(base, ex)()
+        spaces_.append((env.state_N, list(env.state_values), np.asarray(env.observation_space.low), np.asarray(env.observation_space.high),
+                        np.asarray(env.action_space.low), np.asarray(env.action_space.high)))
         np.random.seed(100 + seed)
         o, _ = env.reset()
         rng = np.random.default_rng(seed)
@@ -628,6 +630,9 @@ def test_random_task_on_a_random_network_equals_the_live_reference(kind, n_bus, 
         traj.append(np.array(rows))
     assert traj[0].shape == traj[1].shape
     npt.assert_allclose(traj[1], traj[0], rtol=1e-9, atol=1e-7)
+    assert spaces_[0][0] == spaces_[1][0] and spaces_[0][1] == spaces_[1][1]          # state_N, state_values
+    for a, b in zip(spaces_[0][2:], spaces_[1][2:]):                                      # observation and action boxes
+        npt.assert_array_equal(a, b)
 
 
 @pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
