@@ -595,7 +595,10 @@ def test_random_task_on_a_random_network_equals_the_live_reference(kind, n_bus, 
     def make(base, extra):
         class Task(base):
             def __init__(self):
-                super().__init__(net, "state", 1, 0.25, 0.99, 100, np.array([[0, 23]]), (1, 100), 0, **extra)
+                if seed == 52:  # the optional arguments left at their defaults (anm_env.py:79-90)
+                    super().__init__(net, "state", 1, 0.25, 0.99, 100, **extra)
+                else:
+                    super().__init__(net, "state", 1, 0.25, 0.99, 100, np.array([[0, 23]]), (1, 100), 0, **extra)
 
             def init_state(self):
                 s = np.zeros(self.state_N)
