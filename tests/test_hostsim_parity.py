@@ -695,3 +695,57 @@ def test_the_whole_state_dictionary_equals_the_live_reference(kind, n_bus, seed,
                     npt.assert_allclose(float(ours[unit][i][0]), v, rtol=1e-9, atol=atol, err_msg="%s %s %s" % (key, unit, i))
                     n_checked += 1
     assert n_checked > 500
+
+
+@pytest.mark.skipif(not _reference_available(), reason="reference checkout not present (GPU box)")
+def test_bad_observation_specs_fail_like_the_live_reference():
+    """Observation arguments the reference refuses (anm_env.py:497-545, 193-233): same exception class at
+    construction, or -- where the reference only fails later, in reset() -- a failure at the same stage."""
+    import ref_harness
+
+    ref_harness.load_reference()
+    from gym_anm import ANMEnv as Ref
+    from gym_anm_amd import ANMEnv as Ours
+    from gym_anm_amd import networks
+
+    net = networks.anm6_network()
+    extra = _KW(net)
+    bad = [
+        42,                                             # neither "state", nor a list, nor callable
+        "full",                                         # an unknown string
+        [("foo_p", "all", "MW")],                       # unknown quantity with 'all'
+        [("bus_p", "all", "kV")],                       # unit of another quantity
+        [("dev_p", [0, 99], "MW")],                     # unknown device id
+        [("branch_s", [(0, 5)], "pu")],                 # unknown branch
+        [("des_soc", [2], "MWh")],                      # not a storage unit
+    ]
+
+    def outcome(cls, obs, ex):
+        class Task(cls):
+            def __init__(self):
+                super().__init__(net, obs, 1, 0.25, 0.9, 100, np.array([[0, 10]]), (1, 100), 1, **ex)
+
+            def init_state(self):
+                s = np.zeros(self.state_N)
+                s[-1] = 3
+                return s
+
+            def next_vars(self, s_t):
+                return np.array([-1.0, -2.0, -3.0, 10.0, 10.0, 4.0])
+
+        try:
+            env = Task()
+        except Exception as e:  # noqa: BLE001
+            return "init", type(e).__name__
+        try:
+            env.reset()
+        except Exception as e:  # noqa: BLE001
+            return "reset", type(e).__name__
+        return "ok", None
+
+    for obs in bad:
+        r, o = outcome(Ref, obs, {}), outcome(Ours, obs, extra)
+        assert r[0] != "ok", obs
+        assert o[0] == r[0], (obs, r, o)
+        if r[1] not in ("KeyError", "TypeError", "IndexError", "ValueError", "AttributeError"):   # the reference's own classes
+            assert o[1] == r[1], (obs, r, o)
