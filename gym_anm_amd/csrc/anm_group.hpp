@@ -307,23 +307,41 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       static_for<0, T::T_MAXH + 1>([&](auto H) {
         constexpr int h = H;
         constexpr int NC = T::T_NCH_H[h];
-        JT ga[NC > 0 ? NC : 1], gbb[NC > 0 ? NC : 1], gc[NC > 0 ? NC : 1], gd[NC > 0 ? NC : 1], g0[NC > 0 ? NC : 1],
-            g1[NC > 0 ? NC : 1];
-        static_for<0, NC>([&](auto Cc) {
-          if constexpr (LDSX) {
-            const int c = cl[Cc];
-            ga[Cc] = JT(xl[XA_SC * 64 + c]); gbb[Cc] = JT(xl[(XA_SC + 1) * 64 + c]);
-            gc[Cc] = JT(xl[(XA_SC + 2) * 64 + c]); gd[Cc] = JT(xl[(XA_SC + 3) * 64 + c]);
-            g0[Cc] = JT(xl[XA_LR * 64 + c]); g1[Cc] = JT(xl[(XA_LR + 1) * 64 + c]);
-          } else {
+        // register hand-overs: every lane executes the moves, so they are collected first (NC child slots x 6
+        // values); LDS hand-overs: only the lanes of this height read, and fold as they read -- no staging arrays
+        // (they cost the LDS variant 9 registers too many for a third wavefront per SIMD)
+        JT ga[(!LDSX && NC > 0) ? NC : 1], gbb[(!LDSX && NC > 0) ? NC : 1], gc[(!LDSX && NC > 0) ? NC : 1],
+            gd[(!LDSX && NC > 0) ? NC : 1], g0[(!LDSX && NC > 0) ? NC : 1], g1[(!LDSX && NC > 0) ? NC : 1];
+        if constexpr (!LDSX) {
+          static_for<0, NC>([&](auto Cc) {
             ga[Cc] = X.template from_child<Cc>(Sc.a); gbb[Cc] = X.template from_child<Cc>(Sc.b);
             gc[Cc] = X.template from_child<Cc>(Sc.c); gd[Cc] = X.template from_child<Cc>(Sc.d);
             g0[Cc] = X.template from_child<Cc>(Lr0); g1[Cc] = X.template from_child<Cc>(Lr1);
-          }
-        });
+          });
+        }
         if (height == h) {
           static_for<0, NC>([&](auto Cc) {
-            if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
+            if constexpr (LDSX) {
+              // three child slots are fetched together, then folded (a padding lane's slots hold zeros): staging all
+              // NC slots costs up to 60 registers (and the third wavefront per SIMD), one slot at a time one LDS
+              // latency per child
+              if constexpr (Cc % 3 == 0) {
+                constexpr int CB = (Cc + 1 < NC) ? Cc + 1 : Cc, CC = (Cc + 2 < NC) ? Cc + 2 : Cc;
+                const int c0 = cl[Cc], c1 = cl[CB], c2 = cl[CC];
+                double q0[6], q1[6], q2[6];
+                static_for<0, 6>([&](auto A) {
+                  constexpr int arr = (A < 4) ? XA_SC + A : XA_LR + (A - 4);
+                  q0[A] = xl[arr * 64 + c0]; q1[A] = xl[arr * 64 + c1]; q2[A] = xl[arr * 64 + c2];
+                });
+                Dg.a -= JT(q0[0]); Dg.b -= JT(q0[1]); Dg.c -= JT(q0[2]); Dg.d -= JT(q0[3]); r0 -= JT(q0[4]); r1 -= JT(q0[5]);
+                if constexpr (CB != Cc) {
+                  Dg.a -= JT(q1[0]); Dg.b -= JT(q1[1]); Dg.c -= JT(q1[2]); Dg.d -= JT(q1[3]); r0 -= JT(q1[4]); r1 -= JT(q1[5]);
+                }
+                if constexpr (CC != Cc) {
+                  Dg.a -= JT(q2[0]); Dg.b -= JT(q2[1]); Dg.c -= JT(q2[2]); Dg.d -= JT(q2[3]); r0 -= JT(q2[4]); r1 -= JT(q2[5]);
+                }
+              }
+            } else if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
               Dg.a -= ga[Cc]; Dg.b -= gbb[Cc]; Dg.c -= gc[Cc]; Dg.d -= gd[Cc];
               r0 -= g0[Cc]; r1 -= g1[Cc];
             }
