@@ -1,6 +1,6 @@
 """Batched (and single-environment) drop-ins for ``gym_anm.envs``."""
 
 from .anm_env import BatchedANMEnv
-from .anm6 import ANM6Vec, ANM6EasyVec, ANM6Easy
-from .single import ANM6, ANMEnv
+from .anm6 import ANM6Vec, ANM6EasyVec
+from .single import ANM6, ANM6Easy, ANMEnv
 from .vector import NumpyVectorEnv

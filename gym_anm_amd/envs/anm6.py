@@ -6,7 +6,7 @@ scope) and ``gym_anm/envs/anm6_env/anm6_easy.py`` (task constants :12-19, ``init
 
 * :class:`ANM6EasyVec` -- ``num_envs`` copies on one MI355X.  The daily series live in HBM and the
   ``next_vars`` lookup is fused into the step kernel ("series mode"), so a step is one launch.
-* :class:`ANM6Easy` -- the reference's single-environment NumPy-facing surface
+* the reference's single-environment NumPy-facing ``ANM6`` / ``ANM6Easy`` live in ``single.py``
   (``reset() -> (ndarray(18,), {})``, ``step(ndarray(6,)) -> (ndarray(18,), float, bool, False, {})``)
   on top of a 1-environment batch; its ``reset(seed=...)`` consumes the NumPy generator exactly
   like the reference does, so seeded episodes are reproducible against it.
@@ -119,71 +119,3 @@ class ANM6EasyVec(ANM6Vec):
         aux = torch.remainder(s_t[:, -1] + 1, 24 / self.delta_t).long()
         tab = torch.as_tensor(anm6easy_series(), dtype=torch.float64, device=s_t.device)
         return torch.cat([tab[:, aux].T, aux.unsqueeze(1).to(torch.float64)], dim=1)
-
-
-class ANM6Easy:
-    """Single-environment ``ANM6Easy-v0`` with the reference's NumPy-facing contract."""
-
-    metadata = {"render_modes": []}
-
-    def __init__(self, device="cuda", **kw):
-        kw.setdefault("track_full", True)  # `simulator.state` follows every step, as in the reference
-        self.vec = ANM6EasyVec(num_envs=1, device=device, **kw)
-        v = self.vec
-        self.action_space, self.observation_space = v.action_space, v.observation_space
-        self.K, self.gamma, self.lamb, self.delta_t = v.K, v.gamma, v.lamb, v.delta_t
-        self.costs_clipping = v.costs_clipping
-        self.simulator = v.simulator
-        self.state_N, self.observation_N = v.state_N, v.observation_N
-        self.timestep_length = v.timestep_length
-        self.date = self.date_init = None
-        self.year_count = 0
-        self.render_mode = None
-        self.terminated = False
-        self.timestep = 0
-        self.e_loss = self.penalty = 0.0
-        self.state = None
-
-    @property
-    def np_random(self):
-        return self.vec.np_random
-
-    def _sync_attrs(self):
-        v = self.vec
-        self.state = v.state[0].cpu().numpy()
-        self.terminated = bool(v.terminated[0])
-        self.timestep = int(v.timestep[0])
-        self.e_loss = float(v.e_loss[0])
-        self.penalty = float(v.penalty[0])
-
-    def reset(self, *, seed=None, options=None):
-        opts = dict(options or {})
-        date_init = opts.pop("date_init", None)
-        obs, info = self.vec.reset(seed=seed, options=opts or None)
-        self._sync_attrs()
-        # ANM6.reset (anm6.py:124-141) then ANM6Easy.reset (anm6_easy.py:67-74)
-        self.year_count = 0
-        self.date_init = date_init if date_init is not None else random_date(self.vec.np_random, 2020)
-        self.date = self.date_init
-        self.date_init = self.date = self.date + self.state[-1] * self.timestep_length
-        o = obs[0].cpu().numpy()
-        assert self.observation_space.contains(o), "Observation %r (%s) invalid." % (o, type(o))
-        return o, info
-
-    def step(self, action):
-        action = np.asarray(action, dtype=np.float64)
-        assert self.action_space.contains(action), "Action %r (%s) invalid." % (action, type(action))
-        if self.terminated:
-            return np.zeros(self.observation_N), 0.0, True, False, {}
-        self.vec.check_actions = False
-        obs, r, term, trunc, info = self.vec.step(torch.as_tensor(action).unsqueeze(0))
-        self._sync_attrs()
-        self.date += self.timestep_length  # anm6.py:113-122
-        self.year_count = (self.date - self.date_init).days // 365
-        return obs[0].cpu().numpy(), float(r[0]), bool(term[0]), False, info
-
-    def render(self, mode="human", skip_frames=0):
-        raise NotImplementedError("the web renderer of the reference is out of scope for this build")
-
-    def close(self):
-        pass

@@ -55,8 +55,8 @@ class ANMEnv:
         # environment calls it
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
         kw.setdefault("track_full", True)  # `simulator.state` / `.devices[i].p` follow every step, as in the reference
-        self.vec = _Vec(network, batched_obs if obs_fn is not None else observation, K, delta_t, gamma, lamb, aux_bounds,
-                        costs_clipping, seed, num_envs=1, device=device, **kw)
+        self.vec = self._make_vec(_Vec, network, batched_obs if obs_fn is not None else observation, K, delta_t, gamma,
+                                  lamb, aux_bounds, costs_clipping, seed, device, kw)
         v = self.vec
         self.simulator = v.simulator
         self.action_space, self.observation_space = v.action_space, v.observation_space
@@ -70,6 +70,11 @@ class ANMEnv:
         self.e_loss = self.penalty = 0.0
         self.state = None
         self.pfe_converged = None
+
+    def _make_vec(self, vec_cls, network, observation, K, delta_t, gamma, lamb, aux_bounds, costs_clipping, seed, device, kw):
+        """The one-environment batched environment underneath (a subclass with a fused task overrides this)."""
+        return vec_cls(network, observation, K, delta_t, gamma, lamb, aux_bounds, costs_clipping, seed, num_envs=1,
+                       device=device, **kw)
 
     # ---- hooks (anm_env.py:158-233) ----------------------------------------------------------------------------
     def init_state(self):
@@ -157,3 +162,32 @@ class ANM6(ANMEnv):
             self.date += self.timestep_length  # anm6.py:113-122
             self.year_count = (self.date - self.date_init).days // 365
         return out
+
+
+class ANM6Easy(ANM6):
+    """``ANM6Easy-v0`` (anm6_env/anm6_easy.py): the reference's single-environment, NumPy-facing task.  Underneath runs
+    :class:`ANM6EasyVec` with the daily series fused into the step kernel; ``init_state`` / ``next_vars`` are the
+    batched class's (environment 0 consumes ``np_random`` in the reference's order)."""
+
+    def __init__(self, device="cuda", **kw):
+        self._kw = kw
+        super().__init__("state", 1, 0.25, 0.995, 100, np.array([[0, 24 / 0.25 - 1]]), (1, 100), kw.pop("seed", None),
+                         device=device, **kw)
+        self.P_loads, self.P_maxs = self.vec.P_loads, self.vec.P_maxs
+
+    def _make_vec(self, vec_cls, network, observation, K, delta_t, gamma, lamb, aux_bounds, costs_clipping, seed, device, kw):
+        from .anm6 import ANM6EasyVec
+
+        return ANM6EasyVec(num_envs=1, device=device, seed=seed, **kw)
+
+    def init_state(self):
+        return self.vec.init_state()[0]
+
+    def next_vars(self, s_t):
+        return self.vec.next_vars(np.asarray(s_t, dtype=np.float64).reshape(1, -1))[0].cpu().numpy()
+
+    def reset(self, *, seed=None, options=None):
+        obs, info = super().reset(seed=seed, options=options)
+        # anm6_easy.py:67-74: the displayed date starts at the sampled time of day
+        self.date_init = self.date = self.date + self.state[-1] * self.timestep_length
+        return obs, info
