@@ -18,10 +18,11 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from ..spaces import GymEnv
 from .anm_env import BatchedANMEnv
 
 
-class ANMEnv:
+class ANMEnv(GymEnv):  # gymnasium.Env when gymnasium is installed (wrappers, gym.make), a minimal stand-in otherwise
     metadata = {"render_modes": []}
 
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=(None, None),
