@@ -75,7 +75,8 @@ class _Component:
     """Read-only stand-in for one of the reference's component objects (``Simulator.devices[i]`` / ``.buses[i]`` /
     ``.branches[(i, j)]``, components/*.py): the constants of the spec as attributes of the reference's names (p.u.),
     and the quantities a transition changes (``p``, ``q``, ``soc``, ``p_pot``, ``v``, ``i``, ``p_from`` ...) as
-    ``tensor[num_envs]`` read from the simulator's electrical state."""
+    ``tensor[num_envs]`` read from the simulator's electrical state.  With per-environment networks (``variants=``) the
+    constants are those of the base network (class 0), like the observation Box."""
 
     def __init__(self, sim, const, dyn):
         object.__setattr__(self, "_sim", sim)
