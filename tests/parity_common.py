@@ -584,3 +584,47 @@ def reference_example_simple_env(kw):
         assert -10.0 <= o[1] <= 0.0 and abs(o[3] - 0.2 * o[1]) < 1e-12
     assert env.state.shape == (5,) and env.timestep == 10
     return env
+
+
+def single_env_with_callable_observation(kw):
+    """`gym_anm_amd.ANMEnv` (NumPy-facing, one environment) with a callable observation, an overridden
+    observation_bounds() and K = 2 on the 3-bus loop: the observation is the callable of the state vector, the state
+    follows the oracle's environment step by step."""
+    import anm_oracle as O
+    from gym_anm_amd import ANMEnv
+    from gym_anm_amd.spaces import Box
+
+    net = networks.three_bus_loop_network(base_mva=10, gen_max=100.0)
+    extra = kw(net)
+    fn = lambda s: np.array([s[1] + s[2], s[-1] ** 2, np.tanh(s[0])])  # noqa: E731
+
+    class Task(ANMEnv):
+        def __init__(self):
+            super().__init__(net, fn, 2, 0.5, 0.95, 100, np.array([[0, 50], [-1, 1]]), (10, 200), 4, **extra)
+            self._rng = np.random.default_rng(17)
+
+        def init_state(self):
+            s = self._rng.uniform(size=self.state_N)
+            s[-2:] = [3.0, 0.5]
+            return s
+
+        def next_vars(self, s_t):
+            return np.array([-3 * self._rng.uniform(), 40 * self._rng.uniform(), 60 * self._rng.uniform(), (s_t[-2] + 1) % 50, -s_t[-1]])
+
+        def observation_bounds(self):
+            return Box(low=np.array([-50.0, 0.0, -1.0]), high=np.array([150.0, 1.0, 1.0]))
+
+    env = Task()
+    o, _ = env.reset()
+    npt.assert_array_equal(env.observation_space.high, [150.0, 1.0, 1.0])
+    npt.assert_allclose(o, np.clip(fn(env.state), env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-12)
+    rng = np.random.default_rng(2)
+    for t in range(25):
+        a = rng.uniform(env.action_space.low, env.action_space.high) * 0.2
+        o, r, term, trunc, _ = env.step(a)
+        assert isinstance(o, np.ndarray) and o.shape == (3,) and isinstance(r, float) and trunc is False
+        if term:
+            break
+        npt.assert_allclose(o, np.clip(fn(env.state), env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-12)
+        assert abs(env.state[-2] - (3.0 + t + 1) % 50) < 1e-12          # the aux variables follow next_vars
+    return env

@@ -749,3 +749,7 @@ def test_bad_observation_specs_fail_like_the_live_reference():
         assert o[0] == r[0], (obs, r, o)
         if r[1] not in ("KeyError", "TypeError", "IndexError", "ValueError", "AttributeError"):   # the reference's own classes
             assert o[1] == r[1], (obs, r, o)
+
+
+def test_single_environment_class_with_callable_observation():
+    pc.single_env_with_callable_observation(_KW)
