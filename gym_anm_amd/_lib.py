@@ -51,6 +51,15 @@ class StepWs(C.Structure):
     _fields_ = [("buf", C.c_void_p), ("n_doubles", C.c_int64), ("iter_cap", C.c_int32), ("reserved", C.c_int32)]
 
 
+class MpcDims(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ["planning_steps", "n_load", "n_gen", "n_des", "n_branch", "n_ctrl",
+                                         "n_stage_vars", "n_stage_rows", "table_doubles"]]  # fmt: skip
+
+
+class MpcOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32)]
+
+
 class SolverOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("precision", C.c_int32), ("handoff_after", C.c_int32)]
 
@@ -94,7 +103,11 @@ ABI = {
     "anm_model_bind_state_same": (C.c_int, [C.c_void_p, _P]),
     "anm_model_obs_fusable": (C.c_int, [C.c_void_p]),
     "anm_model_set_obs": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p]),
-    "anm_admm_update_f64": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_double] + [_P] * 9 + [_P]),
+    "anm_mpc_create": (C.c_int, [C.POINTER(NetworkDesc), C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
+    "anm_mpc_destroy": (None, [C.c_void_p]),
+    "anm_mpc_dims_of": (C.c_int, [C.c_void_p, C.POINTER(MpcDims)]),
+    "anm_mpc_get_tables": (C.c_int, [C.c_void_p, c_double_p]),
+    "anm_mpc_solve_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 8 + [C.POINTER(MpcOpts), _P]),
     "anm_gather_obs_f64": (C.c_int, [C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P,
                                      _P]),
     "anm_time_step_launches": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 9 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,

@@ -6,23 +6,23 @@ constraint MATRIX depends only on the network and the horizon; what changes from
 environment to environment are right-hand sides: the load / generation forecasts and the storage state
 of charge (``mpc.py:390-417``).  So here
 
-* :class:`DCOPFProgram` assembles the LP once (NumPy), in the form  min q.x  s.t.  l <= A x <= u  with
-  ``l, u`` affine in the per-environment parameters;
-* :class:`BatchedADMM` solves all environments together with an OSQP-style ADMM whose linear system
-  ``(sigma I + A' diag(rho) A)`` is inverted ONCE on the host: an iteration is two dense fp64 GEMMs over the
-  whole batch (rocBLAS on the MI355X: ``[num_envs, n+m] x [n+m, n]`` and ``[num_envs, n] x [n, m]``) plus an
-  element-wise projection / dual update; iterates are warm-started from the previous call;
+* :class:`BatchedDCOPF` solves all environments in ONE launch of the hand-written interior-point kernel
+  (``csrc/anm_mpc.hpp``; the reduced, stage-structured form of the program is documented in ``dcopf.py``);
 * :class:`MPCAgent` / :class:`MPCAgentConstant` / :class:`MPCAgentPerfect` keep the reference's names,
   constructor arguments and ``act(env)`` contract (``mpc.py:321-346``, ``mpc_constant.py``, ``mpc_perfect.py``)
-  on a :class:`~gym_anm_amd.envs.anm_env.BatchedANMEnv`.
+  on a :class:`~gym_anm_amd.envs.anm_env.BatchedANMEnv`;
+* :class:`DCOPFProgram` spells the reference's program out row by row (``min q.x, l <= A x <= u``); nothing in
+  the solve uses it -- it is what the tests check a solution's feasibility against.
 
 All quantities are per-unit, as in the reference.  An LP optimum is not unique in general (curtailment vs
 storage, charge vs discharge splits), so two exact solvers may return different optimal actions; what is
-comparable is the optimal objective and the feasibility of the action (tests/test_mpc.py, against
-``scipy.optimize.linprog`` on an independently assembled copy of the reference's program).
+comparable is the optimal objective, the feasibility of the action, and the action itself where the minimiser
+is unique (tests/test_mpc.py).
 """
 
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import torch
@@ -143,128 +143,105 @@ class DCOPFProgram:
         return x @ torch.as_tensor(self.q, dtype=torch.float64, device=x.device)
 
 
-class BatchedADMM:
-    """OSQP-style ADMM for  min q.x, l <= A x <= u  over a batch sharing q and A (Stellato et al., OSQP, alg. 1 with
-    P = 0).  Equality rows get a 1e3 times larger penalty; the problem is Ruiz-equilibrated; rho is re-tuned from
-    the residual ratio every ``adapt_every`` iterations (a refactorisation = one small host inverse)."""
+class BatchedDCOPF:
+    """The N-stage DC-OPF of every environment of a batch, solved on the device by ONE launch of the
+    interior-point kernel (``anm_mpc_solve_f64``, ``csrc/anm_mpc.hpp``): one lane per stage, ``64 / 2^ceil(log2 N)``
+    environments per wavefront, the network tables of the reduced program (``dcopf.py``) as scalar loads.
 
-    def __init__(self, A, q, eq_mask, device, sigma=1e-6, rho=0.1, alpha=1.6, backend=None):
-        self.device = torch.device(device)
-        self.backend = backend  # library with anm_admm_update_f64 (the fused non-GEMM part of an iteration)
-        A = np.asarray(A, float)
-        self.m, self.n = A.shape
-        # Ruiz equilibration of [0 A'; A 0]
-        D, Ee = np.ones(self.n), np.ones(self.m)
-        As = A.copy()
-        for _ in range(15):
-            cn = np.sqrt(np.maximum(np.abs(As).max(axis=0), 1e-8))
-            rn = np.sqrt(np.maximum(np.abs(As).max(axis=1), 1e-8))
-            As = As / rn[:, None] / cn[None, :]
-            D, Ee = D / cn, Ee / rn
-        self.D, self.E = D, Ee
-        qs = D * q
-        self.c = 1.0 / max(np.abs(qs).max(), 1e-8)
-        self.As, self.qs = As, qs * self.c
-        self.sigma, self.alpha = sigma, alpha
-        self.eq = np.asarray(eq_mask, bool)
-        self.rho0 = rho
-        self._factor(rho)
-        t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=self.device)
-        self.tD, self.tE, self.tq = t(D), t(Ee), t(self.qs)
-        self.x = self.z = self.y = None
+    ``solve(P_load_forecast [E, n_load, N], P_gen_forecast [E, n_gen, N], soc [E, n_des])`` -> the first-stage
+    ``[P_gen.., P_des..]`` (p.u.); ``objective``, ``iters``, ``info`` (final complementarity, row residual) and, on
+    request, the whole primal solution stay available as tensors."""
 
-    def _factor(self, rho):
-        self.rho = rho
-        rv = np.where(self.eq, 1e3 * rho, rho)
-        M = self.sigma * np.eye(self.n) + self.As.T @ (rv[:, None] * self.As)
-        Minv = np.linalg.inv(M)
-        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=self.device)
-        # x~ = [x, w] @ K1 - const,  w = rho z - y:   x~ = Minv (sigma x - q + A' w)
-        self.K1 = t(np.vstack([self.sigma * Minv, self.As @ Minv]))     # [(n + m), n]
-        self.kq = t(Minv @ self.qs)                                       # [n]
-        self.At = t(self.As.T)                                            # [n, m]
-        self.rv = t(rv)
+    def __init__(self, simulator, gamma, safety_margin, planning_steps, tol=None, max_iter=None, keep_solution=False):
+        from .. import _lib
 
-    def solve(self, l, u, max_iter=4000, eps=1e-6, check_every=25, adapt_every=100, warm=True):
-        """l, u: [E, m] (unscaled).  Returns x [E, n] (unscaled), info."""
-        E_ = l.shape[0]
-        ls, us = l * self.tE, u * self.tE
-        if not warm or self.x is None or self.x.shape[0] != E_:
-            self.x = torch.zeros((E_, self.n), dtype=torch.float64, device=self.device)
-            self.z = torch.zeros((E_, self.m), dtype=torch.float64, device=self.device)
-            self.y = torch.zeros_like(self.z)
-        x, z, y = self.x, self.z, self.y
-        z = torch.minimum(torch.maximum(z, ls), us)
-        info = {"iters": max_iter, "refactor": 0}
-        fused = self.backend is not None
-        if fused:
-            import ctypes as C
+        self.backend, self.device = simulator.backend, simulator.device
+        self._device_ctx = simulator._device_ctx
+        self._stream_ptr = lambda: _lib_stream(self.device)
+        self.N = int(planning_steps)
+        desc, self._keep = _lib.network_desc(simulator.model)
+        self._handle = C.c_void_p()
+        lib = self.backend.lib
+        with self._device_ctx():
+            self.backend.check(lib.anm_mpc_create(C.byref(desc), float(gamma), float(safety_margin), self.N,
+                                                  C.byref(self._handle)), "anm_mpc_create")
+        d = _lib.MpcDims()
+        self.backend.check(lib.anm_mpc_dims_of(self._handle, C.byref(d)), "anm_mpc_dims_of")
+        self.dims = d
+        self.opts = _lib.MpcOpts(tol=0.0 if tol is None else float(tol), max_iter=0 if max_iter is None else int(max_iter))
+        self.max_iter = 40 if max_iter is None else int(max_iter)
+        self.keep_solution = keep_solution
+        self._E = None
 
-            x, z, y = x.contiguous().clone(), z.contiguous().clone(), y.contiguous().clone()
-            ls, us = ls.contiguous(), us.contiguous()
-            xw = torch.cat((x, self.rv * z - y), dim=1).contiguous()
-            stream = None if self.device.type != "cuda" else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            upd = self.backend.lib.anm_admm_update_f64
-        for it in range(1, max_iter + 1):
-            if fused:  # two GEMMs (rocBLAS) + one fused HIP kernel per iteration
-                xt = torch.addmm(-self.kq.expand(E_, -1), xw, self.K1)
-                zt = xt @ self.At
-                rc = upd(E_, self.n, self.m, self.alpha, xt.data_ptr(), zt.data_ptr(), ls.data_ptr(), us.data_ptr(),
-                         self.rv.data_ptr(), x.data_ptr(), z.data_ptr(), y.data_ptr(), xw.data_ptr(), stream)
-                if rc != 0:
-                    self.backend.check(rc, "anm_admm_update_f64")
-            else:
-                w = self.rv * z - y
-                xt = torch.cat((x, w), dim=1) @ self.K1 - self.kq
-                zt = xt @ self.At
-                x = self.alpha * xt + (1 - self.alpha) * x
-                zh = self.alpha * zt + (1 - self.alpha) * z
-                zn = torch.minimum(torch.maximum(zh + y / self.rv, ls), us)
-                y = y + self.rv * (zh - zn)
-                z = zn
-            if it % check_every == 0 or it == max_iter:
-                Ax = x @ self.At
-                rp = ((Ax - z).abs() / self.tE).amax(dim=1)                       # unscaled primal residual
-                rd = ((y @ self.At.T + self.tq).abs() / self.tD).amax(dim=1) / self.c
-                sp = torch.maximum((Ax.abs() / self.tE).amax(dim=1), (z.abs() / self.tE).amax(dim=1))
-                sd = torch.maximum(((y @ self.At.T).abs() / self.tD).amax(dim=1) / self.c, torch.as_tensor(np.abs(self.qs / self.D).max() / self.c, device=self.device))
-                ok = (rp <= eps * (1 + sp)) & (rd <= eps * (1 + sd))
-                info.update(r_prim=float(rp.max()), r_dual=float(rd.max()), iters=it)
-                if bool(ok.all()):
-                    break
-                if it % adapt_every == 0 and info["refactor"] < 12:
-                    ratio = float(torch.sqrt((rp / (sp + 1e-12)).median() / ((rd / (sd + 1e-12)).median() + 1e-18)))
-                    if ratio > 5 or ratio < 0.2:
-                        new_rho = float(np.clip(self.rho * ratio, 1e-6, 1e6))
-                        # (y is the unscaled-by-rho dual: keep it; z/w follow from rv at the next iteration)
-                        self._factor(new_rho)
-                        info["refactor"] += 1
-                        if fused:
-                            xw = torch.cat((x, self.rv * z - y), dim=1).contiguous()
-        self.x, self.z, self.y = x, z, y
-        return x * self.tD, info
+    def tables(self):
+        """host copy of the constant table the kernel reads (layout: ``mpc::Sz`` in csrc/anm_mpc.hpp)"""
+        out = np.zeros(self.dims.table_doubles)
+        self.backend.check(self.backend.lib.anm_mpc_get_tables(self._handle, out.ctypes.data_as(C.POINTER(C.c_double))),
+                           "anm_mpc_get_tables")
+        return out
+
+    def _buffers(self, E):
+        if self._E != E:
+            d, f = self.dims, dict(dtype=torch.float64, device=self.device)
+            self.u0 = torch.zeros((E, d.n_ctrl), **f)
+            self.objective = torch.zeros(E, **f)
+            self.iters = torch.zeros(E, dtype=torch.int32, device=self.device)
+            self.info = torch.zeros((E, 2), **f)
+            self.solution = torch.zeros((E, self.N, d.n_stage_vars), **f) if self.keep_solution else None
+            self._E = E
+
+    def solve(self, P_load_forecast, P_gen_forecast, soc):
+        d = self.dims
+        E = int(soc.shape[0])
+        f = dict(dtype=torch.float64, device=self.device)
+        # [E, n, N] (the reference's forecast layout, mpc.py:348-372) -> stage-major [E, N, n]
+        pl = torch.as_tensor(P_load_forecast, **f).reshape(E, d.n_load, self.N).permute(0, 2, 1).contiguous()
+        pg = torch.as_tensor(P_gen_forecast, **f).reshape(E, d.n_gen, self.N).permute(0, 2, 1).contiguous()
+        sc = torch.as_tensor(soc, **f).reshape(E, d.n_des).contiguous()
+        self._buffers(E)
+        with self._device_ctx():
+            rc = self.backend.lib.anm_mpc_solve_f64(
+                self._handle, E, pl.data_ptr(), pg.data_ptr(), sc.data_ptr(), self.u0.data_ptr(), self.objective.data_ptr(),
+                self.iters.data_ptr(), self.info.data_ptr(), 0 if self.solution is None else self.solution.data_ptr(),
+                C.byref(self.opts), self._stream_ptr())
+        self.backend.check(rc, "anm_mpc_solve_f64")
+        return self.u0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) and self._handle.value:
+                self.backend.lib.anm_mpc_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+def _lib_stream(device):
+    if device.type != "cuda":
+        return None
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class MPCAgent:
     """``MPCAgent(simulator, action_space, gamma, safety_margin=0.9, planning_steps=1)`` (``mpc.py:33-122``):
     ``act(env)`` returns the ``[num_envs, action_dim]`` tensor of the first-stage set-points (MW; reactive
-    set-points 0, ``mpc.py:383-388``), clipped to the action space."""
+    set-points 0, ``mpc.py:383-388``), clipped to the action space.
 
-    def __init__(self, simulator, action_space, gamma, safety_margin=0.9, planning_steps=1, eps=1e-6, max_iter=4000):
+    ``last_converged`` is the per-environment mask of solves that reached the tolerance; like the reference, which
+    prints ``OPF problem is <status>`` and goes on (``mpc.py:377-379``), ``act`` warns when it is not all true."""
+
+    def __init__(self, simulator, action_space, gamma, safety_margin=0.9, planning_steps=1, tol=None, max_iter=None):
         self.simulator = simulator
         self.action_space = action_space
         self.gamma, self.safety_margin, self.planning_steps = gamma, safety_margin, int(planning_steps)
         self.baseMVA, self.lamb, self.delta_t = simulator.baseMVA, simulator.lamb, simulator.delta_t
         m = simulator.model
-        self.program = DCOPFProgram(m, gamma, safety_margin, planning_steps)
         self.load_ids = [m.dev_ids[k] for k in m.load_idx]
         self.non_slack_gen_ids = [m.dev_ids[k] for k in m.gen_idx]
         self.des_ids = [m.dev_ids[k] for k in m.des_idx]
         self.device = simulator.device
-        pr = self.program
-        self.solver = BatchedADMM(pr.A, pr.q, pr.l0 == pr.u0, self.device, backend=simulator.backend)
-        self.eps, self.max_iter = eps, max_iter
-        self.last_info = None
+        self.solver = BatchedDCOPF(simulator, gamma, safety_margin, planning_steps, tol=tol, max_iter=max_iter)
+        self.last_converged = None
         self._lo = torch.as_tensor(np.asarray(action_space.low, float), device=self.device)
         self._hi = torch.as_tensor(np.asarray(action_space.high, float), device=self.device)
 
@@ -276,17 +253,8 @@ class MPCAgent:
         return env.simulator.soc  # p.u., [E, n_des]  (mpc.py:417 reads des_soc in pu)
 
     def solve(self, P_load_forecast, P_gen_forecast, soc):
-        pr = self.program
-        E_ = soc.shape[0]
-        N = pr.N
-        pl = torch.as_tensor(P_load_forecast, dtype=torch.float64, device=self.device).reshape(E_, pr.nl, N)
-        pg = torch.as_tensor(P_gen_forecast, dtype=torch.float64, device=self.device).reshape(E_, pr.ng, N)
-        params = torch.cat((pl.permute(0, 2, 1).reshape(E_, -1), pg.permute(0, 2, 1).reshape(E_, -1),
-                            torch.as_tensor(soc, dtype=torch.float64, device=self.device).reshape(E_, pr.ns)), dim=1)
-        l, u = pr.bounds(params)
-        x, info = self.solver.solve(l, u, max_iter=self.max_iter, eps=self.eps)
-        self.last_info, self.last_x, self.last_bounds = info, x, (l, u)
-        return x
+        """-> first-stage [P_gen.., P_des..] in p.u., [E, n_gen + n_des]"""
+        return self.solver.solve(P_load_forecast, P_gen_forecast, soc)
 
     def act(self, env):
         """``env``: a batched environment -> ``[num_envs, action_dim]`` tensor; or one of the NumPy-facing
@@ -295,12 +263,16 @@ class MPCAgent:
         if hasattr(env, "vec"):
             return self.act(env.vec)[0].cpu().numpy()
         pl, pg = self.forecast(env)
-        x = self.solve(pl, pg, self._soc(env))
-        pr = self.program
-        pd0 = x[:, pr.off["p_dev"] : pr.off["p_dev"] + env.simulator.N_device] * self.baseMVA
-        P_gen = pd0[:, pr.gens]
-        P_des = pd0[:, pr.des]
+        u0 = self.solve(pl, pg, self._soc(env)) * self.baseMVA
+        ng = self.solver.dims.n_gen
+        P_gen, P_des = u0[:, :ng], u0[:, ng:]
         a = torch.cat((P_gen, torch.zeros_like(P_gen), P_des, torch.zeros_like(P_des)), dim=1)
+        self.last_converged = self.solver.iters < self.solver.max_iter
+        if not bool(self.last_converged.all()):
+            import warnings
+
+            warnings.warn("OPF problem did not reach the tolerance in %d of %d environments (see last_converged)"
+                          % (int((~self.last_converged).sum()), a.shape[0]))
         return torch.minimum(torch.maximum(a, self._lo), self._hi)  # mpc.py:341-344
 
 

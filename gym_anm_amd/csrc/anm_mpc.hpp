@@ -1,0 +1,740 @@
+// anm_mpc.hpp -- batched N-stage DC optimal power flow of the MPC policies, one LANE per STAGE.
+//
+// Replaces, for a whole batch of environments and in ONE launch per act(), what the reference does per
+// environment through cvxpy:  MPCAgent._create_optimization_problem / _single_step_optimization_problem /
+// _solve  (gym_anm/agents/mpc.py:163-319, 372-388).  The program (a linear program) is restated in the reduced,
+// stage-structured form of gym_anm_amd/agents/dcopf.py -- the DC balance (mpc.py:232-245) and the load rows
+// (:247-251) are eliminated on the host (build_tables below), so that per stage i there are
+//
+//   inputs   xi_g in [0,1] (P_g = P_min + xi_g max(0, min(P_max, forecast) - P_min), :253-258, 267-271),
+//            p_c >= 0, d >= 0 (charge / discharge, P_des = d - p_c, :273-291), t_e >= 0 (epigraph of
+//            max(0, |flow_e| - beta rate_e), :308-311)
+//   state    sig_i = sig_{i-1} + dt eff p_c - dt/eff d   (state of charge after the stage, :282-287)
+//
+// and every inequality row touches either inputs of its own stage only (boxes, |theta| <= pi :293-299, the
+// three epigraph rows per branch) or the state only (SoC window :288-291).  It is solved by a primal-dual
+// interior-point method (Mehrotra predictor-corrector).  A Newton step is then a linear-quadratic control
+// problem: each lane factors its own stage (a dense (n_gen + 2 n_des)^2 Cholesky, the epigraph variables
+// eliminated in closed form), and the stages are coupled only through the n_des states of charge -- a Riccati
+// sweep over the lanes of a group in the cancellation-free form  P' = P (I + M P)^-1,  M = B R^-1 B'.
+//
+// Lane layout: a group of G = 2^k >= N lanes is one environment, lane = stage; 64 / G environments per
+// wavefront.  N = 1: one thread per environment.  Everything a lane owns (its rows' slacks and multipliers,
+// its factor) lives in registers; the network tables are wave-uniform scalar loads.
+//
+// Plain C++17 with the ANM_HD decoration: tests/hostsim compiles the very same solver with g++ (one host
+// thread per lane, the shuffles replaced by a barrier-protected exchange array) as a TEST DOUBLE.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/anm_mi355x.h"
+#include "anm_device.hpp"
+
+namespace anm {
+namespace mpc {
+
+constexpr int pos(int n) { return n > 0 ? n : 1; }
+
+// every loop over rows / inputs / table columns has compile-time bounds and must be unrolled: the arrays it
+// indexes are registers
+#if defined(__HIPCC__)
+#define ANM_UFOR _Pragma("unroll") for
+#else
+#define ANM_UFOR for
+#endif
+
+template <class T>
+struct Sz {
+  static constexpr int NG = T::NGEN, NS = T::NDES, NL = T::NLOAD, NB1 = T::NB - 1, NBR = T::NBR;
+  static constexpr int NC = NG + NS, NA = NG + 2 * NS, NV = NA + NBR;
+  // rows of one stage, in this order
+  static constexpr int R_XI_UP = 0, R_XI_LO = NG, R_PD_UP = 2 * NG, R_PD_LO = R_PD_UP + NS, R_PC = R_PD_LO + NS,
+                       R_D = R_PC + NS, R_SOC_UP = R_D + NS, R_SOC_LO = R_SOC_UP + NS, R_TH_UP = R_SOC_LO + NS,
+                       R_TH_LO = R_TH_UP + NB1, R_FL1 = R_TH_LO + NB1, R_FL2 = R_FL1 + NBR, R_FL3 = R_FL2 + NBR,
+                       NR = R_FL3 + NBR;
+  // what the register-resident kernel is compiled for (slacks + multipliers + work arrays of NR rows per lane)
+  static constexpr bool FITS = NR <= 72 && NS <= 2 && NA <= 8;
+  // table of constants (doubles), wave-uniform
+  static constexpr int T_THC = 0, T_THL = T_THC + NB1 * NC, T_PHC = T_THL + NB1 * NL, T_PHL = T_PHC + NBR * NC,
+                       T_COST = T_PHL + NBR * NL, T_SGL = T_COST + pos(NC), T_LIM = T_SGL + pos(NL),
+                       T_GPMIN = T_LIM + pos(NBR), T_GPMAX = T_GPMIN + pos(NG), T_SPMIN = T_GPMAX + pos(NG),
+                       T_SPMAX = T_SPMIN + pos(NS), T_SOCMIN = T_SPMAX + pos(NS), T_SOCMAX = T_SOCMIN + pos(NS),
+                       T_BC = T_SOCMAX + pos(NS), T_BD = T_BC + pos(NS), T_LAMB = T_BD + pos(NS), T_WGT = T_LAMB + 1,
+                       T_TOTAL = T_WGT + 64;
+};
+
+struct Opts {
+  double tol;        // stop: complementarity mu <= tol (1 + |objective|) and row residuals <= 1e-9
+  int max_iter;
+};
+
+// per-environment I/O of one solve (device pointers; row-major)
+struct IO {
+  const double* p_load;  // [E][N][NL]  forecasts, p.u.
+  const double* p_gen;   // [E][N][NG]
+  const double* soc0;    // [E][NS]
+  double* u0;            // [E][NC]    first-stage [P_gen.., P_des..], p.u.
+  double* objective;     // [E]
+  int32_t* iters;        // [E]
+  double* info;          // [E][2]     final mu, largest row residual   (may be null)
+  double* solution;      // [E][N][NV] P_g, p_c, d, t per stage         (may be null)
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// host: DC reduction (gym_anm_amd/agents/dcopf.py restated; tests compare the two)
+// ------------------------------------------------------------------------------------------------------------
+inline bool invert(std::vector<double>& a, int n) {  // Gauss-Jordan with partial pivoting, in place
+  std::vector<double> inv(size_t(n) * n, 0.0);
+  for (int i = 0; i < n; ++i) inv[size_t(i) * n + i] = 1.0;
+  for (int c = 0; c < n; ++c) {
+    int p = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::fabs(a[size_t(r) * n + c]) > std::fabs(a[size_t(p) * n + c])) p = r;
+    if (!(std::fabs(a[size_t(p) * n + c]) > 1e-300)) return false;
+    if (p != c)
+      for (int k = 0; k < n; ++k) {
+        std::swap(a[size_t(p) * n + k], a[size_t(c) * n + k]);
+        std::swap(inv[size_t(p) * n + k], inv[size_t(c) * n + k]);
+      }
+    const double piv = 1.0 / a[size_t(c) * n + c];
+    for (int k = 0; k < n; ++k) {
+      a[size_t(c) * n + k] *= piv;
+      inv[size_t(c) * n + k] *= piv;
+    }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = a[size_t(r) * n + c];
+      if (f == 0.0) continue;
+      for (int k = 0; k < n; ++k) {
+        a[size_t(r) * n + k] -= f * a[size_t(c) * n + k];
+        inv[size_t(r) * n + k] -= f * inv[size_t(c) * n + k];
+      }
+    }
+  }
+  a.swap(inv);
+  return true;
+}
+
+template <class T>
+inline bool build_tables(const anm_network_desc& d, double gamma, double safety_margin, int N, std::vector<double>& tab,
+                         std::string& err) {
+  typedef Sz<T> S;
+  const int nb = T::NB, nd = T::ND;
+  if (N < 1 || N > 64) { err = "planning_steps must be in [1, 64] (one lane per stage)"; return false; }
+  // B = Im(Y_bus) (mpc.py:113), Y as in simulator.py:189-197
+  std::vector<double> B(size_t(nb) * nb, 0.0);
+  for (int b = 0; b < T::NBR; ++b) {
+    const int f = d.br_from[b], t = d.br_to[b];
+    const std::complex<double> ys(d.br_series[2 * b], d.br_series[2 * b + 1]), sh(d.br_shunt[2 * b], d.br_shunt[2 * b + 1]),
+        tap(d.br_tap[2 * b], d.br_tap[2 * b + 1]);
+    B[size_t(f) * nb + t] = (-ys / std::conj(tap)).imag();
+    B[size_t(t) * nb + f] = (-ys / tap).imag();
+    B[size_t(f) * nb + f] += ((ys + sh) / (std::abs(tap) * std::abs(tap))).imag();
+    B[size_t(t) * nb + t] += (ys + sh).imag();
+  }
+  int slack_dev = -1;
+  for (int k = 0; k < nd; ++k)
+    if (d.dev_type[k] == DEV_SLACK) slack_dev = k;
+  if (slack_dev < 0 || slack_dev >= nb) {
+    err = "the reference's DC-OPF pins the angle at the slack DEVICE's position (mpc.py:302), which is not a bus here";
+    return false;
+  }
+  const int pin = slack_dev, slack_bus = d.dev_bus[slack_dev];
+  std::vector<double> Lap(size_t(nb) * nb, 0.0);
+  for (int b = 0; b < T::NBR; ++b) {  // mpc.py:232-245
+    const int f = d.br_from[b], t = d.br_to[b];
+    Lap[size_t(f) * nb + f] += B[size_t(f) * nb + t];
+    Lap[size_t(f) * nb + t] -= B[size_t(f) * nb + t];
+    Lap[size_t(t) * nb + t] += B[size_t(t) * nb + f];
+    Lap[size_t(t) * nb + f] -= B[size_t(t) * nb + f];
+  }
+  std::vector<int> keep;
+  for (int b = 0; b < nb; ++b)
+    if (b != pin) keep.push_back(b);
+  std::vector<double> M(size_t(nb) * nb, 0.0);
+  for (int r = 0; r < nb; ++r)
+    for (int c = 0; c < nb - 1; ++c) M[size_t(r) * nb + c] = Lap[size_t(r) * nb + keep[c]];
+  M[size_t(slack_bus) * nb + (nb - 1)] = -1.0;
+  if (!invert(M, nb)) { err = "the DC balance of this network is singular"; return false; }
+  // Th[b][k]: angle of bus b per unit injection of device k; sg[k]: slack injection per unit injection of device k
+  std::vector<double> Th(size_t(nb) * nd, 0.0), sg(nd, 0.0);
+  for (int k = 0; k < nd; ++k) {
+    const int bus = d.dev_bus[k];
+    for (int c = 0; c < nb - 1; ++c) Th[size_t(keep[c]) * nd + k] = M[size_t(c) * nb + bus];
+    sg[k] = M[size_t(nb - 1) * nb + bus];
+  }
+  int loads[pos(S::NL)], ctrl[pos(S::NC)];
+  {
+    int il = 0, ig = 0, is = 0;
+    for (int k = 0; k < nd; ++k) {
+      const int ty = d.dev_type[k];
+      if (ty == DEV_LOAD) loads[il++] = k;
+      else if (ty == DEV_CLASSICAL || ty == DEV_RENEWABLE) ctrl[ig++] = k;
+    }
+    for (int k = 0; k < nd; ++k)
+      if (d.dev_type[k] == DEV_STORAGE) ctrl[S::NG + is++] = k;
+  }
+  tab.assign(S::T_TOTAL, 0.0);
+  for (int r = 0; r < S::NB1; ++r) {
+    const int b = keep[r];
+    for (int c = 0; c < S::NC; ++c) tab[S::T_THC + r * S::NC + c] = Th[size_t(b) * nd + ctrl[c]];
+    for (int l = 0; l < S::NL; ++l) tab[S::T_THL + r * S::NL + l] = Th[size_t(b) * nd + loads[l]];
+  }
+  for (int e = 0; e < S::NBR; ++e) {
+    const int f = d.br_from[e], t = d.br_to[e];
+    const double bft = B[size_t(f) * nb + t];
+    for (int c = 0; c < S::NC; ++c) tab[S::T_PHC + e * S::NC + c] = bft * (Th[size_t(f) * nd + ctrl[c]] - Th[size_t(t) * nd + ctrl[c]]);
+    for (int l = 0; l < S::NL; ++l) tab[S::T_PHL + e * S::NL + l] = bft * (Th[size_t(f) * nd + loads[l]] - Th[size_t(t) * nd + loads[l]]);
+    tab[S::T_LIM + e] = safety_margin * d.br_rate[e];
+  }
+  for (int c = 0; c < S::NC; ++c) {
+    double cost = sg[ctrl[c]];
+    if (c < S::NG && d.dev_type[ctrl[c]] == DEV_CLASSICAL) cost += 1.0;  // mpc.py:304-306
+    tab[S::T_COST + c] = cost;
+  }
+  for (int l = 0; l < S::NL; ++l) tab[S::T_SGL + l] = sg[loads[l]];
+  for (int g = 0; g < S::NG; ++g) {
+    tab[S::T_GPMIN + g] = d.dev_pmin[ctrl[g]];
+    tab[S::T_GPMAX + g] = d.dev_pmax[ctrl[g]];
+  }
+  for (int j = 0; j < S::NS; ++j) {
+    const int k = ctrl[S::NG + j];
+    tab[S::T_SPMIN + j] = d.dev_pmin[k];
+    tab[S::T_SPMAX + j] = d.dev_pmax[k];
+    tab[S::T_SOCMIN + j] = d.dev_soc_min[k];
+    tab[S::T_SOCMAX + j] = d.dev_soc_max[k];
+    tab[S::T_BC + j] = d.delta_t * d.dev_eff[k];
+    tab[S::T_BD + j] = d.delta_t / d.dev_eff[k];
+  }
+  tab[S::T_LAMB] = d.lamb;
+  double w = 1.0;
+  for (int i = 0; i < 64; ++i) {
+    tab[S::T_WGT + i] = w;  // gamma^i (mpc.py:212)
+    w *= gamma;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the solver, as one lane sees it.  `X` gives the lane its place in the group and the exchanges with the other
+// lanes:  stage(), up(v) / down(v) (value of the previous / next stage, 0 outside), sum / min / max over the
+// group, scan (inclusive prefix sum over the stages).
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+struct Lane {
+  typedef Sz<T> S;
+  static constexpr int NG = S::NG, NS = S::NS, NL = S::NL, NB1 = S::NB1, NBR = S::NBR, NC = S::NC, NA = S::NA, NR = S::NR;
+
+  // variables of the stage and of its rows
+  double xi[pos(NG)], pc[pos(NS)], d[pos(NS)], t[pos(NBR)];
+  double s[NR], z[NR];
+  // constants of the stage
+  double wd[pos(NG)], th0[pos(NB1)], f0[pos(NBR)], wgt, ct, objc;
+  // per iteration
+  double rp[NR], w[NR], cross[NR];                  // row residuals, z/s, ds*dz of the predictor
+  double htt[pos(NBR)], hut[pos(NBR)];
+  double Lc[NA * (NA + 1) / 2];                      // Cholesky factor of R (row-major lower triangle)
+  double RiBt[pos(NA * NS)], Mm[pos(NS * NS)], Pm[pos(NS * NS)], Ki[pos(NS * NS)];  // R^-1 B', B R^-1 B', P, (I + M P)^-1
+  double sig[pos(NS)];
+
+  static ANM_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
+
+  // u = [P_g.., P_des..]
+  ANM_HD void phys(cptr_t C, double (&u)[pos(NC)]) const {
+    ANM_UFOR (int g = 0; g < NG; ++g) u[g] = fma(wd[g], xi[g], C[S::T_GPMIN + g]);
+    ANM_UFOR (int j = 0; j < NS; ++j) u[NG + j] = d[j] - pc[j];
+  }
+
+  // g.v - h of every row
+  ANM_HD void row_values(cptr_t C, double (&val)[NR]) const {
+    double u[pos(NC)];
+    phys(C, u);
+    ANM_UFOR (int g = 0; g < NG; ++g) {
+      val[S::R_XI_UP + g] = xi[g] - 1.0;
+      val[S::R_XI_LO + g] = -xi[g];
+    }
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      val[S::R_PD_UP + j] = u[NG + j] - C[S::T_SPMAX + j];
+      val[S::R_PD_LO + j] = C[S::T_SPMIN + j] - u[NG + j];
+      val[S::R_PC + j] = -pc[j];
+      val[S::R_D + j] = -d[j];
+      val[S::R_SOC_UP + j] = sig[j] - C[S::T_SOCMAX + j];
+      val[S::R_SOC_LO + j] = C[S::T_SOCMIN + j] - sig[j];
+    }
+    const double PI = 3.14159265358979323846;
+    ANM_UFOR (int b = 0; b < NB1; ++b) {
+      double th = th0[b];
+      ANM_UFOR (int c = 0; c < NC; ++c) th = fma(C[S::T_THC + b * NC + c], u[c], th);
+      val[S::R_TH_UP + b] = th - PI;
+      val[S::R_TH_LO + b] = -th - PI;
+    }
+    ANM_UFOR (int e = 0; e < NBR; ++e) {
+      double fl = f0[e];
+      ANM_UFOR (int c = 0; c < NC; ++c) fl = fma(C[S::T_PHC + e * NC + c], u[c], fl);
+      const double lim = C[S::T_LIM + e];
+      val[S::R_FL1 + e] = fl - t[e] - lim;
+      val[S::R_FL2 + e] = -fl - t[e] - lim;
+      val[S::R_FL3 + e] = -t[e];
+    }
+  }
+
+  // stage part of the objective (the reference's expression, mpc.py:304-313, with its constants)
+  ANM_HD double objective(cptr_t C) const {
+    double u[pos(NC)];
+    phys(C, u);
+    double o = objc;
+    ANM_UFOR (int c = 0; c < NC; ++c) o = fma(wgt * C[S::T_COST + c], u[c], o);
+    ANM_UFOR (int e = 0; e < NBR; ++e) o = fma(ct, t[e], o);
+    return o;
+  }
+
+  // gradient of the Lagrangian for multipliers zh: inputs (xi, p_c, d) and state; the epigraph variables'
+  // share folded into the flows (eliminate: right-hand sides of a Newton step), their own gradient in gt
+  ANM_HD void gradient(cptr_t C, const double (&zh)[NR], bool eliminate, double (&g_in)[NA], double (&g_st)[pos(NS)],
+                       double (&gt)[pos(NBR)]) const {
+    double gu[pos(NC)];
+    ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = wgt * C[S::T_COST + c];
+    ANM_UFOR (int b = 0; b < NB1; ++b) {
+      const double dz = zh[S::R_TH_UP + b] - zh[S::R_TH_LO + b];
+      ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = fma(dz, C[S::T_THC + b * NC + c], gu[c]);
+    }
+    ANM_UFOR (int e = 0; e < NBR; ++e) {
+      gt[e] = ct - zh[S::R_FL1 + e] - zh[S::R_FL2 + e] - zh[S::R_FL3 + e];
+      double ga = zh[S::R_FL1 + e] - zh[S::R_FL2 + e];
+      if (eliminate) ga = fma(-hut[e], gt[e], ga);
+      ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = fma(ga, C[S::T_PHC + e * NC + c], gu[c]);
+    }
+    ANM_UFOR (int j = 0; j < NS; ++j) gu[NG + j] += zh[S::R_PD_UP + j] - zh[S::R_PD_LO + j];
+    ANM_UFOR (int g = 0; g < NG; ++g) g_in[g] = fma(wd[g], gu[g], zh[S::R_XI_UP + g] - zh[S::R_XI_LO + g]);
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      g_in[NG + j] = -gu[NG + j] - zh[S::R_PC + j];
+      g_in[NG + NS + j] = gu[NG + j] - zh[S::R_D + j];
+      g_st[j] = zh[S::R_SOC_UP + j] - zh[S::R_SOC_LO + j];
+    }
+  }
+
+  // R = J' Hu J + (weights of the direct rows) + rho I, factored; R^-1 B', M = B R^-1 B'
+  ANM_HD void factor_stage(cptr_t C, double rho) {
+    double Hu[pos(NC * (NC + 1) / 2)];
+    ANM_UFOR (int k = 0; k < NC * (NC + 1) / 2; ++k) Hu[k] = 0.0;
+    ANM_UFOR (int b = 0; b < NB1; ++b) {
+      const double wb = w[S::R_TH_UP + b] + w[S::R_TH_LO + b];
+      ANM_UFOR (int i = 0; i < NC; ++i) {
+        const double wi = wb * C[S::T_THC + b * NC + i];
+        ANM_UFOR (int j = 0; j <= i; ++j) Hu[tri(i, j)] = fma(wi, C[S::T_THC + b * NC + j], Hu[tri(i, j)]);
+      }
+    }
+    ANM_UFOR (int e = 0; e < NBR; ++e) {
+      const double w1 = w[S::R_FL1 + e], w2 = w[S::R_FL2 + e], w3 = w[S::R_FL3 + e];
+      const double h = w1 + w2 + w3 + rho, ih = 1.0 / h;
+      htt[e] = ih;                          // (the reciprocal is what every later use needs)
+      hut[e] = (w2 - w1) * ih;
+      const double hat = (4.0 * w1 * w2 + (w3 + rho) * (w1 + w2)) * ih;  // weight of (a.du)^2 with t_e eliminated
+      ANM_UFOR (int i = 0; i < NC; ++i) {
+        const double wi = hat * C[S::T_PHC + e * NC + i];
+        ANM_UFOR (int j = 0; j <= i; ++j) Hu[tri(i, j)] = fma(wi, C[S::T_PHC + e * NC + j], Hu[tri(i, j)]);
+      }
+    }
+    ANM_UFOR (int j = 0; j < NS; ++j) Hu[tri(NG + j, NG + j)] += w[S::R_PD_UP + j] + w[S::R_PD_LO + j];
+    // R over (xi.., pc.., d..):  u_g = wd_g xi_g,  u_des_j = d_j - pc_j
+    double R[NA * (NA + 1) / 2];
+    auto ju = [&](int a, int& c, double& f) {  // input a moves u_c by f
+      if (a < NG) { c = a; f = wd[a]; }
+      else if (a < NG + NS) { c = a; f = -1.0; }
+      else { c = a - NS; f = 1.0; }
+    };
+    ANM_UFOR (int a = 0; a < NA; ++a)
+      ANM_UFOR (int b = 0; b <= a; ++b) {
+        int ca, cb;
+        double fa, fb;
+        ju(a, ca, fa);
+        ju(b, cb, fb);
+        R[tri(a, b)] = fa * fb * (ca >= cb ? Hu[tri(ca, cb)] : Hu[tri(cb, ca)]);
+      }
+    ANM_UFOR (int g = 0; g < NG; ++g) R[tri(g, g)] += w[S::R_XI_UP + g] + w[S::R_XI_LO + g] + rho;
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      R[tri(NG + j, NG + j)] += w[S::R_PC + j] + rho;
+      R[tri(NG + NS + j, NG + NS + j)] += w[S::R_D + j] + rho;
+    }
+    // Cholesky, the diagonal stored inverted
+    ANM_UFOR (int i = 0; i < NA; ++i)
+      ANM_UFOR (int j = 0; j <= i; ++j) {
+        double acc = R[tri(i, j)];
+        ANM_UFOR (int k = 0; k < j; ++k) acc = fma(-Lc[tri(i, k)], Lc[tri(j, k)], acc);
+        if (i == j) Lc[tri(i, i)] = 1.0 / sqrt(acc);
+        else Lc[tri(i, j)] = acc * Lc[tri(j, j)];
+      }
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      double col[NA];
+      ANM_UFOR (int a = 0; a < NA; ++a) col[a] = 0.0;
+      col[NG + j] = C[S::T_BC + j];
+      col[NG + NS + j] = -C[S::T_BD + j];
+      chol_solve(col);
+      ANM_UFOR (int a = 0; a < NA; ++a) RiBt[a * NS + j] = col[a];
+    }
+    ANM_UFOR (int i = 0; i < NS; ++i)
+      ANM_UFOR (int j = 0; j < NS; ++j)
+        Mm[i * NS + j] = C[S::T_BC + i] * RiBt[(NG + i) * NS + j] - C[S::T_BD + i] * RiBt[(NG + NS + i) * NS + j];
+  }
+
+  ANM_HD void chol_solve(double (&x)[NA]) const {
+    ANM_UFOR (int i = 0; i < NA; ++i) {
+      double acc = x[i];
+      ANM_UFOR (int k = 0; k < i; ++k) acc = fma(-Lc[tri(i, k)], x[k], acc);
+      x[i] = acc * Lc[tri(i, i)];
+    }
+    ANM_UFOR (int i = NA - 1; i >= 0; --i) {
+      double acc = x[i];
+      ANM_UFOR (int k = i + 1; k < NA; ++k) acc = fma(-Lc[tri(k, i)], x[k], acc);
+      x[i] = acc * Lc[tri(i, i)];
+    }
+  }
+
+  // Ki = (I + M P)^-1 for the P of this stage
+  ANM_HD void set_P(const double (&P)[pos(NS * NS)]) {
+    double A[pos(NS * NS)];
+    ANM_UFOR (int i = 0; i < NS; ++i)
+      ANM_UFOR (int j = 0; j < NS; ++j) {
+        double acc = i == j ? 1.0 : 0.0;
+        ANM_UFOR (int k = 0; k < NS; ++k) acc = fma(Mm[i * NS + k], P[k * NS + j], acc);
+        A[i * NS + j] = acc;
+        Pm[i * NS + j] = P[i * NS + j];
+        Ki[i * NS + j] = i == j ? 1.0 : 0.0;
+      }
+    ANM_UFOR (int c = 0; c < NS; ++c) {  // Gauss-Jordan (the matrix is I + (PSD)(PSD): eigenvalues >= 1)
+      const double piv = 1.0 / A[c * NS + c];
+      ANM_UFOR (int k = 0; k < NS; ++k) {
+        A[c * NS + k] *= piv;
+        Ki[c * NS + k] *= piv;
+      }
+      ANM_UFOR (int r = 0; r < NS; ++r) {
+        if (r == c) continue;
+        const double f = A[r * NS + c];
+        ANM_UFOR (int k = 0; k < NS; ++k) {
+          A[r * NS + k] = fma(-f, A[c * NS + k], A[r * NS + k]);
+          Ki[r * NS + k] = fma(-f, Ki[c * NS + k], Ki[r * NS + k]);
+        }
+      }
+    }
+  }
+};
+
+// One lane's run of the whole solve.
+template <class T, class X>
+ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool valid, int N, X& x) {
+  typedef Sz<T> S;
+  typedef Lane<T> L;
+  constexpr int NG = S::NG, NS = S::NS, NL = S::NL, NB1 = S::NB1, NBR = S::NBR, NC = S::NC, NA = S::NA, NR = S::NR;
+  const int i = x.stage();
+  const bool on = valid && i < N;  // a lane without a stage runs along with neutral contributions
+  L ln;
+  ANM_UFOR (int k = 0; k < pos(NS * NS); ++k) { ln.Pm[k] = 0.0; ln.Ki[k] = 0.0; ln.Mm[k] = 0.0; }
+  // ---- constants of the stage ----
+  ln.wgt = C[S::T_WGT + (i < 64 ? i : 63)];
+  ln.ct = ln.wgt * C[S::T_LAMB];
+  double pl[pos(NL)], soc0[pos(NS)];
+  ANM_UFOR (int l = 0; l < NL; ++l) pl[l] = on ? io.p_load[(env * N + i) * NL + l] : 0.0;
+  ANM_UFOR (int g = 0; g < NG; ++g) {
+    const double fc = on ? io.p_gen[(env * N + i) * NG + g] : 0.0;
+    ln.wd[g] = fmax(fmin(C[S::T_GPMAX + g], fc) - C[S::T_GPMIN + g], 0.0);
+  }
+  ANM_UFOR (int j = 0; j < NS; ++j) soc0[j] = valid ? io.soc0[env * NS + j] : 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
+  ANM_UFOR (int b = 0; b < NB1; ++b) {
+    double a = 0.0;
+    ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_THL + b * NL + l], pl[l], a);
+    ln.th0[b] = a;
+  }
+  ANM_UFOR (int e = 0; e < NBR; ++e) {
+    double a = 0.0;
+    ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_PHL + e * NL + l], pl[l], a);
+    ln.f0[e] = a;
+  }
+  {
+    double a = 0.0;
+    ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_SGL + l], pl[l], a);
+    ln.objc = ln.wgt * a;
+  }
+  // ---- start: mid-interval generators, a little charge and the discharge that undoes it, no overload ----
+  ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = 0.5;
+  ANM_UFOR (int j = 0; j < NS; ++j) {
+    ln.pc[j] = 0.05 * (C[S::T_SPMAX + j] - C[S::T_SPMIN + j]);
+    ln.d[j] = ln.pc[j] * (C[S::T_BC + j] / C[S::T_BD + j]);
+    ln.sig[j] = soc0[j];
+  }
+  ANM_UFOR (int e = 0; e < NBR; ++e) ln.t[e] = 0.1;
+  {
+    double val[NR];
+    ln.row_values(C, val);
+    ANM_UFOR (int r = 0; r < NR; ++r) {
+      ln.s[r] = fmax(-val[r], 1e-2);
+      ln.z[r] = r >= S::R_FL1 ? ln.ct * (1.0 / 3.0) : 1.0;  // dual feasible for the epigraph variables
+    }
+  }
+  const double m_rows = double(NR) * double(N);
+  int it = 0;
+  bool done = !valid;
+  double mu = 0.0, rpmax = 0.0, obj = 0.0;
+  for (;; ++it) {
+    // ---- evaluate ----
+    ANM_UFOR (int j = 0; j < NS; ++j) ln.sig[j] = soc0[j] + x.scan(on ? fma(C[S::T_BC + j], ln.pc[j], -C[S::T_BD + j] * ln.d[j]) : 0.0);
+    double val[NR];
+    ln.row_values(C, val);
+    double a_mu = 0.0, a_rp = 0.0, a_w = 0.0;
+    ANM_UFOR (int r = 0; r < NR; ++r) {
+      ln.rp[r] = val[r] + ln.s[r];
+      ln.w[r] = ln.z[r] / ln.s[r];
+      a_mu = fma(ln.s[r], ln.z[r], a_mu);
+      a_rp = fmax(a_rp, fabs(ln.rp[r]));
+      a_w = fmax(a_w, ln.w[r]);
+    }
+    const double n_mu = x.sum(on ? a_mu : 0.0) / m_rows, n_rp = x.max(on ? a_rp : 0.0), wmax = x.max(on ? a_w : 0.0);
+    const double n_obj = x.sum(on ? ln.objective(C) : 0.0);
+    if (!done) { mu = n_mu; rpmax = n_rp; obj = n_obj; }
+    if (!done && ((mu <= opt.tol * (1.0 + fabs(obj)) && rpmax <= 1e-9) || it >= opt.max_iter || !(mu == mu))) {
+      done = true;
+      if (valid && i == 0) {
+        io.objective[env] = obj;
+        io.iters[env] = it;
+        if (io.info) { io.info[env * 2] = mu; io.info[env * 2 + 1] = rpmax; }
+        double u[pos(NC)];
+        ln.phys(C, u);
+        ANM_UFOR (int c = 0; c < NC; ++c) io.u0[env * NC + c] = u[c];
+      }
+      if (on && io.solution) {
+        double u[pos(NC)];
+        ln.phys(C, u);
+        double* o = io.solution + (env * N + i) * S::NV;
+        ANM_UFOR (int g = 0; g < NG; ++g) o[g] = u[g];
+        ANM_UFOR (int j = 0; j < NS; ++j) { o[NG + j] = ln.pc[j]; o[NG + NS + j] = ln.d[j]; }
+        ANM_UFOR (int e = 0; e < NBR; ++e) o[NA + e] = ln.t[e];
+      }
+    }
+    if (x.all_done(done)) break;
+    // ---- factor (once per iteration) ----
+    const double rho = fma(1e-13, wmax, 1e-12);  // proximal term: keeps the directions no active row pins well posed
+    ln.factor_stage(C, rho);
+    {  // Riccati sweep, last stage first:  P_i = Q_i + P'_{i+1},  P'_i = P_i (I + M_i P_i)^-1
+      double Pn[pos(NS * NS)];
+      ANM_UFOR (int k = 0; k < NS * NS; ++k) Pn[k] = 0.0;
+      for (int k = N - 1; k >= 0; --k) {
+        double P[pos(NS * NS)], out[pos(NS * NS)];
+        ANM_UFOR (int a = 0; a < NS; ++a)
+          ANM_UFOR (int b = 0; b < NS; ++b) P[a * NS + b] = Pn[a * NS + b] + (a == b ? ln.w[S::R_SOC_UP + a] + ln.w[S::R_SOC_LO + a] : 0.0);
+        if (i == k) ln.set_P(P);
+        ANM_UFOR (int a = 0; a < NS; ++a)
+          ANM_UFOR (int b = 0; b < NS; ++b) {
+            double acc = 0.0;
+            ANM_UFOR (int c = 0; c < NS; ++c) acc = fma(ln.Pm[a * NS + c], ln.Ki[c * NS + b], acc);
+            out[a * NS + b] = acc;
+          }
+        ANM_UFOR (int q = 0; q < NS * NS; ++q) {
+          const double got = x.down(i == k ? out[q] : 0.0);  // stage k - 1 receives P'_k
+          if (i == k - 1) Pn[q] = got;
+        }
+      }
+    }
+    // ---- Newton step for multipliers zh ----
+    double dxi[pos(NG)], dpc[pos(NS)], dd[pos(NS)], dt[pos(NBR)], gv[NR];
+    auto newton = [&](const double (&zh)[NR]) {
+      double g_in[NA], g_st[pos(NS)], gt[pos(NBR)];
+      ln.gradient(C, zh, true, g_in, g_st, gt);
+      double y[NA];
+      ANM_UFOR (int a = 0; a < NA; ++a) y[a] = g_in[a];
+      ln.chol_solve(y);
+      double mv[pos(NS)];
+      ANM_UFOR (int j = 0; j < NS; ++j) mv[j] = fma(C[S::T_BC + j], y[NG + j], -C[S::T_BD + j] * y[NG + NS + j]);
+      // backward: p_i = g_st_i + p'_{i+1},  p'_i = (I + P M)^-1 (p_i - P m_i)
+      double p[pos(NS)], pn[pos(NS)];
+      ANM_UFOR (int j = 0; j < NS; ++j) { p[j] = 0.0; pn[j] = 0.0; }
+      for (int k = N - 1; k >= 0; --k) {
+        double out[pos(NS)];
+        if (i == k)
+          ANM_UFOR (int j = 0; j < NS; ++j) p[j] = g_st[j] + pn[j];
+        double tmp[pos(NS)];
+        ANM_UFOR (int a = 0; a < NS; ++a) {
+          double acc = p[a];
+          ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(-ln.Pm[a * NS + b], mv[b], acc);
+          tmp[a] = acc;
+        }
+        ANM_UFOR (int a = 0; a < NS; ++a) {  // Ki' tmp  ((I + P M)^-1 = ((I + M P)^-1)')
+          double acc = 0.0;
+          ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(ln.Ki[b * NS + a], tmp[b], acc);
+          out[a] = acc;
+        }
+        ANM_UFOR (int j = 0; j < NS; ++j) {
+          const double got = x.down(i == k ? out[j] : 0.0);
+          if (i == k - 1) pn[j] = got;
+        }
+      }
+      // forward: x_i = (I + M P)^-1 (x_{i-1} - m_i - M p_i)
+      double xs[pos(NS)], xp[pos(NS)];
+      ANM_UFOR (int j = 0; j < NS; ++j) { xs[j] = 0.0; xp[j] = 0.0; }
+      for (int k = 0; k < N; ++k) {
+        if (i == k) {
+          double tmp[pos(NS)];
+          ANM_UFOR (int a = 0; a < NS; ++a) {
+            double acc = xp[a] - mv[a];
+            ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(-ln.Mm[a * NS + b], p[b], acc);
+            tmp[a] = acc;
+          }
+          ANM_UFOR (int a = 0; a < NS; ++a) {
+            double acc = 0.0;
+            ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(ln.Ki[a * NS + b], tmp[b], acc);
+            xs[a] = acc;
+          }
+        }
+        ANM_UFOR (int j = 0; j < NS; ++j) {
+          const double got = x.up(i == k ? xs[j] : 0.0);
+          if (i == k + 1) xp[j] = got;
+        }
+      }
+      // costate and inputs
+      double da[NA];
+      ANM_UFOR (int a = 0; a < NA; ++a) da[a] = -y[a];
+      ANM_UFOR (int j = 0; j < NS; ++j) {
+        double co = p[j];
+        ANM_UFOR (int b = 0; b < NS; ++b) co = fma(ln.Pm[j * NS + b], xs[b], co);
+        ANM_UFOR (int a = 0; a < NA; ++a) da[a] = fma(-ln.RiBt[a * NS + j], co, da[a]);
+      }
+      ANM_UFOR (int g = 0; g < NG; ++g) dxi[g] = da[g];
+      ANM_UFOR (int j = 0; j < NS; ++j) { dpc[j] = da[NG + j]; dd[j] = da[NG + NS + j]; }
+      // g.dv of every row
+      double du[pos(NC)];
+      ANM_UFOR (int g = 0; g < NG; ++g) du[g] = ln.wd[g] * dxi[g];
+      ANM_UFOR (int j = 0; j < NS; ++j) du[NG + j] = dd[j] - dpc[j];
+      ANM_UFOR (int g = 0; g < NG; ++g) { gv[S::R_XI_UP + g] = dxi[g]; gv[S::R_XI_LO + g] = -dxi[g]; }
+      ANM_UFOR (int j = 0; j < NS; ++j) {
+        gv[S::R_PD_UP + j] = du[NG + j];
+        gv[S::R_PD_LO + j] = -du[NG + j];
+        gv[S::R_PC + j] = -dpc[j];
+        gv[S::R_D + j] = -dd[j];
+        gv[S::R_SOC_UP + j] = xs[j];
+        gv[S::R_SOC_LO + j] = -xs[j];
+      }
+      ANM_UFOR (int b = 0; b < NB1; ++b) {
+        double a = 0.0;
+        ANM_UFOR (int c = 0; c < NC; ++c) a = fma(C[S::T_THC + b * NC + c], du[c], a);
+        gv[S::R_TH_UP + b] = a;
+        gv[S::R_TH_LO + b] = -a;
+      }
+      ANM_UFOR (int e = 0; e < NBR; ++e) {
+        double al = 0.0;
+        ANM_UFOR (int c = 0; c < NC; ++c) al = fma(C[S::T_PHC + e * NC + c], du[c], al);
+        const double rt = -gt[e], ih = ln.htt[e];
+        const double w1 = ln.w[S::R_FL1 + e], w2 = ln.w[S::R_FL2 + e], w3 = ln.w[S::R_FL3 + e] + rho;
+        dt[e] = fma(rt, ih, -ln.hut[e] * al);
+        // al - dt and -al - dt without the cancellation when one weight dominates
+        gv[S::R_FL1 + e] = (al * (2.0 * w2 + w3) - rt) * ih;
+        gv[S::R_FL2 + e] = (-al * (2.0 * w1 + w3) - rt) * ih;
+        gv[S::R_FL3 + e] = -dt[e];
+      }
+    };
+    // largest step in [0, 1] keeping  v + a dv > 0  over this lane's rows
+    auto max_step = [&](const double (&v)[NR], const double (&dv)[NR]) {
+      double a = 1e300;
+      ANM_UFOR (int r = 0; r < NR; ++r) a = dv[r] < 0.0 ? fmin(a, -v[r] / dv[r]) : a;
+      return a;
+    };
+    // ---- predictor:  s dz + z ds = -s z  ->  zh = w rp ----
+    double zh[NR], ds[NR], dz[NR];
+    ANM_UFOR (int r = 0; r < NR; ++r) zh[r] = ln.w[r] * ln.rp[r];
+    newton(zh);
+    ANM_UFOR (int r = 0; r < NR; ++r) {
+      ds[r] = -ln.rp[r] - gv[r];
+      dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
+    }
+    double ap = fmin(1.0, x.min(on ? max_step(ln.s, ds) : 1e300));
+    double ad = fmin(1.0, x.min(on ? max_step(ln.z, dz) : 1e300));
+    double a_aff = 0.0;
+    ANM_UFOR (int r = 0; r < NR; ++r) {
+      a_aff = fma(fma(ap, ds[r], ln.s[r]), fma(ad, dz[r], ln.z[r]), a_aff);
+      ln.cross[r] = ds[r] * dz[r];
+    }
+    const double mu_aff = x.sum(on ? a_aff : 0.0) / m_rows;
+    const double ratio = mu_aff / n_mu;
+    // centring: Mehrotra's cube, not below what keeps mu from undershooting the target in one step
+    const double sg = fmin(1.0, fmax(ratio * ratio * ratio, 0.1 * opt.tol * (1.0 + fabs(n_obj)) / n_mu));
+    const double smu = sg * n_mu;
+    // ---- corrector:  s dz + z ds = sigma mu - s z - ds dz ----
+    ANM_UFOR (int r = 0; r < NR; ++r) zh[r] = fma(ln.w[r], ln.rp[r], (smu - ln.cross[r]) / ln.s[r]);
+    newton(zh);
+    ANM_UFOR (int r = 0; r < NR; ++r) {
+      ds[r] = -ln.rp[r] - gv[r];
+      dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
+    }
+    ap = fmin(1.0, 0.995 * x.min(on ? max_step(ln.s, ds) : 1e300));
+    ad = fmin(1.0, 0.995 * x.min(on ? max_step(ln.z, dz) : 1e300));
+    if (!done) {
+      ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = fma(ap, dxi[g], ln.xi[g]);
+      ANM_UFOR (int j = 0; j < NS; ++j) { ln.pc[j] = fma(ap, dpc[j], ln.pc[j]); ln.d[j] = fma(ap, dd[j], ln.d[j]); }
+      ANM_UFOR (int e = 0; e < NBR; ++e) ln.t[e] = fma(ap, dt[e], ln.t[e]);
+      ANM_UFOR (int r = 0; r < NR; ++r) {
+        ln.s[r] = fma(ap, ds[r], ln.s[r]);
+        ln.z[r] = fma(ad, dz[r], ln.z[r]);
+      }
+    }
+  }
+}
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------------------
+// gfx950: the lanes of a group exchange through wavefront shuffles.  SINGLE: one stage, one thread per
+// environment, no exchange at all.
+// ------------------------------------------------------------------------------------------------------------
+template <bool SINGLE>
+struct WaveGroup {
+  int G, st;
+  __device__ int stage() const { return st; }
+  __device__ double up(double v) const {
+    if (SINGLE) return 0.0;
+    const double r = __shfl_up(v, 1, G);
+    return st == 0 ? 0.0 : r;
+  }
+  __device__ double down(double v) const {
+    if (SINGLE) return 0.0;
+    const double r = __shfl_down(v, 1, G);
+    return st == G - 1 ? 0.0 : r;
+  }
+  __device__ double sum(double v) const {
+    if (!SINGLE)
+      for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+  }
+  __device__ double max(double v) const {
+    if (!SINGLE)
+      for (int o = G >> 1; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, G));
+    return v;
+  }
+  __device__ double min(double v) const {
+    if (!SINGLE)
+      for (int o = G >> 1; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, G));
+    return v;
+  }
+  __device__ double scan(double v) const {
+    if (!SINGLE)
+      for (int o = 1; o < G; o <<= 1) {
+        const double r = __shfl_up(v, o, G);
+        if (st >= o) v += r;
+      }
+    return v;
+  }
+  __device__ bool all_done(bool d) const { return __all(d); }
+};
+
+template <class T, bool SINGLE>
+__global__ __launch_bounds__(64) void k_mpc(cptr_t C, IO io, Opts opt, int64_t n_envs, int N, int G) {
+  if constexpr (Sz<T>::FITS) {
+    const int lane = threadIdx.x;
+    const int64_t env = int64_t(blockIdx.x) * (64 / G) + lane / G;
+    WaveGroup<SINGLE> x{G, lane % G};
+    solve<T>(C, io, opt, env, env < n_envs, N, x);
+  }
+}
+#endif
+
+}  // namespace mpc
+}  // namespace anm

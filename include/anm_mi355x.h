@@ -256,15 +256,49 @@ int anm_model_obs_fusable(const anm_model* m);
 int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const double* scale, const double* low,
                       const double* high);
 
-/* One ADMM iteration of the batched MPC DC-OPF policy (gym_anm/agents/mpc.py:163-372 solved for all
- * environments together, gym_anm_amd/agents/mpc.py), the part that is not a GEMM: with xt [E, n] and zt [E, m]
- * the results of the two products of the iteration,
- *   x <- alpha xt + (1 - alpha) x;   zh = alpha zt + (1 - alpha) z;   z <- clip(zh + y / rho, l, u);
- *   y <- y + rho (zh - z);           xw[e] <- [x[e], rho z[e] - y[e]]   (left operand of the next product)
- * l, u, z, y: [E, m]; rho: [m]; x: [E, n]; xw: [E, n + m].  All dev. */
-int anm_admm_update_f64(int64_t num_envs, int32_t n, int32_t m, double alpha, const double* xt, const double* zt,
-                        const double* l, const double* u, const double* rho, double* x, double* z, double* y, double* xw,
-                        void* stream);
+/* ---- MPC DC-OPF policy: MPCAgent._create_optimization_problem / _single_step_optimization_problem / _solve,
+ * gym_anm/agents/mpc.py:163-319, 372-388 (cvxpy program built once, `Problem.solve()` per environment and step).
+ * Here: the N-stage linear program of every environment of a batch in ONE launch (one lane per stage, a structured
+ * primal-dual interior-point method; gym_anm_amd/csrc/anm_mpc.hpp).
+ *
+ *   anm_mpc_create    <- MPCAgent.__init__ + _create_optimization_problem   mpc.py:33-122, 163-230
+ *                        builds the tables of the reduced program (DC balance mpc.py:232-245 solved for the angles
+ *                        and the slack injection) from the same network description as anm_model_create
+ *   anm_mpc_solve_f64 <- MPCAgent._update_parameters + _solve               mpc.py:372-417
+ *
+ * planning_steps in [1, 64].  Forecasts and results are per-unit, like the reference's program. */
+typedef struct anm_mpc anm_mpc; /* opaque: device tables of one (network, gamma, safety margin, horizon) */
+
+typedef struct anm_mpc_dims {
+  int32_t planning_steps;
+  int32_t n_load, n_gen, n_des, n_branch;
+  int32_t n_ctrl;          /* n_gen + n_des: width of u0 = [P_gen.., P_des..] */
+  int32_t n_stage_vars;    /* n_gen + 2 n_des + n_branch: width of one stage of `solution` (P_g.., p_c.., d.., t_e..) */
+  int32_t n_stage_rows;    /* inequality rows per stage of the reduced program */
+  int32_t table_doubles;
+} anm_mpc_dims;
+
+typedef struct anm_mpc_opts {
+  double tol;        /* stop when the complementarity gap per row mu <= tol (1 + |objective|) and the row
+                        residuals are <= 1e-9; 0 = default 1e-11 */
+  int32_t max_iter;  /* interior-point iterations; 0 = default 40 */
+} anm_mpc_opts;
+
+int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps,
+                   anm_mpc** out);
+void anm_mpc_destroy(anm_mpc* m);
+int anm_mpc_dims_of(const anm_mpc* m, anm_mpc_dims* out);
+/* host copy of the table of the reduced program (tests compare it with gym_anm_amd/agents/dcopf.py) */
+int anm_mpc_get_tables(const anm_mpc* m, double* out /* [table_doubles] host */);
+/* p_load_forecast [num_envs, N, n_load], p_gen_forecast [num_envs, N, n_gen] (mpc.py:348-372: forecast(), here
+ * stage-major), soc [num_envs, n_des] (mpc.py:417).  Out: u0 [num_envs, n_ctrl] the first-stage P_gen / P_des
+ * (mpc.py:383-388, before the scaling to MW), objective [num_envs] (the value of the reference's program),
+ * iters [num_envs], info [num_envs, 2] (final mu, largest row residual; may be NULL), solution
+ * [num_envs, N, n_stage_vars] (may be NULL).  All dev.  An environment whose solve does not reach the tolerance
+ * within max_iter reports iters = max_iter (not an error, like a non-"optimal" status in the reference, :377-379). */
+int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
+                      const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
+                      const anm_mpc_opts* opts, void* stream);
 
 /* Offsets of each quantity inside one row of `full` (p.u. / rad), in the order of the reference's
  * STATE_VARIABLES (constants.py:31-48): bus_p, bus_q, bus_v_magn, bus_v_ang, bus_i_magn,

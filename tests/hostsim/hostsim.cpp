@@ -15,6 +15,11 @@
 #include ANM_TOPO_HEADER
 #include "../../gym_anm_amd/csrc/anm_env_ops.hpp"
 #include "../../gym_anm_amd/csrc/anm_pack.hpp"
+#include "../../gym_anm_amd/csrc/anm_mpc.hpp"
+
+#include <pthread.h>
+
+#include <thread>
 
 using namespace anm;
 
@@ -27,6 +32,40 @@ struct anm_model {
   std::vector<double> series;
   int period = 0, K = 0;
   bool env_set = false;
+};
+
+struct anm_mpc {
+  int N = 0;
+  std::vector<double> tab;
+};
+
+// the lanes of one group as host threads
+struct HostGroupShared {
+  int n;
+  std::vector<double> slot;
+  pthread_barrier_t bar;
+  explicit HostGroupShared(int n_) : n(n_), slot(n_, 0.0) { pthread_barrier_init(&bar, nullptr, unsigned(n_)); }
+  ~HostGroupShared() { pthread_barrier_destroy(&bar); }
+};
+struct HostGroup {
+  HostGroupShared* g;
+  int st;
+  int stage() const { return st; }
+  template <class F>
+  double exch(double v, F&& f) const {
+    g->slot[st] = v;
+    pthread_barrier_wait(&g->bar);
+    const double r = f(g->slot);
+    pthread_barrier_wait(&g->bar);
+    return r;
+  }
+  double up(double v) const { return exch(v, [&](const std::vector<double>& s) { return st > 0 ? s[st - 1] : 0.0; }); }
+  double down(double v) const { return exch(v, [&](const std::vector<double>& s) { return st + 1 < g->n ? s[st + 1] : 0.0; }); }
+  double sum(double v) const { return exch(v, [&](const std::vector<double>& s) { double a = 0; for (double q : s) a += q; return a; }); }
+  double max(double v) const { return exch(v, [&](const std::vector<double>& s) { double a = s[0]; for (double q : s) a = std::fmax(a, q); return a; }); }
+  double min(double v) const { return exch(v, [&](const std::vector<double>& s) { double a = s[0]; for (double q : s) a = std::fmin(a, q); return a; }); }
+  double scan(double v) const { return exch(v, [&](const std::vector<double>& s) { double a = 0; for (int k = 0; k <= st; ++k) a += s[k]; return a; }); }
+  bool all_done(bool d) const { return exch(d ? 1.0 : 0.0, [&](const std::vector<double>& s) { double a = 1; for (double q : s) a = std::fmin(a, q); return a; }) > 0.5; }
 };
 
 static SolverOpts solver(const anm_solver_opts* o, int& prec) {
@@ -161,21 +200,51 @@ int anm_model_set_classes(anm_model*, int32_t n_classes, const anm_network_desc*
 int anm_model_bind_env_classes(anm_model*, const int32_t* env_class, int64_t) {
   return env_class ? fail("the host test double has no parameter classes") : 0;
 }
-int anm_admm_update_f64(int64_t E, int32_t n, int32_t m, double alpha, const double* xt, const double* zt, const double* l,
-                        const double* u, const double* rv, double* x, double* z, double* y, double* xw, void*) {
-  for (int64_t e = 0; e < E; ++e) {
-    for (int k = 0; k < n; ++k) {
-      x[e * n + k] = alpha * xt[e * n + k] + (1.0 - alpha) * x[e * n + k];
-      xw[e * (n + m) + k] = x[e * n + k];
+// ---- MPC DC-OPF: the solver of gym_anm_amd/csrc/anm_mpc.hpp with one HOST THREAD per lane (= stage); what the
+// wavefront shuffles do on the GPU goes through an exchange array between two barriers
+int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps, anm_mpc** out) {
+  if constexpr (!mpc::Sz<Topo>::FITS) {
+    return fail("anm_mpc_create: this network has too many rows per stage for the register-resident MPC kernel");
+  } else {
+    std::string err;
+    if (!check_topology<Topo>(*desc, err)) { g_err = err; return -3; }
+    anm_mpc* m = new anm_mpc();
+    if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err)) { delete m; g_err = err; return -3; }
+    m->N = planning_steps;
+    *out = m;
+    return 0;
+  }
+}
+void anm_mpc_destroy(anm_mpc* m) { delete m; }
+int anm_mpc_dims_of(const anm_mpc* m, anm_mpc_dims* o) {
+  typedef mpc::Sz<Topo> S;
+  o->planning_steps = m->N; o->n_load = S::NL; o->n_gen = S::NG; o->n_des = S::NS; o->n_branch = S::NBR;
+  o->n_ctrl = S::NC; o->n_stage_vars = S::NV; o->n_stage_rows = S::NR; o->table_doubles = S::T_TOTAL;
+  return 0;
+}
+int anm_mpc_get_tables(const anm_mpc* m, double* out) {
+  std::memcpy(out, m->tab.data(), m->tab.size() * sizeof(double));
+  return 0;
+}
+int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
+                      const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
+                      const anm_mpc_opts* opts, void*) {
+  if constexpr (mpc::Sz<Topo>::FITS) {
+    mpc::Opts o{1e-11, 40};
+    if (opts) {
+      if (opts->tol > 0.0) o.tol = opts->tol;
+      if (opts->max_iter > 0) o.max_iter = opts->max_iter;
     }
-    for (int j = 0; j < m; ++j) {
-      const int64_t i = e * m + j;
-      const double zh = alpha * zt[i] + (1.0 - alpha) * z[i];
-      const double zn = std::fmin(std::fmax(zh + y[i] / rv[j], l[i]), u[i]);
-      y[i] += rv[j] * (zh - zn);
-      z[i] = zn;
-      xw[e * (n + m) + n + j] = rv[j] * zn - y[i];
-    }
+    mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution};
+    const int N = m->N;
+    HostGroupShared sh(N);
+    std::vector<std::thread> th;
+    for (int st = 0; st < N; ++st)
+      th.emplace_back([&, st]() {
+        HostGroup x{&sh, st};
+        for (int64_t e = 0; e < num_envs; ++e) mpc::solve<Topo>(m->tab.data(), io, o, e, true, N, x);
+      });
+    for (auto& t : th) t.join();
   }
   return 0;
 }

@@ -31,7 +31,7 @@ def hostsim_backend(topo):
     ]
     newest = max(os.path.getmtime(p) for p in srcs + [hdr])
     if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ftemplate-depth=4096", "-ffp-contract=off",
+        cmd = ["g++", "-pthread", "-O2", "-std=c++17", "-fPIC", "-shared", "-ftemplate-depth=4096", "-ffp-contract=off",
                '-DANM_TOPO_HEADER="%s"' % hdr, "-I", os.path.join(ROOT, "include"), srcs[0], "-o", lib]  # fmt: skip
         subprocess.run(cmd, check=True, capture_output=True)
     be = Backend(ctypes.CDLL(lib), "cpu", lib)
