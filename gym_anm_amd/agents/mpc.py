@@ -149,7 +149,7 @@ class BatchedDCOPF:
     environments per wavefront, the network tables of the reduced program (``dcopf.py``) as scalar loads.
 
     ``solve(P_load_forecast [E, n_load, N], P_gen_forecast [E, n_gen, N], soc [E, n_des])`` -> the first-stage
-    ``[P_gen.., P_des..]`` (p.u.); ``objective``, ``iters``, ``info`` (final complementarity, row residual) and, on
+    ``[P_gen.., P_des..]`` (p.u.); ``objective``, ``iters``, ``info`` (final complementarity, row residual, dual residual) and, on
     request, the whole primal solution stay available as tensors."""
 
     def __init__(self, simulator, gamma, safety_margin, planning_steps, tol=None, max_iter=None, keep_solution=False):
@@ -186,7 +186,7 @@ class BatchedDCOPF:
             self.u0 = torch.zeros((E, d.n_ctrl), **f)
             self.objective = torch.zeros(E, **f)
             self.iters = torch.zeros(E, dtype=torch.int32, device=self.device)
-            self.info = torch.zeros((E, 2), **f)
+            self.info = torch.zeros((E, 3), **f)
             self.solution = torch.zeros((E, self.N, d.n_stage_vars), **f) if self.keep_solution else None
             self._E = E
 
@@ -267,7 +267,8 @@ class MPCAgent:
         ng = self.solver.dims.n_gen
         P_gen, P_des = u0[:, :ng], u0[:, ng:]
         a = torch.cat((P_gen, torch.zeros_like(P_gen), P_des, torch.zeros_like(P_des)), dim=1)
-        self.last_converged = self.solver.iters < self.solver.max_iter
+        # reached the tolerance, with a dual residual that is small against the costs (info: mu, row residual, dual residual)
+        self.last_converged = (self.solver.iters < self.solver.max_iter) & (self.solver.info[:, 2] <= 1e-6 * (1.0 + self.lamb))
         if not bool(self.last_converged.all()):
             import warnings
 

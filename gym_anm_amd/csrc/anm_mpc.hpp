@@ -27,6 +27,7 @@
 #pragma once
 
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -68,7 +69,8 @@ struct Sz {
 };
 
 struct Opts {
-  double tol;        // stop: complementarity mu <= tol (1 + |objective|) and row residuals <= 1e-9
+  double tol;        // stop: complementarity mu <= tol (1 + |objective|) and row residuals <= 1e-9 (the dual residual is
+                     // reported: a solve is to be trusted when it is small against the costs)
   int max_iter;
 };
 
@@ -80,7 +82,7 @@ struct IO {
   double* u0;            // [E][NC]    first-stage [P_gen.., P_des..], p.u.
   double* objective;     // [E]
   int32_t* iters;        // [E]
-  double* info;          // [E][2]     final mu, largest row residual   (may be null)
+  double* info;          // [E][3]     final mu, largest row residual, largest dual residual   (may be null)
   double* solution;      // [E][N][NV] P_g, p_c, d, t per stage         (may be null)
 };
 
@@ -237,8 +239,8 @@ struct Lane {
   // per iteration
   double rp[NR], w[NR], cross[NR];                  // row residuals, z/s, ds*dz of the predictor
   double htt[pos(NBR)], hut[pos(NBR)];
-  double Lc[NA * (NA + 1) / 2];                      // Cholesky factor of R (row-major lower triangle)
-  double RiBt[pos(NA * NS)], Mm[pos(NS * NS)], Pm[pos(NS * NS)], Ki[pos(NS * NS)];  // R^-1 B', B R^-1 B', P, (I + M P)^-1
+  double Lc[pos(NA * (NA + 1) / 2)];                      // Cholesky factor of R (row-major lower triangle)
+  double RiBt[pos(NA * NS)], Mm[pos(NS * NS)], Pm[pos(NS * NS)], Ki[pos(NS * NS)], Po[pos(NS * NS)];  // R^-1 B', B R^-1 B', P, (I + M P)^-1, P (I + M P)^-1
   double sig[pos(NS)];
 
   static ANM_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
@@ -294,7 +296,7 @@ struct Lane {
 
   // gradient of the Lagrangian for multipliers zh: inputs (xi, p_c, d) and state; the epigraph variables'
   // share folded into the flows (eliminate: right-hand sides of a Newton step), their own gradient in gt
-  ANM_HD void gradient(cptr_t C, const double (&zh)[NR], bool eliminate, double (&g_in)[NA], double (&g_st)[pos(NS)],
+  ANM_HD void gradient(cptr_t C, const double (&zh)[NR], bool eliminate, double (&g_in)[pos(NA)], double (&g_st)[pos(NS)],
                        double (&gt)[pos(NBR)]) const {
     double gu[pos(NC)];
     ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = wgt * C[S::T_COST + c];
@@ -317,8 +319,11 @@ struct Lane {
     }
   }
 
-  // R = J' Hu J + (weights of the direct rows) + rho I, factored; R^-1 B', M = B R^-1 B'
-  ANM_HD void factor_stage(cptr_t C, double rho) {
+  // R = J' Hu J + (weights of the direct rows) + rho I, factored; R^-1 B', M = B R^-1 B'.  rho = a few units of
+  // roundoff of the largest diagonal entry: what keeps R numerically positive definite when the weights of a
+  // stage span more than 1/eps (directions only inactive rows see, next to rows about to become active); anything
+  // larger freezes those directions and leaves a dual residual rho |dv| behind
+  ANM_HD void factor_stage(cptr_t C) {
     double Hu[pos(NC * (NC + 1) / 2)];
     ANM_UFOR (int k = 0; k < NC * (NC + 1) / 2; ++k) Hu[k] = 0.0;
     ANM_UFOR (int b = 0; b < NB1; ++b) {
@@ -330,10 +335,10 @@ struct Lane {
     }
     ANM_UFOR (int e = 0; e < NBR; ++e) {
       const double w1 = w[S::R_FL1 + e], w2 = w[S::R_FL2 + e], w3 = w[S::R_FL3 + e];
-      const double h = w1 + w2 + w3 + rho, ih = 1.0 / h;
+      const double h = w1 + w2 + w3, ih = 1.0 / h;
       htt[e] = ih;                          // (the reciprocal is what every later use needs)
       hut[e] = (w2 - w1) * ih;
-      const double hat = (4.0 * w1 * w2 + (w3 + rho) * (w1 + w2)) * ih;  // weight of (a.du)^2 with t_e eliminated
+      const double hat = (4.0 * w1 * w2 + w3 * (w1 + w2)) * ih;  // weight of (a.du)^2 with t_e eliminated
       ANM_UFOR (int i = 0; i < NC; ++i) {
         const double wi = hat * C[S::T_PHC + e * NC + i];
         ANM_UFOR (int j = 0; j <= i; ++j) Hu[tri(i, j)] = fma(wi, C[S::T_PHC + e * NC + j], Hu[tri(i, j)]);
@@ -341,7 +346,7 @@ struct Lane {
     }
     ANM_UFOR (int j = 0; j < NS; ++j) Hu[tri(NG + j, NG + j)] += w[S::R_PD_UP + j] + w[S::R_PD_LO + j];
     // R over (xi.., pc.., d..):  u_g = wd_g xi_g,  u_des_j = d_j - pc_j
-    double R[NA * (NA + 1) / 2];
+    double R[pos(NA * (NA + 1) / 2)];
     auto ju = [&](int a, int& c, double& f) {  // input a moves u_c by f
       if (a < NG) { c = a; f = wd[a]; }
       else if (a < NG + NS) { c = a; f = -1.0; }
@@ -355,11 +360,15 @@ struct Lane {
         ju(b, cb, fb);
         R[tri(a, b)] = fa * fb * (ca >= cb ? Hu[tri(ca, cb)] : Hu[tri(cb, ca)]);
       }
-    ANM_UFOR (int g = 0; g < NG; ++g) R[tri(g, g)] += w[S::R_XI_UP + g] + w[S::R_XI_LO + g] + rho;
+    ANM_UFOR (int g = 0; g < NG; ++g) R[tri(g, g)] += w[S::R_XI_UP + g] + w[S::R_XI_LO + g];
     ANM_UFOR (int j = 0; j < NS; ++j) {
-      R[tri(NG + j, NG + j)] += w[S::R_PC + j] + rho;
-      R[tri(NG + NS + j, NG + NS + j)] += w[S::R_D + j] + rho;
+      R[tri(NG + j, NG + j)] += w[S::R_PC + j];
+      R[tri(NG + NS + j, NG + NS + j)] += w[S::R_D + j];
     }
+    double dmax = 0.0;
+    ANM_UFOR (int a = 0; a < NA; ++a) dmax = fmax(dmax, R[tri(a, a)]);
+    const double rho = fma(4e-16, dmax, 1e-14);
+    ANM_UFOR (int a = 0; a < NA; ++a) R[tri(a, a)] += rho;
     // Cholesky, the diagonal stored inverted
     ANM_UFOR (int i = 0; i < NA; ++i)
       ANM_UFOR (int j = 0; j <= i; ++j) {
@@ -369,7 +378,7 @@ struct Lane {
         else Lc[tri(i, j)] = acc * Lc[tri(j, j)];
       }
     ANM_UFOR (int j = 0; j < NS; ++j) {
-      double col[NA];
+      double col[pos(NA)];
       ANM_UFOR (int a = 0; a < NA; ++a) col[a] = 0.0;
       col[NG + j] = C[S::T_BC + j];
       col[NG + NS + j] = -C[S::T_BD + j];
@@ -381,7 +390,7 @@ struct Lane {
         Mm[i * NS + j] = C[S::T_BC + i] * RiBt[(NG + i) * NS + j] - C[S::T_BD + i] * RiBt[(NG + NS + i) * NS + j];
   }
 
-  ANM_HD void chol_solve(double (&x)[NA]) const {
+  ANM_HD void chol_solve(double (&x)[pos(NA)]) const {
     ANM_UFOR (int i = 0; i < NA; ++i) {
       double acc = x[i];
       ANM_UFOR (int k = 0; k < i; ++k) acc = fma(-Lc[tri(i, k)], x[k], acc);
@@ -394,30 +403,70 @@ struct Lane {
     }
   }
 
-  // Ki = (I + M P)^-1 for the P of this stage
+  // For the P of this stage:  Ki = (I + M P)^-1  and  Po = P (I + M P)^-1, through the symmetric form
+  //   P = L L',  S = I + L' M L (SPD, eigenvalues >= 1):   Ki = L^-T S^-1 L',   Po = L S^-1 L'
+  // (I + M P itself is neither symmetric nor well conditioned once a state-of-charge row is about to become active
+  // next to inputs nothing pins: an unpivoted elimination of it loses the dual residual)
   ANM_HD void set_P(const double (&P)[pos(NS * NS)]) {
-    double A[pos(NS * NS)];
-    ANM_UFOR (int i = 0; i < NS; ++i)
-      ANM_UFOR (int j = 0; j < NS; ++j) {
-        double acc = i == j ? 1.0 : 0.0;
-        ANM_UFOR (int k = 0; k < NS; ++k) acc = fma(Mm[i * NS + k], P[k * NS + j], acc);
-        A[i * NS + j] = acc;
-        Pm[i * NS + j] = P[i * NS + j];
-        Ki[i * NS + j] = i == j ? 1.0 : 0.0;
+    double L[pos(NS * NS)], Li[pos(NS * NS)], Sm[pos(NS * NS)], Ls[pos(NS * NS)], Lsi[pos(NS * NS)], Si[pos(NS * NS)];
+    ANM_UFOR (int k = 0; k < NS * NS; ++k) { Pm[k] = P[k]; L[k] = 0.0; Li[k] = 0.0; Ls[k] = 0.0; Lsi[k] = 0.0; }
+    chol_small(P, L);
+    tri_inv(L, Li);
+    // S = I + L' M L
+    double ML[pos(NS * NS)];
+    ANM_UFOR (int a = 0; a < NS; ++a)
+      ANM_UFOR (int b = 0; b < NS; ++b) {
+        double acc = 0.0;
+        ANM_UFOR (int c = b; c < NS; ++c) acc = fma(Mm[a * NS + c], L[c * NS + b], acc);
+        ML[a * NS + b] = acc;
       }
-    ANM_UFOR (int c = 0; c < NS; ++c) {  // Gauss-Jordan (the matrix is I + (PSD)(PSD): eigenvalues >= 1)
-      const double piv = 1.0 / A[c * NS + c];
-      ANM_UFOR (int k = 0; k < NS; ++k) {
-        A[c * NS + k] *= piv;
-        Ki[c * NS + k] *= piv;
+    ANM_UFOR (int a = 0; a < NS; ++a)
+      ANM_UFOR (int b = 0; b < NS; ++b) {
+        double acc = a == b ? 1.0 : 0.0;
+        ANM_UFOR (int c = a; c < NS; ++c) acc = fma(L[c * NS + a], ML[c * NS + b], acc);
+        Sm[a * NS + b] = acc;
       }
-      ANM_UFOR (int r = 0; r < NS; ++r) {
-        if (r == c) continue;
-        const double f = A[r * NS + c];
-        ANM_UFOR (int k = 0; k < NS; ++k) {
-          A[r * NS + k] = fma(-f, A[c * NS + k], A[r * NS + k]);
-          Ki[r * NS + k] = fma(-f, Ki[c * NS + k], Ki[r * NS + k]);
-        }
+    chol_small(Sm, Ls);
+    tri_inv(Ls, Lsi);
+    ANM_UFOR (int a = 0; a < NS; ++a)
+      ANM_UFOR (int b = 0; b < NS; ++b) {  // S^-1 = Ls^-T Ls^-1
+        double acc = 0.0;
+        ANM_UFOR (int c = (a > b ? a : b); c < NS; ++c) acc = fma(Lsi[c * NS + a], Lsi[c * NS + b], acc);
+        Si[a * NS + b] = acc;
+      }
+    double SLt[pos(NS * NS)];  // S^-1 L'
+    ANM_UFOR (int a = 0; a < NS; ++a)
+      ANM_UFOR (int b = 0; b < NS; ++b) {
+        double acc = 0.0;
+        ANM_UFOR (int c = 0; c <= b; ++c) acc = fma(Si[a * NS + c], L[b * NS + c], acc);
+        SLt[a * NS + b] = acc;
+      }
+    ANM_UFOR (int a = 0; a < NS; ++a)
+      ANM_UFOR (int b = 0; b < NS; ++b) {
+        double k = 0.0, o = 0.0;
+        ANM_UFOR (int c = a; c < NS; ++c) k = fma(Li[c * NS + a], SLt[c * NS + b], k);   // L^-T (S^-1 L')
+        ANM_UFOR (int c = 0; c <= a; ++c) o = fma(L[a * NS + c], SLt[c * NS + b], o);    // L (S^-1 L')
+        Ki[a * NS + b] = k;
+        Po[a * NS + b] = o;
+      }
+  }
+
+  // lower Cholesky factor of a small SPD matrix (full storage); inverse of a lower triangular matrix
+  static ANM_HD void chol_small(const double (&A)[pos(NS * NS)], double (&L)[pos(NS * NS)]) {
+    ANM_UFOR (int a = 0; a < NS; ++a)
+      ANM_UFOR (int b = 0; b <= a; ++b) {
+        double acc = A[a * NS + b];
+        ANM_UFOR (int c = 0; c < b; ++c) acc = fma(-L[a * NS + c], L[b * NS + c], acc);
+        L[a * NS + b] = a == b ? sqrt(acc) : acc / L[b * NS + b];
+      }
+  }
+  static ANM_HD void tri_inv(const double (&L)[pos(NS * NS)], double (&Li)[pos(NS * NS)]) {
+    ANM_UFOR (int b = 0; b < NS; ++b) {
+      Li[b * NS + b] = 1.0 / L[b * NS + b];
+      ANM_UFOR (int a = b + 1; a < NS; ++a) {
+        double acc = 0.0;
+        ANM_UFOR (int c = b; c < a; ++c) acc = fma(L[a * NS + c], Li[c * NS + b], acc);
+        Li[a * NS + b] = -acc / L[a * NS + a];
       }
     }
   }
@@ -432,7 +481,7 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
   const int i = x.stage();
   const bool on = valid && i < N;  // a lane without a stage runs along with neutral contributions
   L ln;
-  ANM_UFOR (int k = 0; k < pos(NS * NS); ++k) { ln.Pm[k] = 0.0; ln.Ki[k] = 0.0; ln.Mm[k] = 0.0; }
+  ANM_UFOR (int k = 0; k < pos(NS * NS); ++k) { ln.Pm[k] = 0.0; ln.Ki[k] = 0.0; ln.Mm[k] = 0.0; ln.Po[k] = 0.0; }
   // ---- constants of the stage ----
   ln.wgt = C[S::T_WGT + (i < 64 ? i : 63)];
   ln.ct = ln.wgt * C[S::T_LAMB];
@@ -458,48 +507,78 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
     ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_SGL + l], pl[l], a);
     ln.objc = ln.wgt * a;
   }
-  // ---- start: mid-interval generators, a little charge and the discharge that undoes it, no overload ----
+  // ---- start: strictly inside every row, so that the row residuals are zero from the first iteration on (the
+  // rows are linear: they stay zero) -- mid-interval generators; a little charge and the discharge that undoes
+  // it, plus what moves the state of charge a fifth of the way towards the middle of its window over the horizon
+  // (a state of charge AT a bound is the usual case: an empty or a full unit); epigraph variables above the
+  // overloads of that point ----
   ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = 0.5;
   ANM_UFOR (int j = 0; j < NS; ++j) {
-    ln.pc[j] = 0.05 * (C[S::T_SPMAX + j] - C[S::T_SPMIN + j]);
-    ln.d[j] = ln.pc[j] * (C[S::T_BC + j] / C[S::T_BD + j]);
-    ln.sig[j] = soc0[j];
+    const double bc = C[S::T_BC + j], bd = C[S::T_BD + j], pmax = C[S::T_SPMAX + j], pmin = C[S::T_SPMIN + j];
+    const double base = 0.05 * (pmax - pmin);
+    const double mid = 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
+    double dsig = 0.2 * (mid - soc0[j]) / double(N);
+    dsig = fmin(fmax(dsig, -0.25 * pmax * bd), -0.25 * pmin * bc);   // (a quarter of the power limits at most)
+    ln.pc[j] = base + fmax(dsig, 0.0) / bc;
+    ln.d[j] = base * (bc / bd) + fmax(-dsig, 0.0) / bd;
+    ln.sig[j] = soc0[j] + double(i + 1) * dsig;
   }
-  ANM_UFOR (int e = 0; e < NBR; ++e) ln.t[e] = 0.1;
+  {
+    double u[pos(NC)];
+    ln.phys(C, u);
+    ANM_UFOR (int e = 0; e < NBR; ++e) {
+      double fl = ln.f0[e];
+      ANM_UFOR (int c = 0; c < NC; ++c) fl = fma(C[S::T_PHC + e * NC + c], u[c], fl);
+      ln.t[e] = fmax(fabs(fl) - C[S::T_LIM + e], 0.0) + 0.1;
+    }
+  }
   {
     double val[NR];
     ln.row_values(C, val);
     ANM_UFOR (int r = 0; r < NR; ++r) {
-      ln.s[r] = fmax(-val[r], 1e-2);
+      ln.s[r] = -val[r] > 0.0 ? -val[r] : 1e-2;               // (not strictly inside: a residual the iteration removes)
       ln.z[r] = r >= S::R_FL1 ? ln.ct * (1.0 / 3.0) : 1.0;  // dual feasible for the epigraph variables
     }
   }
   const double m_rows = double(NR) * double(N);
   int it = 0;
   bool done = !valid;
-  double mu = 0.0, rpmax = 0.0, obj = 0.0;
+  double mu = 0.0, rpmax = 0.0, rdmax = 0.0, obj = 0.0;
   for (;; ++it) {
     // ---- evaluate ----
     ANM_UFOR (int j = 0; j < NS; ++j) ln.sig[j] = soc0[j] + x.scan(on ? fma(C[S::T_BC + j], ln.pc[j], -C[S::T_BD + j] * ln.d[j]) : 0.0);
     double val[NR];
     ln.row_values(C, val);
-    double a_mu = 0.0, a_rp = 0.0, a_w = 0.0;
+    double a_mu = 0.0, a_rp = 0.0;
     ANM_UFOR (int r = 0; r < NR; ++r) {
       ln.rp[r] = val[r] + ln.s[r];
       ln.w[r] = ln.z[r] / ln.s[r];
       a_mu = fma(ln.s[r], ln.z[r], a_mu);
       a_rp = fmax(a_rp, fabs(ln.rp[r]));
-      a_w = fmax(a_w, ln.w[r]);
     }
-    const double n_mu = x.sum(on ? a_mu : 0.0) / m_rows, n_rp = x.max(on ? a_rp : 0.0), wmax = x.max(on ? a_w : 0.0);
+    double a_rd = 0.0;
+    {  // dual residual: gradient of the Lagrangian; the state rows of the stages from here on act on this stage's
+       // inputs through B
+      double g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
+      ln.gradient(C, ln.z, false, g_in, g_st, gt);
+      ANM_UFOR (int j = 0; j < NS; ++j) {
+        const double mine = on ? g_st[j] : 0.0;
+        const double lam = x.sum(mine) - x.scan(mine) + mine;
+        g_in[NG + j] = fma(C[S::T_BC + j], lam, g_in[NG + j]);
+        g_in[NG + NS + j] = fma(-C[S::T_BD + j], lam, g_in[NG + NS + j]);
+      }
+      ANM_UFOR (int a = 0; a < NA; ++a) a_rd = fmax(a_rd, fabs(g_in[a]));
+      ANM_UFOR (int e = 0; e < NBR; ++e) a_rd = fmax(a_rd, fabs(gt[e]));
+    }
+    const double n_mu = x.sum(on ? a_mu : 0.0) / m_rows, n_rp = x.max(on ? a_rp : 0.0), n_rd = x.max(on ? a_rd : 0.0);
     const double n_obj = x.sum(on ? ln.objective(C) : 0.0);
-    if (!done) { mu = n_mu; rpmax = n_rp; obj = n_obj; }
+    if (!done) { mu = n_mu; rpmax = n_rp; rdmax = n_rd; obj = n_obj; }
     if (!done && ((mu <= opt.tol * (1.0 + fabs(obj)) && rpmax <= 1e-9) || it >= opt.max_iter || !(mu == mu))) {
       done = true;
       if (valid && i == 0) {
         io.objective[env] = obj;
         io.iters[env] = it;
-        if (io.info) { io.info[env * 2] = mu; io.info[env * 2 + 1] = rpmax; }
+        if (io.info) { io.info[env * 3] = mu; io.info[env * 3 + 1] = rpmax; io.info[env * 3 + 2] = rdmax; }
         double u[pos(NC)];
         ln.phys(C, u);
         ANM_UFOR (int c = 0; c < NC; ++c) io.u0[env * NC + c] = u[c];
@@ -515,34 +594,27 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
     }
     if (x.all_done(done)) break;
     // ---- factor (once per iteration) ----
-    const double rho = fma(1e-13, wmax, 1e-12);  // proximal term: keeps the directions no active row pins well posed
-    ln.factor_stage(C, rho);
+    ln.factor_stage(C);
     {  // Riccati sweep, last stage first:  P_i = Q_i + P'_{i+1},  P'_i = P_i (I + M_i P_i)^-1
       double Pn[pos(NS * NS)];
       ANM_UFOR (int k = 0; k < NS * NS; ++k) Pn[k] = 0.0;
       for (int k = N - 1; k >= 0; --k) {
-        double P[pos(NS * NS)], out[pos(NS * NS)];
+        double P[pos(NS * NS)];
         ANM_UFOR (int a = 0; a < NS; ++a)
           ANM_UFOR (int b = 0; b < NS; ++b) P[a * NS + b] = Pn[a * NS + b] + (a == b ? ln.w[S::R_SOC_UP + a] + ln.w[S::R_SOC_LO + a] : 0.0);
         if (i == k) ln.set_P(P);
-        ANM_UFOR (int a = 0; a < NS; ++a)
-          ANM_UFOR (int b = 0; b < NS; ++b) {
-            double acc = 0.0;
-            ANM_UFOR (int c = 0; c < NS; ++c) acc = fma(ln.Pm[a * NS + c], ln.Ki[c * NS + b], acc);
-            out[a * NS + b] = acc;
-          }
         ANM_UFOR (int q = 0; q < NS * NS; ++q) {
-          const double got = x.down(i == k ? out[q] : 0.0);  // stage k - 1 receives P'_k
+          const double got = x.down(i == k ? ln.Po[q] : 0.0);  // stage k - 1 receives P'_k
           if (i == k - 1) Pn[q] = got;
         }
       }
     }
     // ---- Newton step for multipliers zh ----
-    double dxi[pos(NG)], dpc[pos(NS)], dd[pos(NS)], dt[pos(NBR)], gv[NR];
+    double dxi[pos(NG)], dpc[pos(NS)], dd[pos(NS)], dt[pos(NBR)], gv[NR], dsig[pos(NS)];
     auto newton = [&](const double (&zh)[NR]) {
-      double g_in[NA], g_st[pos(NS)], gt[pos(NBR)];
+      double g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
       ln.gradient(C, zh, true, g_in, g_st, gt);
-      double y[NA];
+      double y[pos(NA)];
       ANM_UFOR (int a = 0; a < NA; ++a) y[a] = g_in[a];
       ln.chol_solve(y);
       double mv[pos(NS)];
@@ -592,14 +664,17 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
           if (i == k + 1) xp[j] = got;
         }
       }
-      // costate and inputs
-      double da[NA];
-      ANM_UFOR (int a = 0; a < NA; ++a) da[a] = -y[a];
+      // costate, then the inputs from  R da = -(g_in + B' co): the sum first, the solve after -- adding
+      // R^-1 g_in and R^-1 B' co instead would cancel AFTER both were amplified along the directions no row pins
+      double da[pos(NA)];
+      ANM_UFOR (int a = 0; a < NA; ++a) da[a] = -g_in[a];
       ANM_UFOR (int j = 0; j < NS; ++j) {
         double co = p[j];
         ANM_UFOR (int b = 0; b < NS; ++b) co = fma(ln.Pm[j * NS + b], xs[b], co);
-        ANM_UFOR (int a = 0; a < NA; ++a) da[a] = fma(-ln.RiBt[a * NS + j], co, da[a]);
+        da[NG + j] = fma(-C[S::T_BC + j], co, da[NG + j]);
+        da[NG + NS + j] = fma(C[S::T_BD + j], co, da[NG + NS + j]);
       }
+      ln.chol_solve(da);
       ANM_UFOR (int g = 0; g < NG; ++g) dxi[g] = da[g];
       ANM_UFOR (int j = 0; j < NS; ++j) { dpc[j] = da[NG + j]; dd[j] = da[NG + NS + j]; }
       // g.dv of every row
@@ -612,8 +687,13 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         gv[S::R_PD_LO + j] = -du[NG + j];
         gv[S::R_PC + j] = -dpc[j];
         gv[S::R_D + j] = -dd[j];
+        // the sweep's state step for the multipliers (w * it is what balances the gradient: accurate to roundoff of
+        // the SWEEP), and the state step the inputs themselves produce for the slacks (the rows stay satisfied to
+        // roundoff); the two differ by what the recovery of the inputs loses, ~1e-10 when a window row is about
+        // to become active -- times the row's weight that would be the whole dual residual
         gv[S::R_SOC_UP + j] = xs[j];
         gv[S::R_SOC_LO + j] = -xs[j];
+        dsig[j] = x.scan(on ? fma(C[S::T_BC + j], dpc[j], -C[S::T_BD + j] * dd[j]) : 0.0);
       }
       ANM_UFOR (int b = 0; b < NB1; ++b) {
         double a = 0.0;
@@ -625,7 +705,7 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         double al = 0.0;
         ANM_UFOR (int c = 0; c < NC; ++c) al = fma(C[S::T_PHC + e * NC + c], du[c], al);
         const double rt = -gt[e], ih = ln.htt[e];
-        const double w1 = ln.w[S::R_FL1 + e], w2 = ln.w[S::R_FL2 + e], w3 = ln.w[S::R_FL3 + e] + rho;
+        const double w1 = ln.w[S::R_FL1 + e], w2 = ln.w[S::R_FL2 + e], w3 = ln.w[S::R_FL3 + e];
         dt[e] = fma(rt, ih, -ln.hut[e] * al);
         // al - dt and -al - dt without the cancellation when one weight dominates
         gv[S::R_FL1 + e] = (al * (2.0 * w2 + w3) - rt) * ih;
@@ -647,6 +727,10 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       ds[r] = -ln.rp[r] - gv[r];
       dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
     }
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      ds[S::R_SOC_UP + j] = -ln.rp[S::R_SOC_UP + j] - dsig[j];
+      ds[S::R_SOC_LO + j] = -ln.rp[S::R_SOC_LO + j] + dsig[j];
+    }
     double ap = fmin(1.0, x.min(on ? max_step(ln.s, ds) : 1e300));
     double ad = fmin(1.0, x.min(on ? max_step(ln.z, dz) : 1e300));
     double a_aff = 0.0;
@@ -666,8 +750,30 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       ds[r] = -ln.rp[r] - gv[r];
       dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
     }
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      ds[S::R_SOC_UP + j] = -ln.rp[S::R_SOC_UP + j] - dsig[j];
+      ds[S::R_SOC_LO + j] = -ln.rp[S::R_SOC_LO + j] + dsig[j];
+    }
     ap = fmin(1.0, 0.995 * x.min(on ? max_step(ln.s, ds) : 1e300));
     ad = fmin(1.0, 0.995 * x.min(on ? max_step(ln.z, dz) : 1e300));
+#if defined(ANM_MPC_DEBUG) && !defined(__HIPCC__)
+    {  // residual of the Newton system just solved: gradient of the Lagrangian at the multipliers z + dz (full step)
+      double zf[NR], g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
+      for (int r = 0; r < NR; ++r) zf[r] = fma(ln.w[r], gv[r], zh[r]);
+      ln.gradient(C, zf, false, g_in, g_st, gt);
+      double worst = 0.0;
+      for (int j = 0; j < NS; ++j) {
+        const double lam = x.sum(g_st[j]) - x.scan(g_st[j]) + g_st[j];
+        g_in[NG + j] += C[S::T_BC + j] * lam;
+        g_in[NG + NS + j] -= C[S::T_BD + j] * lam;
+      }
+      for (int a = 0; a < NA; ++a) worst = fmax(worst, fabs(g_in[a]));
+      double wm = 0.0;
+      for (int r = 0; r < NR; ++r) wm = fmax(wm, ln.w[r]);
+      const double res = x.max(worst), wmx = x.max(wm);
+      if (i == 0) printf("it %d mu %.2e rd %.2e newton residual %.2e wmax %.1e M %.2e P %.2e ap %.3f ad %.3f\n", it, n_mu, n_rd, res, wmx, ln.Mm[0], ln.Pm[0], ap, ad);
+    }
+#endif
     if (!done) {
       ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = fma(ap, dxi[g], ln.xi[g]);
       ANM_UFOR (int j = 0; j < NS; ++j) { ln.pc[j] = fma(ap, dpc[j], ln.pc[j]); ln.d[j] = fma(ap, dd[j], ln.d[j]); }

@@ -279,8 +279,8 @@ typedef struct anm_mpc_dims {
 } anm_mpc_dims;
 
 typedef struct anm_mpc_opts {
-  double tol;        /* stop when the complementarity gap per row mu <= tol (1 + |objective|) and the row
-                        residuals are <= 1e-9; 0 = default 1e-11 */
+  double tol;        /* stop when the complementarity gap per row mu <= tol (1 + |objective|) and the row residuals
+                        are <= 1e-9; 0 = default 1e-11.  info[., 2] reports the dual residual reached */
   int32_t max_iter;  /* interior-point iterations; 0 = default 40 */
 } anm_mpc_opts;
 
@@ -293,7 +293,7 @@ int anm_mpc_get_tables(const anm_mpc* m, double* out /* [table_doubles] host */)
 /* p_load_forecast [num_envs, N, n_load], p_gen_forecast [num_envs, N, n_gen] (mpc.py:348-372: forecast(), here
  * stage-major), soc [num_envs, n_des] (mpc.py:417).  Out: u0 [num_envs, n_ctrl] the first-stage P_gen / P_des
  * (mpc.py:383-388, before the scaling to MW), objective [num_envs] (the value of the reference's program),
- * iters [num_envs], info [num_envs, 2] (final mu, largest row residual; may be NULL), solution
+ * iters [num_envs], info [num_envs, 3] (final mu, largest row residual, largest dual residual; may be NULL), solution
  * [num_envs, N, n_stage_vars] (may be NULL).  All dev.  An environment whose solve does not reach the tolerance
  * within max_iter reports iters = max_iter (not an error, like a non-"optimal" status in the reference, :377-379). */
 int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,

@@ -12,17 +12,14 @@ minimiser is optimal here too.  What is NOT pinned: cvxpy's default solver (abse
 reference's program was solved by HiGHS behind oracle/ref_harness.py's stand-in for cvxpy's modelling API).
 An LP's optimal value does not depend on the solver; its minimiser may, where it is not unique.
 
-Only tests/ import this module.
+Only tests/ (and scripts/ used for development) import this module.
 """
 import numpy as np
 from scipy.optimize import linprog
 
 
-def solve_dcopf(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N, first_stage_p_dev=None):
-    """net: anm_oracle.Net.  Forecasts [n_load, N] / [n_gen, N] in p.u. (device-id order), soc0 [n_des] p.u.
-    first_stage_p_dev [D]: additionally fix the first stage's device injections (to test whether a given
-    minimiser of somebody else's statement of the program is optimal for this one).
-    Returns dict(objective, P_dev [N, D], theta [N, nb], status)."""
+def build_lp(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N):
+    """The program as scipy ``linprog`` arguments: dict(c, A_ub, b_ub, A_eq, b_eq, lb, ub, per, PD, TH)."""
     nb, D, nbr = net.N, net.D, net.B
     loads, gens, des = list(net.loads), list(net.gens), list(net.des)
     ns = len(des)
@@ -98,11 +95,44 @@ def solve_dcopf(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin
                 r[o + TH + f], r[o + TH + t], r[o + S + e] = sgn * B[f, t], -sgn * B[f, t], -1.0
                 A_ub.append(r)
                 b_ub.append(lim)
+    return dict(c=c, A_ub=np.array(A_ub), b_ub=np.array(b_ub), A_eq=np.array(A_eq), b_eq=np.array(b_eq), lb=lb, ub=ub,
+                per=per, PD=PD, TH=TH, n=n, D=D, nb=nb)
+
+
+def solve_dcopf(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N, first_stage_p_dev=None):
+    """net: anm_oracle.Net.  Forecasts [n_load, N] / [n_gen, N] in p.u. (device-id order), soc0 [n_des] p.u.
+    first_stage_p_dev [D]: additionally fix the first stage's device injections (to test whether a given
+    minimiser of somebody else's statement of the program is optimal for this one).
+    Returns dict(objective, P_dev [N, D], theta [N, nb], status)."""
+    lp = build_lp(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N)
+    lb, ub, PD, D, per, TH, nb, n = lp["lb"].copy(), lp["ub"].copy(), lp["PD"], lp["D"], lp["per"], lp["TH"], lp["nb"], lp["n"]
     if first_stage_p_dev is not None:
         for k in range(D):
             lb[PD + k] = ub[PD + k] = first_stage_p_dev[k]
-    res = linprog(c, A_ub=np.array(A_ub), b_ub=np.array(b_ub), A_eq=np.array(A_eq), b_eq=np.array(b_eq),
+    res = linprog(lp["c"], A_ub=lp["A_ub"], b_ub=lp["b_ub"], A_eq=lp["A_eq"], b_eq=lp["b_eq"],
                   bounds=list(zip(lb, ub)), method="highs")
     x = res.x if res.x is not None else np.full(n, np.nan)
     X = x.reshape(N, per)
     return dict(objective=res.fun, status=res.status, P_dev=X[:, PD : PD + D], theta=X[:, TH : TH + nb], x=x)
+
+
+def first_stage_range(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N, devices, slack=1e-9):
+    """Over the set of minimisers: (lowest, highest) first-stage injection of each device in ``devices``
+    (two more linear programs per device, on the optimal face  c.x <= optimum + slack (1 + |optimum|)).
+    A device whose two values coincide has a UNIQUE optimal first-stage set-point: there, and only there, two exact
+    solvers must agree on the action."""
+    lp = build_lp(net, P_load_forecast, P_gen_forecast, soc0, gamma, safety_margin, N)
+    bounds = list(zip(lp["lb"], lp["ub"]))
+    res = linprog(lp["c"], A_ub=lp["A_ub"], b_ub=lp["b_ub"], A_eq=lp["A_eq"], b_eq=lp["b_eq"], bounds=bounds, method="highs")
+    assert res.status == 0
+    A_ub = np.vstack((lp["A_ub"], lp["c"][None, :]))
+    b_ub = np.append(lp["b_ub"], res.fun + slack * (1 + abs(res.fun)))
+    out = []
+    for k in devices:
+        e = np.zeros(lp["n"])
+        e[lp["PD"] + k] = 1.0
+        lo = linprog(e, A_ub=A_ub, b_ub=b_ub, A_eq=lp["A_eq"], b_eq=lp["b_eq"], bounds=bounds, method="highs")
+        hi = linprog(-e, A_ub=A_ub, b_ub=b_ub, A_eq=lp["A_eq"], b_eq=lp["b_eq"], bounds=bounds, method="highs")
+        assert lo.status == 0 and hi.status == 0
+        out.append((lo.fun, -hi.fun))
+    return res.fun, out

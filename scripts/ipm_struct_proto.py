@@ -101,7 +101,7 @@ def ipm_struct(red, pl, pg, soc0, tol=1e-9, max_iter=40, verbose=False, n_ref=0)
         if verbose:
             print(it, "mu %.2e rp %.2e rd %.2e obj %.10f" % (mu, rpmax, rdmax, obj))
         final = False
-        if mu < tol * (1 + abs(obj)) and rpmax < 1e-9:
+        if mu < tol * (1 + abs(obj)) and rpmax < 1e-9 and rdmax < float(os.environ.get('RDTOL', '1e30')) * (1 + ct.max()):
             break
         # ---- factorisation (once per iteration) ----
         Hu = np.einsum("nb,bi,bj->nij", W["th"][0] + W["th"][1], Thc, Thc) + np.einsum("ne,ei,ej->nij", hat, Phc, Phc)
@@ -115,8 +115,12 @@ def ipm_struct(red, pl, pg, soc0, tol=1e-9, max_iter=40, verbose=False, n_ref=0)
             R[:, ng + ns + j, ng + ns + j] += W["pcd"][1][:, j]
         RHO_REL = float(os.environ.get("RHO", "0"))
         if RHO_REL > 0:
-            wm = max(x.max() for k in W for x in W[k])
-            R = R + (RHO_REL * wm + 1e-12) * np.eye(na)[None]
+            if os.environ.get("LOCALRHO"):
+                dmax = np.max(np.diagonal(R, axis1=1, axis2=2), axis=1)
+                R = R + (RHO_REL * dmax + 1e-14)[:, None, None] * np.eye(na)[None]
+            else:
+                wm = max(x.max() for k in W for x in W[k])
+                R = R + (RHO_REL * wm + 1e-12) * np.eye(na)[None]
         Lc = np.linalg.cholesky(R)
         Rinv = lambda X: np.linalg.solve(Lc.transpose(0, 2, 1), np.linalg.solve(Lc, X))  # noqa: E731
         RiBt = Rinv(np.tile(Bm.T[None], (N, 1, 1)))          # [N, na, ns]
@@ -214,6 +218,7 @@ def ipm_struct(red, pl, pg, soc0, tol=1e-9, max_iter=40, verbose=False, n_ref=0)
     p_dev0 = np.zeros(red.n_dev)
     p_dev0[red.loads], p_dev0[red.gens], p_dev0[red.des] = pl[:, 0], u[0, :ng], u[0, ng:]
     p_dev0[red.slack_dev] = red.sg_l @ pl[:, 0] + red.sg_c @ u[0]
+    ipm_struct.last = dict(mu=mu, rp=rpmax, rd=rdmax)
     return obj, p_dev0, it
 
 

@@ -1,19 +1,60 @@
-"""Batched MPC DC-OPF policy on ANM6Easy: time per act() (all environments together) and closed-loop return."""
-import os, sys, time
+"""Batched MPC DC-OPF policy on ANM6Easy: time of one solve of all environments (one launch of k_mpc: HIP events on the
+launch stream and wall clock around act()), interior-point iterations, closed-loop return.
+
+    python scripts/mpc_bench.py [--quick]
+"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
+from gym_anm_amd.agents import MPCAgentConstant, MPCAgentPerfect
 from gym_anm_amd.envs import ANM6EasyVec
-from gym_anm_amd.agents import MPCAgentPerfect, MPCAgentConstant
+
 DEV = "cuda:0"
-for Agent, N, E in ((MPCAgentConstant, 1, 4096), (MPCAgentPerfect, 4, 4096), (MPCAgentPerfect, 8, 1024), (MPCAgentConstant, 1, 65536)):
-    env = ANM6EasyVec(num_envs=E, device=DEV, seed=3); env.reset(seed=3)
-    ag = Agent(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=N, eps=1e-4, max_iter=4000)
-    tot = torch.zeros(E, dtype=torch.float64, device=DEV); its = []; ts = []
-    for s in range(6):
-        torch.cuda.synchronize(); t = time.perf_counter()
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+CASES = [(MPCAgentConstant, 1, 65536), (MPCAgentPerfect, 1, 65536), (MPCAgentPerfect, 4, 65536), (MPCAgentPerfect, 10, 65536),
+         (MPCAgentConstant, 20, 65536), (MPCAgentPerfect, 10, 4096), (MPCAgentPerfect, 64, 16384)]
+if "--quick" in sys.argv:
+    CASES = CASES[:4]
+for Agent, N, E in CASES:
+    env = ANM6EasyVec(num_envs=E, device=DEV, seed=3)
+    env.reset(seed=3)
+    ag = Agent(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=N)
+    tot = torch.zeros(E, dtype=torch.float64, device=DEV)
+    wall, kern, its = [], [], []
+    for s in range(8):
+        pl, pg = ag.forecast(env)
+        soc = ag._soc(env)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        ag.solver.solve(pl, pg, soc)      # (layout change of the forecasts + the launch)
+        e1.record()
+        torch.cuda.synchronize()
+        kern.append(e0.elapsed_time(e1))
+        torch.cuda.synchronize()
+        t = time.perf_counter()
         a = ag.act(env)
-        torch.cuda.synchronize(); ts.append(time.perf_counter() - t); its.append(ag.last_info["iters"])
-        _, r, term, _, _ = env.step(a); tot += r
-    pr = ag.program
-    print("%-17s N=%d E=%6d  LP %dx%d  act() %.3f s (%d ADMM iterations, %.1f us/iteration)  return/step %.3f  terminated %d"
-          % (Agent.__name__, N, E, pr.m, pr.n, ts[-1], its[-1], 1e6 * ts[-1] / its[-1], float(tot.mean()) / 6, int(env.terminated.sum())), flush=True)
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t)
+        its.append(ag.solver.iters.double())
+        bad = ~ag.last_converged
+        if bool(bad.any()) and not os.path.exists(os.path.join(OUT, "mpc_unconverged_N%d.npz" % N)):
+            import numpy as np
+
+            os.makedirs(OUT, exist_ok=True)
+            np.savez(os.path.join(OUT, "mpc_unconverged_N%d.npz" % N), pl=pl[bad].cpu().numpy(), pg=pg[bad].cpu().numpy(),
+                     soc=soc[bad].cpu().numpy(), iters=ag.solver.iters[bad].cpu().numpy(), info=ag.solver.info[bad].cpu().numpy(),
+                     objective=ag.solver.objective[bad].cpu().numpy())
+            print("  %d environments did not converge (step %d): dumped" % (int(bad.sum()), s), flush=True)
+        _, r, term, _, _ = env.step(a)
+        tot += r
+    it = torch.stack(its[2:])
+    d = ag.solver.dims
+    print("%-17s N=%2d E=%6d  %d rows x %d variables per stage  solve %.3f ms (events)  act() %.3f ms (wall)  iterations mean %.1f max %d"
+          "  %.2e programs/s  return/step %.3f  terminated %d"
+          % (Agent.__name__, N, E, d.n_stage_rows, d.n_stage_vars, min(kern[2:]), 1e3 * min(wall[2:]), float(it.mean()), int(it.max()),
+             E / (1e-3 * min(kern[2:])), float(tot.mean()) / 8, int(env.terminated.sum())), flush=True)
