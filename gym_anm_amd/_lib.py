@@ -57,7 +57,7 @@ class MpcDims(C.Structure):
 
 
 class MpcOpts(C.Structure):
-    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32)]
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("trace", C.c_void_p)]
 
 
 class SolverOpts(C.Structure):

@@ -152,7 +152,8 @@ class BatchedDCOPF:
     ``[P_gen.., P_des..]`` (p.u.); ``objective``, ``iters``, ``info`` (final complementarity, row residual, dual residual) and, on
     request, the whole primal solution stay available as tensors."""
 
-    def __init__(self, simulator, gamma, safety_margin, planning_steps, tol=None, max_iter=None, keep_solution=False):
+    def __init__(self, simulator, gamma, safety_margin, planning_steps, tol=None, max_iter=None, keep_solution=False,
+                 keep_trace=False):
         from .. import _lib
 
         self.backend, self.device = simulator.backend, simulator.device
@@ -170,7 +171,7 @@ class BatchedDCOPF:
         self.dims = d
         self.opts = _lib.MpcOpts(tol=0.0 if tol is None else float(tol), max_iter=0 if max_iter is None else int(max_iter))
         self.max_iter = 40 if max_iter is None else int(max_iter)
-        self.keep_solution = keep_solution
+        self.keep_solution, self.keep_trace = keep_solution, keep_trace
         self._E = None
 
     def tables(self):
@@ -188,6 +189,8 @@ class BatchedDCOPF:
             self.iters = torch.zeros(E, dtype=torch.int32, device=self.device)
             self.info = torch.zeros((E, 3), **f)
             self.solution = torch.zeros((E, self.N, d.n_stage_vars), **f) if self.keep_solution else None
+            self.trace = torch.full((E, self.max_iter + 1, 12), float("nan"), **f) if self.keep_trace else None
+            self.opts.trace = None if self.trace is None else self.trace.data_ptr()
             self._E = E
 
     def solve(self, P_load_forecast, P_gen_forecast, soc):

@@ -971,7 +971,7 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
     if (opts->tol > 0.0) o.tol = opts->tol;
     if (opts->max_iter > 0) o.max_iter = opts->max_iter;
   }
-  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution};
+  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, opts ? opts->trace : nullptr};
   int G = 1;
   while (G < m->N) G *= 2;
   const int per_wave = 64 / G;

@@ -84,6 +84,9 @@ struct IO {
   int32_t* iters;        // [E]
   double* info;          // [E][3]     final mu, largest row residual, largest dual residual   (may be null)
   double* solution;      // [E][N][NV] P_g, p_c, d, t per stage         (may be null)
+  double* trace;         // [E][max_iter + 1][12] per iteration: mu, row residual, dual residual, objective, then (of the
+                         //   step taken from there) primal and dual step length, centring, mu of the predictor, and the row
+                         //   that limits the primal step: stage, row, its slack and slack step   (may be null)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -239,8 +242,12 @@ struct Lane {
   // per iteration
   double rp[NR], w[NR], cross[NR];                  // row residuals, z/s, ds*dz of the predictor
   double htt[pos(NBR)], hut[pos(NBR)];
-  double Lc[pos(NA * (NA + 1) / 2)];                      // Cholesky factor of R (row-major lower triangle)
-  double RiBt[pos(NA * NS)], Mm[pos(NS * NS)], Pm[pos(NS * NS)], Ki[pos(NS * NS)], Po[pos(NS * NS)];  // R^-1 B', B R^-1 B', P, (I + M P)^-1, P (I + M P)^-1
+  // factor of the stage: Lc = lower Cholesky factor (row-major triangle, diagonal stored inverted) of
+  //   [R_xx R_xs; R_sx R_ss + Bs' P Bs]   over (xi.., p_c.., d..): the xi columns are local (factor_stage, every lane
+  //   at once), the (p_c, d) block needs the P of the stage (factor_coupled, last stage first);
+  // Ts = R_ss - L_sx L_sx' (what the xi columns leave of the (p_c, d) block), Wm = L_ss^-1 Bs' P
+  double Lc[pos(NA * (NA + 1) / 2)];
+  double Ts[pos(NS * (2 * NS + 1))], Wm[pos(2 * NS * NS)], Pm[pos(NS * NS)], Po[pos(NS * NS)];
   double sig[pos(NS)];
 
   static ANM_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
@@ -369,106 +376,56 @@ struct Lane {
     ANM_UFOR (int a = 0; a < NA; ++a) dmax = fmax(dmax, R[tri(a, a)]);
     const double rho = fma(4e-16, dmax, 1e-14);
     ANM_UFOR (int a = 0; a < NA; ++a) R[tri(a, a)] += rho;
-    // Cholesky, the diagonal stored inverted
-    ANM_UFOR (int i = 0; i < NA; ++i)
-      ANM_UFOR (int j = 0; j <= i; ++j) {
-        double acc = R[tri(i, j)];
-        ANM_UFOR (int k = 0; k < j; ++k) acc = fma(-Lc[tri(i, k)], Lc[tri(j, k)], acc);
-        if (i == j) Lc[tri(i, i)] = 1.0 / sqrt(acc);
-        else Lc[tri(i, j)] = acc * Lc[tri(j, j)];
+    // the xi columns of the Cholesky factor (they do not depend on the other stages), and what they leave of the
+    // (p_c, d) block
+    ANM_UFOR (int jc = 0; jc < NG; ++jc)
+      ANM_UFOR (int ir = jc; ir < NA; ++ir) {
+        double acc = R[tri(ir, jc)];
+        ANM_UFOR (int k = 0; k < jc; ++k) acc = fma(-Lc[tri(ir, k)], Lc[tri(jc, k)], acc);
+        if (ir == jc) Lc[tri(jc, jc)] = 1.0 / sqrt(acc);
+        else Lc[tri(ir, jc)] = acc * Lc[tri(jc, jc)];
       }
-    ANM_UFOR (int j = 0; j < NS; ++j) {
-      double col[pos(NA)];
-      ANM_UFOR (int a = 0; a < NA; ++a) col[a] = 0.0;
-      col[NG + j] = C[S::T_BC + j];
-      col[NG + NS + j] = -C[S::T_BD + j];
-      chol_solve(col);
-      ANM_UFOR (int a = 0; a < NA; ++a) RiBt[a * NS + j] = col[a];
-    }
-    ANM_UFOR (int i = 0; i < NS; ++i)
-      ANM_UFOR (int j = 0; j < NS; ++j)
-        Mm[i * NS + j] = C[S::T_BC + i] * RiBt[(NG + i) * NS + j] - C[S::T_BD + i] * RiBt[(NG + NS + i) * NS + j];
-  }
-
-  ANM_HD void chol_solve(double (&x)[pos(NA)]) const {
-    ANM_UFOR (int i = 0; i < NA; ++i) {
-      double acc = x[i];
-      ANM_UFOR (int k = 0; k < i; ++k) acc = fma(-Lc[tri(i, k)], x[k], acc);
-      x[i] = acc * Lc[tri(i, i)];
-    }
-    ANM_UFOR (int i = NA - 1; i >= 0; --i) {
-      double acc = x[i];
-      ANM_UFOR (int k = i + 1; k < NA; ++k) acc = fma(-Lc[tri(k, i)], x[k], acc);
-      x[i] = acc * Lc[tri(i, i)];
-    }
-  }
-
-  // For the P of this stage:  Ki = (I + M P)^-1  and  Po = P (I + M P)^-1, through the symmetric form
-  //   P = L L',  S = I + L' M L (SPD, eigenvalues >= 1):   Ki = L^-T S^-1 L',   Po = L S^-1 L'
-  // (I + M P itself is neither symmetric nor well conditioned once a state-of-charge row is about to become active
-  // next to inputs nothing pins: an unpivoted elimination of it loses the dual residual)
-  ANM_HD void set_P(const double (&P)[pos(NS * NS)]) {
-    double L[pos(NS * NS)], Li[pos(NS * NS)], Sm[pos(NS * NS)], Ls[pos(NS * NS)], Lsi[pos(NS * NS)], Si[pos(NS * NS)];
-    ANM_UFOR (int k = 0; k < NS * NS; ++k) { Pm[k] = P[k]; L[k] = 0.0; Li[k] = 0.0; Ls[k] = 0.0; Lsi[k] = 0.0; }
-    chol_small(P, L);
-    tri_inv(L, Li);
-    // S = I + L' M L
-    double ML[pos(NS * NS)];
-    ANM_UFOR (int a = 0; a < NS; ++a)
-      ANM_UFOR (int b = 0; b < NS; ++b) {
-        double acc = 0.0;
-        ANM_UFOR (int c = b; c < NS; ++c) acc = fma(Mm[a * NS + c], L[c * NS + b], acc);
-        ML[a * NS + b] = acc;
-      }
-    ANM_UFOR (int a = 0; a < NS; ++a)
-      ANM_UFOR (int b = 0; b < NS; ++b) {
-        double acc = a == b ? 1.0 : 0.0;
-        ANM_UFOR (int c = a; c < NS; ++c) acc = fma(L[c * NS + a], ML[c * NS + b], acc);
-        Sm[a * NS + b] = acc;
-      }
-    chol_small(Sm, Ls);
-    tri_inv(Ls, Lsi);
-    ANM_UFOR (int a = 0; a < NS; ++a)
-      ANM_UFOR (int b = 0; b < NS; ++b) {  // S^-1 = Ls^-T Ls^-1
-        double acc = 0.0;
-        ANM_UFOR (int c = (a > b ? a : b); c < NS; ++c) acc = fma(Lsi[c * NS + a], Lsi[c * NS + b], acc);
-        Si[a * NS + b] = acc;
-      }
-    double SLt[pos(NS * NS)];  // S^-1 L'
-    ANM_UFOR (int a = 0; a < NS; ++a)
-      ANM_UFOR (int b = 0; b < NS; ++b) {
-        double acc = 0.0;
-        ANM_UFOR (int c = 0; c <= b; ++c) acc = fma(Si[a * NS + c], L[b * NS + c], acc);
-        SLt[a * NS + b] = acc;
-      }
-    ANM_UFOR (int a = 0; a < NS; ++a)
-      ANM_UFOR (int b = 0; b < NS; ++b) {
-        double k = 0.0, o = 0.0;
-        ANM_UFOR (int c = a; c < NS; ++c) k = fma(Li[c * NS + a], SLt[c * NS + b], k);   // L^-T (S^-1 L')
-        ANM_UFOR (int c = 0; c <= a; ++c) o = fma(L[a * NS + c], SLt[c * NS + b], o);    // L (S^-1 L')
-        Ki[a * NS + b] = k;
-        Po[a * NS + b] = o;
-      }
-  }
-
-  // lower Cholesky factor of a small SPD matrix (full storage); inverse of a lower triangular matrix
-  static ANM_HD void chol_small(const double (&A)[pos(NS * NS)], double (&L)[pos(NS * NS)]) {
-    ANM_UFOR (int a = 0; a < NS; ++a)
+    ANM_UFOR (int a = 0; a < 2 * NS; ++a)
       ANM_UFOR (int b = 0; b <= a; ++b) {
-        double acc = A[a * NS + b];
-        ANM_UFOR (int c = 0; c < b; ++c) acc = fma(-L[a * NS + c], L[b * NS + c], acc);
-        L[a * NS + b] = a == b ? sqrt(acc) : acc / L[b * NS + b];
+        double acc = R[tri(NG + a, NG + b)];
+        ANM_UFOR (int k = 0; k < NG; ++k) acc = fma(-Lc[tri(NG + a, k)], Lc[tri(NG + b, k)], acc);
+        Ts[tri(a, b)] = acc;
       }
   }
-  static ANM_HD void tri_inv(const double (&L)[pos(NS * NS)], double (&Li)[pos(NS * NS)]) {
-    ANM_UFOR (int b = 0; b < NS; ++b) {
-      Li[b * NS + b] = 1.0 / L[b * NS + b];
-      ANM_UFOR (int a = b + 1; a < NS; ++a) {
-        double acc = 0.0;
-        ANM_UFOR (int c = b; c < a; ++c) acc = fma(L[a * NS + c], Li[c * NS + b], acc);
-        Li[a * NS + b] = -acc / L[a * NS + a];
+
+  // coefficient of input s (0..NS-1: p_c, NS..2NS-1: d) in the state equation of its storage unit
+  static ANM_HD double bcoef(cptr_t C, int a) { return a < NS ? C[S::T_BC + a] : -C[S::T_BD + a - NS]; }
+
+  // The coupled part of the factor, for the value function  V(x) = 1/2 x' P x  of the state AFTER this stage:
+  //   Lam = Ts + Bs' P Bs = L_ss L_ss',   Wm = L_ss^-1 Bs' P,   Po = P - Wm' Wm
+  // (one block step of the Cholesky factorisation of the whole Newton matrix, states eliminated, last stage first:
+  // every quantity is a sum of positive terms or what a Cholesky step subtracts -- nothing is inverted on its own,
+  // so the weights of the rows may span the whole double range, like in a dense factorisation)
+  ANM_HD void factor_coupled(cptr_t C, const double (&P)[pos(NS * NS)]) {
+    ANM_UFOR (int k = 0; k < NS * NS; ++k) Pm[k] = P[k];
+    double cm[pos(2 * NS * NS)];  // Bs' P
+    ANM_UFOR (int a = 0; a < 2 * NS; ++a)
+      ANM_UFOR (int q = 0; q < NS; ++q) cm[a * NS + q] = bcoef(C, a) * P[(a % NS) * NS + q];
+    ANM_UFOR (int a = 0; a < 2 * NS; ++a)
+      ANM_UFOR (int b = 0; b <= a; ++b) {
+        double acc = fma(cm[a * NS + (b % NS)], bcoef(C, b), Ts[tri(a, b)]);
+        ANM_UFOR (int k = 0; k < b; ++k) acc = fma(-Lc[tri(NG + a, NG + k)], Lc[tri(NG + b, NG + k)], acc);
+        if (a == b) Lc[tri(NG + a, NG + a)] = 1.0 / sqrt(acc);
+        else Lc[tri(NG + a, NG + b)] = acc * Lc[tri(NG + b, NG + b)];
       }
-    }
+    ANM_UFOR (int q = 0; q < NS; ++q)
+      ANM_UFOR (int a = 0; a < 2 * NS; ++a) {
+        double acc = cm[a * NS + q];
+        ANM_UFOR (int k = 0; k < a; ++k) acc = fma(-Lc[tri(NG + a, NG + k)], Wm[k * NS + q], acc);
+        Wm[a * NS + q] = acc * Lc[tri(NG + a, NG + a)];
+      }
+    ANM_UFOR (int q = 0; q < NS; ++q)
+      ANM_UFOR (int r = 0; r < NS; ++r) {
+        double acc = P[q * NS + r];
+        ANM_UFOR (int a = 0; a < 2 * NS; ++a) acc = fma(-Wm[a * NS + q], Wm[a * NS + r], acc);
+        Po[q * NS + r] = acc;
+      }
+    ANM_UFOR (int q = 0; q < NS; ++q) Po[q * NS + q] = fmax(Po[q * NS + q], 0.0);
   }
 };
 
@@ -481,7 +438,9 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
   const int i = x.stage();
   const bool on = valid && i < N;  // a lane without a stage runs along with neutral contributions
   L ln;
-  ANM_UFOR (int k = 0; k < pos(NS * NS); ++k) { ln.Pm[k] = 0.0; ln.Ki[k] = 0.0; ln.Mm[k] = 0.0; ln.Po[k] = 0.0; }
+  ANM_UFOR (int k = 0; k < pos(NS * NS); ++k) { ln.Pm[k] = 0.0; ln.Po[k] = 0.0; }
+  ANM_UFOR (int k = 0; k < pos(2 * NS * NS); ++k) ln.Wm[k] = 0.0;
+  ANM_UFOR (int k = 0; k < pos(NA * (NA + 1) / 2); ++k) ln.Lc[k] = 0.0;
   // ---- constants of the stage ----
   ln.wgt = C[S::T_WGT + (i < 64 ? i : 63)];
   ln.ct = ln.wgt * C[S::T_LAMB];
@@ -592,17 +551,22 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         ANM_UFOR (int e = 0; e < NBR; ++e) o[NA + e] = ln.t[e];
       }
     }
+    double* trg = (io.trace && on && !done && it <= opt.max_iter) ? io.trace + (env * (opt.max_iter + 1) + it) * 12 : nullptr;
+    double* tr = i == 0 ? trg : nullptr;
+    if (tr) { tr[0] = n_mu; tr[1] = n_rp; tr[2] = n_rd; tr[3] = n_obj; }
     if (x.all_done(done)) break;
     // ---- factor (once per iteration) ----
     ln.factor_stage(C);
-    {  // Riccati sweep, last stage first:  P_i = Q_i + P'_{i+1},  P'_i = P_i (I + M_i P_i)^-1
+    {  // value functions, last stage first:  P_i = Q_i + P'_{i+1}  (Q: the weights of the window rows)
       double Pn[pos(NS * NS)];
       ANM_UFOR (int k = 0; k < NS * NS; ++k) Pn[k] = 0.0;
       for (int k = N - 1; k >= 0; --k) {
-        double P[pos(NS * NS)];
-        ANM_UFOR (int a = 0; a < NS; ++a)
-          ANM_UFOR (int b = 0; b < NS; ++b) P[a * NS + b] = Pn[a * NS + b] + (a == b ? ln.w[S::R_SOC_UP + a] + ln.w[S::R_SOC_LO + a] : 0.0);
-        if (i == k) ln.set_P(P);
+        if (i == k) {
+          double P[pos(NS * NS)];
+          ANM_UFOR (int a = 0; a < NS; ++a)
+            ANM_UFOR (int b = 0; b < NS; ++b) P[a * NS + b] = Pn[a * NS + b] + (a == b ? ln.w[S::R_SOC_UP + a] + ln.w[S::R_SOC_LO + a] : 0.0);
+          ln.factor_coupled(C, P);
+        }
         ANM_UFOR (int q = 0; q < NS * NS; ++q) {
           const double got = x.down(i == k ? ln.Po[q] : 0.0);  // stage k - 1 receives P'_k
           if (i == k - 1) Pn[q] = got;
@@ -610,71 +574,80 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       }
     }
     // ---- Newton step for multipliers zh ----
-    double dxi[pos(NG)], dpc[pos(NS)], dd[pos(NS)], dt[pos(NBR)], gv[NR], dsig[pos(NS)];
+    double dxi[pos(NG)], dpc[pos(NS)], dd[pos(NS)], dt[pos(NBR)], gv[NR];
     auto newton = [&](const double (&zh)[NR]) {
       double g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
       ln.gradient(C, zh, true, g_in, g_st, gt);
+      // Residual form.  The multipliers of the window rows of this and the later stages act on the inputs of this
+      // stage through B: lam_i = sum_{k >= i} g_st_k is the costate the multipliers THEMSELVES imply.  With it
+      // folded into the input gradient (g_in + B' lam: the dual residual, small near the solution) the sweep
+      // only has to find the CORRECTION of the costate.  Sweeping on g_in alone means R^-1 g_in -- huge along
+      // directions no row pins, where the gradient is balanced by the costate (charging now against the value of
+      // the stored energy later) -- and a state step that is the small difference of two such terms.
+      ANM_UFOR (int j = 0; j < NS; ++j) {
+        const double mine = on ? g_st[j] : 0.0;
+        g_st[j] = x.sum(mine) - x.scan(mine) + mine;   // lam_i
+        g_in[NG + j] = fma(C[S::T_BC + j], g_st[j], g_in[NG + j]);
+        g_in[NG + NS + j] = fma(-C[S::T_BD + j], g_st[j], g_in[NG + NS + j]);
+      }
+      // forward substitution: the xi part at once, the (p_c, d) part stage by stage (last first), each stage
+      // handing the linear term of its value function down:  y_s = L_ss^-1 (g_s - L_sx y_x + Bs' p),  p' = p - Wm' y_s
       double y[pos(NA)];
-      ANM_UFOR (int a = 0; a < NA; ++a) y[a] = g_in[a];
-      ln.chol_solve(y);
-      double mv[pos(NS)];
-      ANM_UFOR (int j = 0; j < NS; ++j) mv[j] = fma(C[S::T_BC + j], y[NG + j], -C[S::T_BD + j] * y[NG + NS + j]);
-      // backward: p_i = g_st_i + p'_{i+1},  p'_i = (I + P M)^-1 (p_i - P m_i)
+      ANM_UFOR (int a = 0; a < NA; ++a) {
+        double acc = g_in[a];
+        ANM_UFOR (int k = 0; k < (a < NG ? a : NG); ++k) acc = fma(-ln.Lc[L::tri(a, k)], y[k], acc);
+        y[a] = a < NG ? acc * ln.Lc[L::tri(a, a)] : acc;
+      }
       double p[pos(NS)], pn[pos(NS)];
       ANM_UFOR (int j = 0; j < NS; ++j) { p[j] = 0.0; pn[j] = 0.0; }
       for (int k = N - 1; k >= 0; --k) {
         double out[pos(NS)];
-        if (i == k)
-          ANM_UFOR (int j = 0; j < NS; ++j) p[j] = g_st[j] + pn[j];
-        double tmp[pos(NS)];
-        ANM_UFOR (int a = 0; a < NS; ++a) {
-          double acc = p[a];
-          ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(-ln.Pm[a * NS + b], mv[b], acc);
-          tmp[a] = acc;
-        }
-        ANM_UFOR (int a = 0; a < NS; ++a) {  // Ki' tmp  ((I + P M)^-1 = ((I + M P)^-1)')
-          double acc = 0.0;
-          ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(ln.Ki[b * NS + a], tmp[b], acc);
-          out[a] = acc;
+        ANM_UFOR (int j = 0; j < NS; ++j) out[j] = 0.0;
+        if (i == k) {
+          ANM_UFOR (int j = 0; j < NS; ++j) p[j] = pn[j];   // (residual form: the g_st of the stages are in lam)
+          ANM_UFOR (int a = 0; a < 2 * NS; ++a) {
+            double acc = fma(L::bcoef(C, a), p[a % NS], y[NG + a]);
+            ANM_UFOR (int kk = 0; kk < a; ++kk) acc = fma(-ln.Lc[L::tri(NG + a, NG + kk)], y[NG + kk], acc);
+            y[NG + a] = acc * ln.Lc[L::tri(NG + a, NG + a)];
+          }
+          ANM_UFOR (int q = 0; q < NS; ++q) {
+            double acc = p[q];
+            ANM_UFOR (int a = 0; a < 2 * NS; ++a) acc = fma(-ln.Wm[a * NS + q], y[NG + a], acc);
+            out[q] = acc;
+          }
         }
         ANM_UFOR (int j = 0; j < NS; ++j) {
           const double got = x.down(i == k ? out[j] : 0.0);
           if (i == k - 1) pn[j] = got;
         }
       }
-      // forward: x_i = (I + M P)^-1 (x_{i-1} - m_i - M p_i)
-      double xs[pos(NS)], xp[pos(NS)];
+      // back substitution, first stage first:  a_s = -L_ss^-T (y_s + Wm x_{i-1}),  x_i = x_{i-1} + Bs a_s  -- the
+      // state step IS what the inputs add up to; then the xi part
+      double da[pos(NA)], xs[pos(NS)], xp[pos(NS)];
+      ANM_UFOR (int a = 0; a < NA; ++a) da[a] = 0.0;
       ANM_UFOR (int j = 0; j < NS; ++j) { xs[j] = 0.0; xp[j] = 0.0; }
       for (int k = 0; k < N; ++k) {
         if (i == k) {
-          double tmp[pos(NS)];
-          ANM_UFOR (int a = 0; a < NS; ++a) {
-            double acc = xp[a] - mv[a];
-            ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(-ln.Mm[a * NS + b], p[b], acc);
-            tmp[a] = acc;
+          ANM_UFOR (int a = 2 * NS - 1; a >= 0; --a) {
+            double acc = y[NG + a];
+            ANM_UFOR (int q = 0; q < NS; ++q) acc = fma(ln.Wm[a * NS + q], xp[q], acc);
+            acc = -acc * ln.Lc[L::tri(NG + a, NG + a)];
+            // (row a of L_ss' x = b:  x_a = (b_a - sum_{kk > a} L[kk][a] x_kk) / L[a][a], with b = -(y + W x))
+            ANM_UFOR (int kk = a + 1; kk < 2 * NS; ++kk) acc = fma(-ln.Lc[L::tri(NG + kk, NG + a)] * ln.Lc[L::tri(NG + a, NG + a)], da[NG + kk], acc);
+            da[NG + a] = acc;
           }
-          ANM_UFOR (int a = 0; a < NS; ++a) {
-            double acc = 0.0;
-            ANM_UFOR (int b = 0; b < NS; ++b) acc = fma(ln.Ki[a * NS + b], tmp[b], acc);
-            xs[a] = acc;
-          }
+          ANM_UFOR (int j = 0; j < NS; ++j) xs[j] = xp[j] + fma(C[S::T_BC + j], da[NG + j], -C[S::T_BD + j] * da[NG + NS + j]);
         }
         ANM_UFOR (int j = 0; j < NS; ++j) {
           const double got = x.up(i == k ? xs[j] : 0.0);
           if (i == k + 1) xp[j] = got;
         }
       }
-      // costate, then the inputs from  R da = -(g_in + B' co): the sum first, the solve after -- adding
-      // R^-1 g_in and R^-1 B' co instead would cancel AFTER both were amplified along the directions no row pins
-      double da[pos(NA)];
-      ANM_UFOR (int a = 0; a < NA; ++a) da[a] = -g_in[a];
-      ANM_UFOR (int j = 0; j < NS; ++j) {
-        double co = p[j];
-        ANM_UFOR (int b = 0; b < NS; ++b) co = fma(ln.Pm[j * NS + b], xs[b], co);
-        da[NG + j] = fma(-C[S::T_BC + j], co, da[NG + j]);
-        da[NG + NS + j] = fma(C[S::T_BD + j], co, da[NG + NS + j]);
+      ANM_UFOR (int a = NG - 1; a >= 0; --a) {
+        double acc = -y[a];
+        ANM_UFOR (int kk = a + 1; kk < NA; ++kk) acc = fma(-ln.Lc[L::tri(kk, a)], da[kk], acc);
+        da[a] = acc * ln.Lc[L::tri(a, a)];
       }
-      ln.chol_solve(da);
       ANM_UFOR (int g = 0; g < NG; ++g) dxi[g] = da[g];
       ANM_UFOR (int j = 0; j < NS; ++j) { dpc[j] = da[NG + j]; dd[j] = da[NG + NS + j]; }
       // g.dv of every row
@@ -687,13 +660,8 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         gv[S::R_PD_LO + j] = -du[NG + j];
         gv[S::R_PC + j] = -dpc[j];
         gv[S::R_D + j] = -dd[j];
-        // the sweep's state step for the multipliers (w * it is what balances the gradient: accurate to roundoff of
-        // the SWEEP), and the state step the inputs themselves produce for the slacks (the rows stay satisfied to
-        // roundoff); the two differ by what the recovery of the inputs loses, ~1e-10 when a window row is about
-        // to become active -- times the row's weight that would be the whole dual residual
         gv[S::R_SOC_UP + j] = xs[j];
         gv[S::R_SOC_LO + j] = -xs[j];
-        dsig[j] = x.scan(on ? fma(C[S::T_BC + j], dpc[j], -C[S::T_BD + j] * dd[j]) : 0.0);
       }
       ANM_UFOR (int b = 0; b < NB1; ++b) {
         double a = 0.0;
@@ -727,10 +695,6 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       ds[r] = -ln.rp[r] - gv[r];
       dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
     }
-    ANM_UFOR (int j = 0; j < NS; ++j) {
-      ds[S::R_SOC_UP + j] = -ln.rp[S::R_SOC_UP + j] - dsig[j];
-      ds[S::R_SOC_LO + j] = -ln.rp[S::R_SOC_LO + j] + dsig[j];
-    }
     double ap = fmin(1.0, x.min(on ? max_step(ln.s, ds) : 1e300));
     double ad = fmin(1.0, x.min(on ? max_step(ln.z, dz) : 1e300));
     double a_aff = 0.0;
@@ -750,12 +714,16 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       ds[r] = -ln.rp[r] - gv[r];
       dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
     }
-    ANM_UFOR (int j = 0; j < NS; ++j) {
-      ds[S::R_SOC_UP + j] = -ln.rp[S::R_SOC_UP + j] - dsig[j];
-      ds[S::R_SOC_LO + j] = -ln.rp[S::R_SOC_LO + j] + dsig[j];
-    }
-    ap = fmin(1.0, 0.995 * x.min(on ? max_step(ln.s, ds) : 1e300));
+    const double my_ap = on ? max_step(ln.s, ds) : 1e300;
+    const double grp_ap = x.min(my_ap);
+    ap = fmin(1.0, 0.995 * grp_ap);
     ad = fmin(1.0, 0.995 * x.min(on ? max_step(ln.z, dz) : 1e300));
+    if (trg && my_ap == grp_ap) {
+      int rb = -1;
+      ANM_UFOR (int r = 0; r < NR; ++r) rb = (ds[r] < 0.0 && -ln.s[r] / ds[r] == my_ap) ? r : rb;
+      trg[8] = double(i); trg[9] = double(rb);
+      ANM_UFOR (int r = 0; r < NR; ++r) if (r == rb) { trg[10] = ln.s[r]; trg[11] = ds[r]; }
+    }
 #if defined(ANM_MPC_DEBUG) && !defined(__HIPCC__)
     {  // residual of the Newton system just solved: gradient of the Lagrangian at the multipliers z + dz (full step)
       double zf[NR], g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
@@ -771,9 +739,10 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       double wm = 0.0;
       for (int r = 0; r < NR; ++r) wm = fmax(wm, ln.w[r]);
       const double res = x.max(worst), wmx = x.max(wm);
-      if (i == 0) printf("it %d mu %.2e rd %.2e newton residual %.2e wmax %.1e M %.2e P %.2e ap %.3f ad %.3f\n", it, n_mu, n_rd, res, wmx, ln.Mm[0], ln.Pm[0], ap, ad);
+      if (i == 0) printf("it %d mu %.2e rd %.2e newton residual %.2e wmax %.1e P %.2e ap %.3f ad %.3f\n", it, n_mu, n_rd, res, wmx, ln.Pm[0], ap, ad);
     }
 #endif
+    if (tr) { tr[4] = ap; tr[5] = ad; tr[6] = sg; tr[7] = mu_aff; }
     if (!done) {
       ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = fma(ap, dxi[g], ln.xi[g]);
       ANM_UFOR (int j = 0; j < NS; ++j) { ln.pc[j] = fma(ap, dpc[j], ln.pc[j]); ln.d[j] = fma(ap, dd[j], ln.d[j]); }

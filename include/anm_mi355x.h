@@ -280,8 +280,11 @@ typedef struct anm_mpc_dims {
 
 typedef struct anm_mpc_opts {
   double tol;        /* stop when the complementarity gap per row mu <= tol (1 + |objective|) and the row residuals
-                        are <= 1e-9; 0 = default 1e-11.  info[., 2] reports the dual residual reached */
+                        are <= 1e-9; 0 = default 1e-11 (values within ~1e-8 relative of the optimum).  info[., 2] reports the dual residual reached */
   int32_t max_iter;  /* interior-point iterations; 0 = default 40 */
+  double* trace;     /* NULL, or dev [num_envs, max_iter + 1, 12]: per iteration mu, row residual, dual residual, objective,
+                        then, of the step taken from there: primal / dual step length, centring parameter, predictor mu,
+                        and the row that limited the primal step (stage, row, its slack, its slack step) */
 } anm_mpc_opts;
 
 int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps,

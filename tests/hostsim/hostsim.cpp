@@ -235,7 +235,7 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
       if (opts->tol > 0.0) o.tol = opts->tol;
       if (opts->max_iter > 0) o.max_iter = opts->max_iter;
     }
-    mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution};
+    mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, opts ? opts->trace : nullptr};
     const int N = m->N;
     HostGroupShared sh(N);
     std::vector<std::thread> th;

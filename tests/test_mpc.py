@@ -369,8 +369,8 @@ def test_gpu_kernel_equals_the_host_build_of_the_same_solver():
         s = BatchedDCOPF(sim, float(g["gamma"]), float(g["safety_margin"][k]), int(g["N"][k]))
         s.solve(*args)
         out.append((s.objective.cpu().numpy(), s.iters.cpu().numpy()))
-    np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=1e-8)
-    assert np.abs(out[0][1] - out[1][1]).max() <= 2
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-8, atol=1e-8)
+    assert np.abs(out[0][1] - out[1][1]).max() <= 4
 
 
 @pytest.mark.gpu
