@@ -927,6 +927,15 @@ int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_mar
       return -3;
     }
     m->N = planning_steps;
+    if (size_t(2) * mpc::Sz<Topo>::NR * 64 * sizeof(double) > 64 * 1024) {
+      // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, here, not in a launch path)
+      hipError_t a1 = hipFuncSetAttribute((const void*)mpc::k_mpc<Topo, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipError_t a2 = hipFuncSetAttribute((const void*)mpc::k_mpc<Topo, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (a1 != hipSuccess || a2 != hipSuccess) {
+        delete m;
+        return fail_hip(a1 != hipSuccess ? a1 : a2, "anm_mpc_create: LDS size attribute");
+      }
+    }
     hipError_t e = hipMalloc(&m->d_tab, m->tab.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(m->d_tab, m->tab.data(), m->tab.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -977,10 +986,11 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
   const int per_wave = 64 / G;
   const unsigned grid = unsigned((num_envs + per_wave - 1) / per_wave);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds_bytes = size_t(2) * S::NR * 64 * sizeof(double);
   if (G == 1)
-    hipLaunchKernelGGL((mpc::k_mpc<Topo, true>), dim3(grid), dim3(64), 0, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+    hipLaunchKernelGGL((mpc::k_mpc<Topo, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
   else
-    hipLaunchKernelGGL((mpc::k_mpc<Topo, false>), dim3(grid), dim3(64), 0, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+    hipLaunchKernelGGL((mpc::k_mpc<Topo, false>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_mpc");
   return 0;

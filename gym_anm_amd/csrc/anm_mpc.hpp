@@ -69,8 +69,8 @@ struct Sz {
 };
 
 struct Opts {
-  double tol;        // stop: complementarity mu <= tol (1 + |objective|) and row residuals <= 1e-9 (the dual residual is
-                     // reported: a solve is to be trusted when it is small against the costs)
+  double tol;        // stop: complementarity mu <= tol (1 + |objective|) (the iterate satisfies every row throughout; the
+                     // dual residual is reported: a solve is to be trusted when it is small against the costs)
   int max_iter;
 };
 
@@ -82,11 +82,11 @@ struct IO {
   double* u0;            // [E][NC]    first-stage [P_gen.., P_des..], p.u.
   double* objective;     // [E]
   int32_t* iters;        // [E]
-  double* info;          // [E][3]     final mu, largest row residual, largest dual residual   (may be null)
+  double* info;          // [E][3]     final mu, 1 if the stage has no interior start (else 0), largest dual residual   (may be null)
   double* solution;      // [E][N][NV] P_g, p_c, d, t per stage         (may be null)
-  double* trace;         // [E][max_iter + 1][12] per iteration: mu, row residual, dual residual, objective, then (of the
+  double* trace;         // [E][max_iter + 1][12] per iteration: mu, 0, dual residual, objective, then (of the
                          //   step taken from there) primal and dual step length, centring, mu of the predictor, and the row
-                         //   that limits the primal step: stage, row, its slack and slack step   (may be null)
+                         //   that limits the primal step: stage, row, 0, 0   (may be null)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -234,23 +234,41 @@ struct Lane {
   typedef Sz<T> S;
   static constexpr int NG = S::NG, NS = S::NS, NL = S::NL, NB1 = S::NB1, NBR = S::NBR, NC = S::NC, NA = S::NA, NR = S::NR;
 
-  // variables of the stage and of its rows
+  // variables of the stage and of its rows: slack s, multiplier z, 1/s (of the iteration), ds*dz of the predictor.
+  // The iterate is kept strictly inside every row (the start is, the steps stay): s is then the row's true slack and
+  // moves with the inputs; nothing else has to be remembered per row.
   double xi[pos(NG)], pc[pos(NS)], d[pos(NS)], t[pos(NBR)];
   double s[NR], z[NR];
+  // 1/s and the predictor's ds*dz: on the GPU in LDS (row-major [row][lane] of the wavefront: conflict-free, and 4 NR
+  // registers less per lane -- with them the kernel needs more than the 512 a lane can have), registers on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (volatile: every use is a ds_read -- otherwise the compiler keeps what it has read in registers, which is what
+  // moving the arrays to LDS is meant to avoid)
+  volatile __attribute__((address_space(3))) double* lds;   // this lane's column of the wavefront's [2 NR][64] block
+  ANM_HD volatile __attribute__((address_space(3))) double& is(int r) { return lds[r * 64]; }
+  ANM_HD double is(int r) const { return lds[r * 64]; }
+  ANM_HD volatile __attribute__((address_space(3))) double& cross(int r) { return lds[(NR + r) * 64]; }
+  ANM_HD double cross(int r) const { return lds[(NR + r) * 64]; }
+#else
+  double is_[NR], cross_[NR];
+  ANM_HD double& is(int r) { return is_[r]; }
+  ANM_HD double is(int r) const { return is_[r]; }
+  ANM_HD double& cross(int r) { return cross_[r]; }
+  ANM_HD double cross(int r) const { return cross_[r]; }
+#endif
   // constants of the stage
   double wd[pos(NG)], th0[pos(NB1)], f0[pos(NBR)], wgt, ct, objc;
   // per iteration
-  double rp[NR], w[NR], cross[NR];                  // row residuals, z/s, ds*dz of the predictor
   double htt[pos(NBR)], hut[pos(NBR)];
   // factor of the stage: Lc = lower Cholesky factor (row-major triangle, diagonal stored inverted) of
   //   [R_xx R_xs; R_sx R_ss + Bs' P Bs]   over (xi.., p_c.., d..): the xi columns are local (factor_stage, every lane
   //   at once), the (p_c, d) block needs the P of the stage (factor_coupled, last stage first);
   // Ts = R_ss - L_sx L_sx' (what the xi columns leave of the (p_c, d) block), Wm = L_ss^-1 Bs' P
   double Lc[pos(NA * (NA + 1) / 2)];
-  double Ts[pos(NS * (2 * NS + 1))], Wm[pos(2 * NS * NS)], Pm[pos(NS * NS)], Po[pos(NS * NS)];
-  double sig[pos(NS)];
+  double Ts[pos(NS * (2 * NS + 1))], Wm[pos(2 * NS * NS)], Po[pos(NS * NS)];
 
   static ANM_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
+  ANM_HD double w(int r) const { return z[r] * is(r); }
 
   // u = [P_g.., P_des..]
   ANM_HD void phys(cptr_t C, double (&u)[pos(NC)]) const {
@@ -258,8 +276,8 @@ struct Lane {
     ANM_UFOR (int j = 0; j < NS; ++j) u[NG + j] = d[j] - pc[j];
   }
 
-  // g.v - h of every row
-  ANM_HD void row_values(cptr_t C, double (&val)[NR]) const {
+  // g.v - h of every row (sig: the states of charge after the stage)
+  ANM_HD void row_values(cptr_t C, const double (&sig)[pos(NS)], double (&val)[NR]) const {
     double u[pos(NC)];
     phys(C, u);
     ANM_UFOR (int g = 0; g < NG; ++g) {
@@ -301,48 +319,50 @@ struct Lane {
     return o;
   }
 
-  // gradient of the Lagrangian for multipliers zh: inputs (xi, p_c, d) and state; the epigraph variables'
-  // share folded into the flows (eliminate: right-hand sides of a Newton step), their own gradient in gt
-  ANM_HD void gradient(cptr_t C, const double (&zh)[NR], bool eliminate, double (&g_in)[pos(NA)], double (&g_st)[pos(NS)],
+  // gradient of the Lagrangian for multipliers zh(r): inputs (xi, p_c, d) and state; with `eliminate` the epigraph
+  // variables' share is folded into the flows (right-hand sides of a Newton step); their own gradient in gt
+  template <class ZH>
+  ANM_HD void gradient(cptr_t C, ZH&& zh, bool eliminate, double (&g_in)[pos(NA)], double (&g_st)[pos(NS)],
                        double (&gt)[pos(NBR)]) const {
     double gu[pos(NC)];
     ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = wgt * C[S::T_COST + c];
     ANM_UFOR (int b = 0; b < NB1; ++b) {
-      const double dz = zh[S::R_TH_UP + b] - zh[S::R_TH_LO + b];
+      const double dz = zh(S::R_TH_UP + b) - zh(S::R_TH_LO + b);
       ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = fma(dz, C[S::T_THC + b * NC + c], gu[c]);
     }
     ANM_UFOR (int e = 0; e < NBR; ++e) {
-      gt[e] = ct - zh[S::R_FL1 + e] - zh[S::R_FL2 + e] - zh[S::R_FL3 + e];
-      double ga = zh[S::R_FL1 + e] - zh[S::R_FL2 + e];
+      const double z1 = zh(S::R_FL1 + e), z2 = zh(S::R_FL2 + e);
+      gt[e] = ct - z1 - z2 - zh(S::R_FL3 + e);
+      double ga = z1 - z2;
       if (eliminate) ga = fma(-hut[e], gt[e], ga);
       ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = fma(ga, C[S::T_PHC + e * NC + c], gu[c]);
     }
-    ANM_UFOR (int j = 0; j < NS; ++j) gu[NG + j] += zh[S::R_PD_UP + j] - zh[S::R_PD_LO + j];
-    ANM_UFOR (int g = 0; g < NG; ++g) g_in[g] = fma(wd[g], gu[g], zh[S::R_XI_UP + g] - zh[S::R_XI_LO + g]);
+    ANM_UFOR (int j = 0; j < NS; ++j) gu[NG + j] += zh(S::R_PD_UP + j) - zh(S::R_PD_LO + j);
+    ANM_UFOR (int g = 0; g < NG; ++g) g_in[g] = fma(wd[g], gu[g], zh(S::R_XI_UP + g) - zh(S::R_XI_LO + g));
     ANM_UFOR (int j = 0; j < NS; ++j) {
-      g_in[NG + j] = -gu[NG + j] - zh[S::R_PC + j];
-      g_in[NG + NS + j] = gu[NG + j] - zh[S::R_D + j];
-      g_st[j] = zh[S::R_SOC_UP + j] - zh[S::R_SOC_LO + j];
+      g_in[NG + j] = -gu[NG + j] - zh(S::R_PC + j);
+      g_in[NG + NS + j] = gu[NG + j] - zh(S::R_D + j);
+      g_st[j] = zh(S::R_SOC_UP + j) - zh(S::R_SOC_LO + j);
     }
   }
 
-  // R = J' Hu J + (weights of the direct rows) + rho I, factored; R^-1 B', M = B R^-1 B'.  rho = a few units of
-  // roundoff of the largest diagonal entry: what keeps R numerically positive definite when the weights of a
-  // stage span more than 1/eps (directions only inactive rows see, next to rows about to become active); anything
-  // larger freezes those directions and leaves a dual residual rho |dv| behind
+  // R = J' Hu J + (weights of the direct rows) + rho I: the xi columns of its Cholesky factor and what they leave
+  // of the (p_c, d) block.  rho = a few units of roundoff of the largest diagonal entry: it keeps R numerically
+  // positive definite when the weights of a stage span more than 1/eps (directions only inactive rows see, next to
+  // rows about to become active); anything larger freezes those directions and leaves a dual residual rho |dv|
   ANM_HD void factor_stage(cptr_t C) {
     double Hu[pos(NC * (NC + 1) / 2)];
     ANM_UFOR (int k = 0; k < NC * (NC + 1) / 2; ++k) Hu[k] = 0.0;
     ANM_UFOR (int b = 0; b < NB1; ++b) {
-      const double wb = w[S::R_TH_UP + b] + w[S::R_TH_LO + b];
+      const double wb = w(S::R_TH_UP + b) + w(S::R_TH_LO + b);
       ANM_UFOR (int i = 0; i < NC; ++i) {
         const double wi = wb * C[S::T_THC + b * NC + i];
         ANM_UFOR (int j = 0; j <= i; ++j) Hu[tri(i, j)] = fma(wi, C[S::T_THC + b * NC + j], Hu[tri(i, j)]);
       }
     }
     ANM_UFOR (int e = 0; e < NBR; ++e) {
-      const double w1 = w[S::R_FL1 + e], w2 = w[S::R_FL2 + e], w3 = w[S::R_FL3 + e];
-      const double h = w1 + w2 + w3, ih = 1.0 / h;
+      const double w1 = w(S::R_FL1 + e), w2 = w(S::R_FL2 + e), w3 = w(S::R_FL3 + e);
+      const double ih = recip(w1 + w2 + w3);
       htt[e] = ih;                          // (the reciprocal is what every later use needs)
       hut[e] = (w2 - w1) * ih;
       const double hat = (4.0 * w1 * w2 + w3 * (w1 + w2)) * ih;  // weight of (a.du)^2 with t_e eliminated
@@ -351,11 +371,11 @@ struct Lane {
         ANM_UFOR (int j = 0; j <= i; ++j) Hu[tri(i, j)] = fma(wi, C[S::T_PHC + e * NC + j], Hu[tri(i, j)]);
       }
     }
-    ANM_UFOR (int j = 0; j < NS; ++j) Hu[tri(NG + j, NG + j)] += w[S::R_PD_UP + j] + w[S::R_PD_LO + j];
+    ANM_UFOR (int j = 0; j < NS; ++j) Hu[tri(NG + j, NG + j)] += w(S::R_PD_UP + j) + w(S::R_PD_LO + j);
     // R over (xi.., pc.., d..):  u_g = wd_g xi_g,  u_des_j = d_j - pc_j
     double R[pos(NA * (NA + 1) / 2)];
     auto ju = [&](int a, int& c, double& f) {  // input a moves u_c by f
-      if (a < NG) { c = a; f = wd[a]; }
+      if (a < NG) { c = a; f = wd[a < NG ? a : 0]; }
       else if (a < NG + NS) { c = a; f = -1.0; }
       else { c = a - NS; f = 1.0; }
     };
@@ -367,17 +387,15 @@ struct Lane {
         ju(b, cb, fb);
         R[tri(a, b)] = fa * fb * (ca >= cb ? Hu[tri(ca, cb)] : Hu[tri(cb, ca)]);
       }
-    ANM_UFOR (int g = 0; g < NG; ++g) R[tri(g, g)] += w[S::R_XI_UP + g] + w[S::R_XI_LO + g];
+    ANM_UFOR (int g = 0; g < NG; ++g) R[tri(g, g)] += w(S::R_XI_UP + g) + w(S::R_XI_LO + g);
     ANM_UFOR (int j = 0; j < NS; ++j) {
-      R[tri(NG + j, NG + j)] += w[S::R_PC + j];
-      R[tri(NG + NS + j, NG + NS + j)] += w[S::R_D + j];
+      R[tri(NG + j, NG + j)] += w(S::R_PC + j);
+      R[tri(NG + NS + j, NG + NS + j)] += w(S::R_D + j);
     }
     double dmax = 0.0;
     ANM_UFOR (int a = 0; a < NA; ++a) dmax = fmax(dmax, R[tri(a, a)]);
     const double rho = fma(4e-16, dmax, 1e-14);
     ANM_UFOR (int a = 0; a < NA; ++a) R[tri(a, a)] += rho;
-    // the xi columns of the Cholesky factor (they do not depend on the other stages), and what they leave of the
-    // (p_c, d) block
     ANM_UFOR (int jc = 0; jc < NG; ++jc)
       ANM_UFOR (int ir = jc; ir < NA; ++ir) {
         double acc = R[tri(ir, jc)];
@@ -394,7 +412,7 @@ struct Lane {
   }
 
   // coefficient of input s (0..NS-1: p_c, NS..2NS-1: d) in the state equation of its storage unit
-  static ANM_HD double bcoef(cptr_t C, int a) { return a < NS ? C[S::T_BC + a] : -C[S::T_BD + a - NS]; }
+  static ANM_HD double bcoef(cptr_t C, int a) { return a < NS ? C[S::T_BC + (a < NS ? a : 0)] : -C[S::T_BD + (a < NS ? 0 : a - NS)]; }
 
   // The coupled part of the factor, for the value function  V(x) = 1/2 x' P x  of the state AFTER this stage:
   //   Lam = Ts + Bs' P Bs = L_ss L_ss',   Wm = L_ss^-1 Bs' P,   Po = P - Wm' Wm
@@ -402,13 +420,12 @@ struct Lane {
   // every quantity is a sum of positive terms or what a Cholesky step subtracts -- nothing is inverted on its own,
   // so the weights of the rows may span the whole double range, like in a dense factorisation)
   ANM_HD void factor_coupled(cptr_t C, const double (&P)[pos(NS * NS)]) {
-    ANM_UFOR (int k = 0; k < NS * NS; ++k) Pm[k] = P[k];
     double cm[pos(2 * NS * NS)];  // Bs' P
     ANM_UFOR (int a = 0; a < 2 * NS; ++a)
-      ANM_UFOR (int q = 0; q < NS; ++q) cm[a * NS + q] = bcoef(C, a) * P[(a % NS) * NS + q];
+      ANM_UFOR (int q = 0; q < NS; ++q) cm[a * NS + q] = bcoef(C, a) * P[(a % pos(NS)) * NS + q];
     ANM_UFOR (int a = 0; a < 2 * NS; ++a)
       ANM_UFOR (int b = 0; b <= a; ++b) {
-        double acc = fma(cm[a * NS + (b % NS)], bcoef(C, b), Ts[tri(a, b)]);
+        double acc = fma(cm[a * NS + (b % pos(NS))], bcoef(C, b), Ts[tri(a, b)]);
         ANM_UFOR (int k = 0; k < b; ++k) acc = fma(-Lc[tri(NG + a, NG + k)], Lc[tri(NG + b, NG + k)], acc);
         if (a == b) Lc[tri(NG + a, NG + a)] = 1.0 / sqrt(acc);
         else Lc[tri(NG + a, NG + b)] = acc * Lc[tri(NG + b, NG + b)];
@@ -429,97 +446,168 @@ struct Lane {
   }
 };
 
+// "this value may have changed": the compiler must not keep what it computed from it before (see Step::forget)
+ANM_HD void forget(double& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
+
+// a Newton step of one stage, and what it does to the rows
+template <class T>
+struct Step {
+  typedef Sz<T> S;
+  double dxi[pos(S::NG)], dpc[pos(S::NS)], dd[pos(S::NS)], dt[pos(S::NBR)], xs[pos(S::NS)], gt[pos(S::NBR)];
+
+  // The rows are visited twice with the same step (once for the step length, once, after the group's reduction,
+  // for the update), and recomputing g.dv, dz and the target multiplier of a row costs a handful of instructions.
+  // Left alone, the compiler keeps all of them from the first visit to the second instead: 6 registers per row,
+  // more than a lane has.  Passing the step through an empty asm between the visits makes the second one recompute.
+  ANM_HD void forget_all() {
+    ANM_UFOR (int g = 0; g < S::NG; ++g) forget(dxi[g]);
+    ANM_UFOR (int j = 0; j < S::NS; ++j) { forget(dpc[j]); forget(dd[j]); forget(xs[j]); }
+    ANM_UFOR (int e = 0; e < S::NBR; ++e) { forget(dt[e]); forget(gt[e]); }
+  }
+
+  // f(r, g_r . dv) for every row r of the stage, in row order
+  template <class F>
+  ANM_HD void rows(cptr_t C, const Lane<T>& ln, F&& f) const {
+    constexpr int NG = S::NG, NS = S::NS, NB1 = S::NB1, NBR = S::NBR, NC = S::NC;
+    double du[pos(NC)];
+    ANM_UFOR (int g = 0; g < NG; ++g) du[g] = ln.wd[g] * dxi[g];
+    ANM_UFOR (int j = 0; j < NS; ++j) du[NG + j] = dd[j] - dpc[j];
+    ANM_UFOR (int g = 0; g < NG; ++g) { f(S::R_XI_UP + g, dxi[g]); f(S::R_XI_LO + g, -dxi[g]); }
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      f(S::R_PD_UP + j, du[NG + j]);
+      f(S::R_PD_LO + j, -du[NG + j]);
+      f(S::R_PC + j, -dpc[j]);
+      f(S::R_D + j, -dd[j]);
+      f(S::R_SOC_UP + j, xs[j]);
+      f(S::R_SOC_LO + j, -xs[j]);
+    }
+    ANM_UFOR (int b = 0; b < NB1; ++b) {
+      double a = 0.0;
+      ANM_UFOR (int c = 0; c < NC; ++c) a = fma(C[S::T_THC + b * NC + c], du[c], a);
+      f(S::R_TH_UP + b, a);
+      f(S::R_TH_LO + b, -a);
+    }
+    ANM_UFOR (int e = 0; e < NBR; ++e) {
+      double al = 0.0;
+      ANM_UFOR (int c = 0; c < NC; ++c) al = fma(C[S::T_PHC + e * NC + c], du[c], al);
+      const double rt = -gt[e], ih = ln.htt[e];
+      const double w1 = ln.w(S::R_FL1 + e), w2 = ln.w(S::R_FL2 + e), w3 = ln.w(S::R_FL3 + e);
+      // al - dt and -al - dt without the cancellation when one weight dominates
+      f(S::R_FL1 + e, (al * (2.0 * w2 + w3) - rt) * ih);
+      f(S::R_FL2 + e, (-al * (2.0 * w1 + w3) - rt) * ih);
+      f(S::R_FL3 + e, -dt[e]);
+    }
+  }
+};
+
 // One lane's run of the whole solve.
 template <class T, class X>
-ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool valid, int N, X& x) {
+ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool valid, int N, X& x, double* lane_lds = nullptr) {
   typedef Sz<T> S;
   typedef Lane<T> L;
   constexpr int NG = S::NG, NS = S::NS, NL = S::NL, NB1 = S::NB1, NBR = S::NBR, NC = S::NC, NA = S::NA, NR = S::NR;
   const int i = x.stage();
   const bool on = valid && i < N;  // a lane without a stage runs along with neutral contributions
   L ln;
-  ANM_UFOR (int k = 0; k < pos(NS * NS); ++k) { ln.Pm[k] = 0.0; ln.Po[k] = 0.0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  ln.lds = (volatile __attribute__((address_space(3))) double*)lane_lds;
+#else
+  (void)lane_lds;
+#endif
+  ANM_UFOR (int k = 0; k < pos(NS * NS); ++k) ln.Po[k] = 0.0;
   ANM_UFOR (int k = 0; k < pos(2 * NS * NS); ++k) ln.Wm[k] = 0.0;
   ANM_UFOR (int k = 0; k < pos(NA * (NA + 1) / 2); ++k) ln.Lc[k] = 0.0;
   // ---- constants of the stage ----
   ln.wgt = C[S::T_WGT + (i < 64 ? i : 63)];
   ln.ct = ln.wgt * C[S::T_LAMB];
-  double pl[pos(NL)], soc0[pos(NS)];
-  ANM_UFOR (int l = 0; l < NL; ++l) pl[l] = on ? io.p_load[(env * N + i) * NL + l] : 0.0;
-  ANM_UFOR (int g = 0; g < NG; ++g) {
-    const double fc = on ? io.p_gen[(env * N + i) * NG + g] : 0.0;
-    ln.wd[g] = fmax(fmin(C[S::T_GPMAX + g], fc) - C[S::T_GPMIN + g], 0.0);
-  }
-  ANM_UFOR (int j = 0; j < NS; ++j) soc0[j] = valid ? io.soc0[env * NS + j] : 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
-  ANM_UFOR (int b = 0; b < NB1; ++b) {
-    double a = 0.0;
-    ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_THL + b * NL + l], pl[l], a);
-    ln.th0[b] = a;
-  }
-  ANM_UFOR (int e = 0; e < NBR; ++e) {
-    double a = 0.0;
-    ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_PHL + e * NL + l], pl[l], a);
-    ln.f0[e] = a;
-  }
+  double soc0[pos(NS)];
   {
+    double pl[pos(NL)];
+    ANM_UFOR (int l = 0; l < NL; ++l) pl[l] = on ? io.p_load[(env * N + i) * NL + l] : 0.0;
+    ANM_UFOR (int g = 0; g < NG; ++g) {
+      const double fc = on ? io.p_gen[(env * N + i) * NG + g] : 0.0;
+      ln.wd[g] = fmax(fmin(C[S::T_GPMAX + g], fc) - C[S::T_GPMIN + g], 0.0);
+    }
+    ANM_UFOR (int j = 0; j < NS; ++j) {  // (a state of charge outside its window -- not a state the simulator produces -- is moved onto it)
+      const double raw = valid ? io.soc0[env * NS + j] : 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
+      soc0[j] = fmin(fmax(raw, C[S::T_SOCMIN + j]), C[S::T_SOCMAX + j]);
+    }
+    ANM_UFOR (int b = 0; b < NB1; ++b) {
+      double a = 0.0;
+      ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_THL + b * NL + l], pl[l], a);
+      ln.th0[b] = a;
+    }
+    ANM_UFOR (int e = 0; e < NBR; ++e) {
+      double a = 0.0;
+      ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_PHL + e * NL + l], pl[l], a);
+      ln.f0[e] = a;
+    }
     double a = 0.0;
     ANM_UFOR (int l = 0; l < NL; ++l) a = fma(C[S::T_SGL + l], pl[l], a);
     ln.objc = ln.wgt * a;
   }
-  // ---- start: strictly inside every row, so that the row residuals are zero from the first iteration on (the
-  // rows are linear: they stay zero) -- mid-interval generators; a little charge and the discharge that undoes
+  // ---- start: strictly inside every row -- mid-interval generators; a little charge and the discharge that undoes
   // it, plus what moves the state of charge a fifth of the way towards the middle of its window over the horizon
   // (a state of charge AT a bound is the usual case: an empty or a full unit); epigraph variables above the
-  // overloads of that point ----
-  ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = 0.5;
-  ANM_UFOR (int j = 0; j < NS; ++j) {
-    const double bc = C[S::T_BC + j], bd = C[S::T_BD + j], pmax = C[S::T_SPMAX + j], pmin = C[S::T_SPMIN + j];
-    const double base = 0.05 * (pmax - pmin);
-    const double mid = 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
-    double dsig = 0.2 * (mid - soc0[j]) / double(N);
-    dsig = fmin(fmax(dsig, -0.25 * pmax * bd), -0.25 * pmin * bc);   // (a quarter of the power limits at most)
-    ln.pc[j] = base + fmax(dsig, 0.0) / bc;
-    ln.d[j] = base * (bc / bd) + fmax(-dsig, 0.0) / bd;
-    ln.sig[j] = soc0[j] + double(i + 1) * dsig;
-  }
+  // overloads of that point.  The slacks are the rows' own: from here on they move with the inputs. ----
+  bool inside = true;
   {
-    double u[pos(NC)];
-    ln.phys(C, u);
-    ANM_UFOR (int e = 0; e < NBR; ++e) {
-      double fl = ln.f0[e];
-      ANM_UFOR (int c = 0; c < NC; ++c) fl = fma(C[S::T_PHC + e * NC + c], u[c], fl);
-      ln.t[e] = fmax(fabs(fl) - C[S::T_LIM + e], 0.0) + 0.1;
+    double sig[pos(NS)];
+    ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = 0.5;
+    ANM_UFOR (int j = 0; j < NS; ++j) {
+      const double bc = C[S::T_BC + j], bd = C[S::T_BD + j], pmax = C[S::T_SPMAX + j], pmin = C[S::T_SPMIN + j];
+      const double base = 0.05 * (pmax - pmin);
+      const double mid = 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
+      double dsig = 0.2 * (mid - soc0[j]) / double(N);
+      dsig = fmin(fmax(dsig, -0.25 * pmax * bd), -0.25 * pmin * bc);   // (a quarter of the power limits at most)
+      ln.pc[j] = base + fmax(dsig, 0.0) / bc;
+      ln.d[j] = base * (bc / bd) + fmax(-dsig, 0.0) / bd;
+      sig[j] = soc0[j] + double(i + 1) * dsig;
     }
-  }
-  {
+    {
+      double u[pos(NC)];
+      ln.phys(C, u);
+      ANM_UFOR (int e = 0; e < NBR; ++e) {
+        double fl = ln.f0[e];
+        ANM_UFOR (int c = 0; c < NC; ++c) fl = fma(C[S::T_PHC + e * NC + c], u[c], fl);
+        ln.t[e] = fmax(fabs(fl) - C[S::T_LIM + e], 0.0) + 0.1;
+      }
+    }
     double val[NR];
-    ln.row_values(C, val);
+    ln.row_values(C, sig, val);
     ANM_UFOR (int r = 0; r < NR; ++r) {
-      ln.s[r] = -val[r] > 0.0 ? -val[r] : 1e-2;               // (not strictly inside: a residual the iteration removes)
+      inside = inside && (-val[r] > 0.0);
+      ln.s[r] = -val[r] > 0.0 ? -val[r] : 1.0;
       ln.z[r] = r >= S::R_FL1 ? ln.ct * (1.0 / 3.0) : 1.0;  // dual feasible for the epigraph variables
+      ln.cross(r) = 0.0;
     }
   }
+  // (no interior start: a storage unit that cannot both charge and discharge, an angle limit the loads alone
+  // violate ... -- reported as not converged)
+  const bool startable = x.min(on ? (inside ? 1.0 : 0.0) : 1.0) > 0.5;
   const double m_rows = double(NR) * double(N);
   int it = 0;
   bool done = !valid;
-  double mu = 0.0, rpmax = 0.0, rdmax = 0.0, obj = 0.0;
+  double mu = 0.0, rdmax = 0.0, obj = 0.0;
   for (;; ++it) {
-    // ---- evaluate ----
-    ANM_UFOR (int j = 0; j < NS; ++j) ln.sig[j] = soc0[j] + x.scan(on ? fma(C[S::T_BC + j], ln.pc[j], -C[S::T_BD + j] * ln.d[j]) : 0.0);
-    double val[NR];
-    ln.row_values(C, val);
-    double a_mu = 0.0, a_rp = 0.0;
-    ANM_UFOR (int r = 0; r < NR; ++r) {
-      ln.rp[r] = val[r] + ln.s[r];
-      ln.w[r] = ln.z[r] / ln.s[r];
-      a_mu = fma(ln.s[r], ln.z[r], a_mu);
-      a_rp = fmax(a_rp, fabs(ln.rp[r]));
-    }
-    double a_rd = 0.0;
-    {  // dual residual: gradient of the Lagrangian; the state rows of the stages from here on act on this stage's
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the network tables are re-read (scalar loads, scalar cache) in every iteration: kept across iterations they
+    // would occupy some 150 registers of every lane
+    asm volatile("" ::: "memory");
+#endif
+    // ---- where the iterate stands ----
+    double a_mu = 0.0, a_rd = 0.0;
+    ANM_UFOR (int r = 0; r < NR; ++r) a_mu = fma(ln.s[r], ln.z[r], a_mu);
+    {  // dual residual: gradient of the Lagrangian; the window rows of the stages from here on act on this stage's
        // inputs through B
       double g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
-      ln.gradient(C, ln.z, false, g_in, g_st, gt);
+      ln.gradient(C, [&](int r) { return ln.z[r]; }, false, g_in, g_st, gt);
       ANM_UFOR (int j = 0; j < NS; ++j) {
         const double mine = on ? g_st[j] : 0.0;
         const double lam = x.sum(mine) - x.scan(mine) + mine;
@@ -529,15 +617,15 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       ANM_UFOR (int a = 0; a < NA; ++a) a_rd = fmax(a_rd, fabs(g_in[a]));
       ANM_UFOR (int e = 0; e < NBR; ++e) a_rd = fmax(a_rd, fabs(gt[e]));
     }
-    const double n_mu = x.sum(on ? a_mu : 0.0) / m_rows, n_rp = x.max(on ? a_rp : 0.0), n_rd = x.max(on ? a_rd : 0.0);
+    const double n_mu = x.sum(on ? a_mu : 0.0) / m_rows, n_rd = x.max(on ? a_rd : 0.0);
     const double n_obj = x.sum(on ? ln.objective(C) : 0.0);
-    if (!done) { mu = n_mu; rpmax = n_rp; rdmax = n_rd; obj = n_obj; }
-    if (!done && ((mu <= opt.tol * (1.0 + fabs(obj)) && rpmax <= 1e-9) || it >= opt.max_iter || !(mu == mu))) {
+    if (!done) { mu = n_mu; rdmax = n_rd; obj = n_obj; }
+    if (!done && (mu <= opt.tol * (1.0 + fabs(obj)) || it >= opt.max_iter || !(mu == mu) || !startable)) {
       done = true;
       if (valid && i == 0) {
         io.objective[env] = obj;
-        io.iters[env] = it;
-        if (io.info) { io.info[env * 3] = mu; io.info[env * 3 + 1] = rpmax; io.info[env * 3 + 2] = rdmax; }
+        io.iters[env] = startable ? it : opt.max_iter;
+        if (io.info) { io.info[env * 3] = mu; io.info[env * 3 + 1] = startable ? 0.0 : 1.0; io.info[env * 3 + 2] = rdmax; }
         double u[pos(NC)];
         ln.phys(C, u);
         ANM_UFOR (int c = 0; c < NC; ++c) io.u0[env * NC + c] = u[c];
@@ -553,42 +641,37 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
     }
     double* trg = (io.trace && on && !done && it <= opt.max_iter) ? io.trace + (env * (opt.max_iter + 1) + it) * 12 : nullptr;
     double* tr = i == 0 ? trg : nullptr;
-    if (tr) { tr[0] = n_mu; tr[1] = n_rp; tr[2] = n_rd; tr[3] = n_obj; }
+    if (tr) { tr[0] = n_mu; tr[1] = 0.0; tr[2] = n_rd; tr[3] = n_obj; }
     if (x.all_done(done)) break;
     // ---- factor (once per iteration) ----
+    ANM_UFOR (int r = 0; r < NR; ++r) ln.is(r) = recip(ln.s[r]);
     ln.factor_stage(C);
-    {  // value functions, last stage first:  P_i = Q_i + P'_{i+1}  (Q: the weights of the window rows)
+    {  // value functions, last stage first:  P_i = Q_i + P'_{i+1}  (Q: the weights of the window rows).  Systolic:
+       // in every step EVERY lane refactors with what its successor handed down last; stage k has its final input
+       // from step N - 1 - k on (the lanes of a wavefront execute the step anyway)
       double Pn[pos(NS * NS)];
       ANM_UFOR (int k = 0; k < NS * NS; ++k) Pn[k] = 0.0;
       for (int k = N - 1; k >= 0; --k) {
-        if (i == k) {
-          double P[pos(NS * NS)];
-          ANM_UFOR (int a = 0; a < NS; ++a)
-            ANM_UFOR (int b = 0; b < NS; ++b) P[a * NS + b] = Pn[a * NS + b] + (a == b ? ln.w[S::R_SOC_UP + a] + ln.w[S::R_SOC_LO + a] : 0.0);
-          ln.factor_coupled(C, P);
-        }
-        ANM_UFOR (int q = 0; q < NS * NS; ++q) {
-          const double got = x.down(i == k ? ln.Po[q] : 0.0);  // stage k - 1 receives P'_k
-          if (i == k - 1) Pn[q] = got;
-        }
+        double P[pos(NS * NS)];
+        ANM_UFOR (int a = 0; a < NS; ++a)
+          ANM_UFOR (int b = 0; b < NS; ++b) P[a * NS + b] = Pn[a * NS + b] + (a == b ? ln.w(S::R_SOC_UP + a) + ln.w(S::R_SOC_LO + a) : 0.0);
+        ln.factor_coupled(C, P);
+        ANM_UFOR (int q = 0; q < NS * NS; ++q) Pn[q] = x.down(i < N ? ln.Po[q] : 0.0);  // (the last stage receives 0)
       }
     }
-    // ---- Newton step for multipliers zh ----
-    double dxi[pos(NG)], dpc[pos(NS)], dd[pos(NS)], dt[pos(NBR)], gv[NR];
-    auto newton = [&](const double (&zh)[NR]) {
-      double g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
-      ln.gradient(C, zh, true, g_in, g_st, gt);
+    // ---- Newton step for multipliers zh(r):  H dv = -(c + G' zh) ----
+    Step<T> st;
+    auto newton = [&](auto&& zh) {
+      double g_in[pos(NA)], g_st[pos(NS)];
+      ln.gradient(C, zh, true, g_in, g_st, st.gt);
       // Residual form.  The multipliers of the window rows of this and the later stages act on the inputs of this
       // stage through B: lam_i = sum_{k >= i} g_st_k is the costate the multipliers THEMSELVES imply.  With it
-      // folded into the input gradient (g_in + B' lam: the dual residual, small near the solution) the sweep
-      // only has to find the CORRECTION of the costate.  Sweeping on g_in alone means R^-1 g_in -- huge along
-      // directions no row pins, where the gradient is balanced by the costate (charging now against the value of
-      // the stored energy later) -- and a state step that is the small difference of two such terms.
+      // folded into the input gradient the sweeps only have to find the CORRECTION of the costate.
       ANM_UFOR (int j = 0; j < NS; ++j) {
         const double mine = on ? g_st[j] : 0.0;
-        g_st[j] = x.sum(mine) - x.scan(mine) + mine;   // lam_i
-        g_in[NG + j] = fma(C[S::T_BC + j], g_st[j], g_in[NG + j]);
-        g_in[NG + NS + j] = fma(-C[S::T_BD + j], g_st[j], g_in[NG + NS + j]);
+        const double lam = x.sum(mine) - x.scan(mine) + mine;
+        g_in[NG + j] = fma(C[S::T_BC + j], lam, g_in[NG + j]);
+        g_in[NG + NS + j] = fma(-C[S::T_BD + j], lam, g_in[NG + NS + j]);
       }
       // forward substitution: the xi part at once, the (p_c, d) part stage by stage (last first), each stage
       // handing the linear term of its value function down:  y_s = L_ss^-1 (g_s - L_sx y_x + Bs' p),  p' = p - Wm' y_s
@@ -598,159 +681,111 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         ANM_UFOR (int k = 0; k < (a < NG ? a : NG); ++k) acc = fma(-ln.Lc[L::tri(a, k)], y[k], acc);
         y[a] = a < NG ? acc * ln.Lc[L::tri(a, a)] : acc;
       }
-      double p[pos(NS)], pn[pos(NS)];
-      ANM_UFOR (int j = 0; j < NS; ++j) { p[j] = 0.0; pn[j] = 0.0; }
-      for (int k = N - 1; k >= 0; --k) {
-        double out[pos(NS)];
-        ANM_UFOR (int j = 0; j < NS; ++j) out[j] = 0.0;
-        if (i == k) {
-          ANM_UFOR (int j = 0; j < NS; ++j) p[j] = pn[j];   // (residual form: the g_st of the stages are in lam)
-          ANM_UFOR (int a = 0; a < 2 * NS; ++a) {
-            double acc = fma(L::bcoef(C, a), p[a % NS], y[NG + a]);
-            ANM_UFOR (int kk = 0; kk < a; ++kk) acc = fma(-ln.Lc[L::tri(NG + a, NG + kk)], y[NG + kk], acc);
-            y[NG + a] = acc * ln.Lc[L::tri(NG + a, NG + a)];
-          }
-          ANM_UFOR (int q = 0; q < NS; ++q) {
-            double acc = p[q];
-            ANM_UFOR (int a = 0; a < 2 * NS; ++a) acc = fma(-ln.Wm[a * NS + q], y[NG + a], acc);
-            out[q] = acc;
-          }
+      double pn[pos(NS)], ys[pos(2 * NS)];
+      ANM_UFOR (int j = 0; j < NS; ++j) pn[j] = 0.0;
+      ANM_UFOR (int a = 0; a < 2 * NS; ++a) ys[a] = 0.0;
+      for (int k = N - 1; k >= 0; --k) {  // (systolic, like the factor sweep)
+        ANM_UFOR (int a = 0; a < 2 * NS; ++a) {
+          double acc = fma(L::bcoef(C, a), pn[a % pos(NS)], y[NG + a]);
+          ANM_UFOR (int kk = 0; kk < a; ++kk) acc = fma(-ln.Lc[L::tri(NG + a, NG + kk)], ys[kk], acc);
+          ys[a] = acc * ln.Lc[L::tri(NG + a, NG + a)];
         }
-        ANM_UFOR (int j = 0; j < NS; ++j) {
-          const double got = x.down(i == k ? out[j] : 0.0);
-          if (i == k - 1) pn[j] = got;
+        ANM_UFOR (int q = 0; q < NS; ++q) {
+          double acc = pn[q];
+          ANM_UFOR (int a = 0; a < 2 * NS; ++a) acc = fma(-ln.Wm[a * NS + q], ys[a], acc);
+          pn[q] = x.down(i < N ? acc : 0.0);
         }
       }
+      ANM_UFOR (int a = 0; a < 2 * NS; ++a) y[NG + a] = ys[a];
       // back substitution, first stage first:  a_s = -L_ss^-T (y_s + Wm x_{i-1}),  x_i = x_{i-1} + Bs a_s  -- the
       // state step IS what the inputs add up to; then the xi part
-      double da[pos(NA)], xs[pos(NS)], xp[pos(NS)];
+      double da[pos(NA)], xp[pos(NS)];
       ANM_UFOR (int a = 0; a < NA; ++a) da[a] = 0.0;
-      ANM_UFOR (int j = 0; j < NS; ++j) { xs[j] = 0.0; xp[j] = 0.0; }
+      ANM_UFOR (int j = 0; j < NS; ++j) { st.xs[j] = 0.0; xp[j] = 0.0; }
       for (int k = 0; k < N; ++k) {
-        if (i == k) {
-          ANM_UFOR (int a = 2 * NS - 1; a >= 0; --a) {
-            double acc = y[NG + a];
-            ANM_UFOR (int q = 0; q < NS; ++q) acc = fma(ln.Wm[a * NS + q], xp[q], acc);
-            acc = -acc * ln.Lc[L::tri(NG + a, NG + a)];
-            // (row a of L_ss' x = b:  x_a = (b_a - sum_{kk > a} L[kk][a] x_kk) / L[a][a], with b = -(y + W x))
-            ANM_UFOR (int kk = a + 1; kk < 2 * NS; ++kk) acc = fma(-ln.Lc[L::tri(NG + kk, NG + a)] * ln.Lc[L::tri(NG + a, NG + a)], da[NG + kk], acc);
-            da[NG + a] = acc;
-          }
-          ANM_UFOR (int j = 0; j < NS; ++j) xs[j] = xp[j] + fma(C[S::T_BC + j], da[NG + j], -C[S::T_BD + j] * da[NG + NS + j]);
+        ANM_UFOR (int a = 2 * NS - 1; a >= 0; --a) {
+          double acc = y[NG + a];
+          ANM_UFOR (int q = 0; q < NS; ++q) acc = fma(ln.Wm[a * NS + q], xp[q], acc);
+          ANM_UFOR (int kk = a + 1; kk < 2 * NS; ++kk) acc = fma(ln.Lc[L::tri(NG + kk, NG + a)], da[NG + kk], acc);
+          da[NG + a] = -acc * ln.Lc[L::tri(NG + a, NG + a)];
         }
         ANM_UFOR (int j = 0; j < NS; ++j) {
-          const double got = x.up(i == k ? xs[j] : 0.0);
-          if (i == k + 1) xp[j] = got;
+          st.xs[j] = xp[j] + fma(C[S::T_BC + j], da[NG + j], -C[S::T_BD + j] * da[NG + NS + j]);
+          xp[j] = x.up(i < N ? st.xs[j] : 0.0);
         }
       }
+      // (xp is now the state step of the previous stage; the last pass used the final one)
       ANM_UFOR (int a = NG - 1; a >= 0; --a) {
-        double acc = -y[a];
-        ANM_UFOR (int kk = a + 1; kk < NA; ++kk) acc = fma(-ln.Lc[L::tri(kk, a)], da[kk], acc);
-        da[a] = acc * ln.Lc[L::tri(a, a)];
+        double acc = y[a];
+        ANM_UFOR (int kk = a + 1; kk < NA; ++kk) acc = fma(ln.Lc[L::tri(kk, a)], da[kk], acc);
+        da[a] = -acc * ln.Lc[L::tri(a, a)];
       }
-      ANM_UFOR (int g = 0; g < NG; ++g) dxi[g] = da[g];
-      ANM_UFOR (int j = 0; j < NS; ++j) { dpc[j] = da[NG + j]; dd[j] = da[NG + NS + j]; }
-      // g.dv of every row
-      double du[pos(NC)];
-      ANM_UFOR (int g = 0; g < NG; ++g) du[g] = ln.wd[g] * dxi[g];
-      ANM_UFOR (int j = 0; j < NS; ++j) du[NG + j] = dd[j] - dpc[j];
-      ANM_UFOR (int g = 0; g < NG; ++g) { gv[S::R_XI_UP + g] = dxi[g]; gv[S::R_XI_LO + g] = -dxi[g]; }
-      ANM_UFOR (int j = 0; j < NS; ++j) {
-        gv[S::R_PD_UP + j] = du[NG + j];
-        gv[S::R_PD_LO + j] = -du[NG + j];
-        gv[S::R_PC + j] = -dpc[j];
-        gv[S::R_D + j] = -dd[j];
-        gv[S::R_SOC_UP + j] = xs[j];
-        gv[S::R_SOC_LO + j] = -xs[j];
-      }
-      ANM_UFOR (int b = 0; b < NB1; ++b) {
-        double a = 0.0;
-        ANM_UFOR (int c = 0; c < NC; ++c) a = fma(C[S::T_THC + b * NC + c], du[c], a);
-        gv[S::R_TH_UP + b] = a;
-        gv[S::R_TH_LO + b] = -a;
-      }
-      ANM_UFOR (int e = 0; e < NBR; ++e) {
-        double al = 0.0;
-        ANM_UFOR (int c = 0; c < NC; ++c) al = fma(C[S::T_PHC + e * NC + c], du[c], al);
-        const double rt = -gt[e], ih = ln.htt[e];
-        const double w1 = ln.w[S::R_FL1 + e], w2 = ln.w[S::R_FL2 + e], w3 = ln.w[S::R_FL3 + e];
-        dt[e] = fma(rt, ih, -ln.hut[e] * al);
-        // al - dt and -al - dt without the cancellation when one weight dominates
-        gv[S::R_FL1 + e] = (al * (2.0 * w2 + w3) - rt) * ih;
-        gv[S::R_FL2 + e] = (-al * (2.0 * w1 + w3) - rt) * ih;
-        gv[S::R_FL3 + e] = -dt[e];
+      ANM_UFOR (int g = 0; g < NG; ++g) st.dxi[g] = da[g];
+      ANM_UFOR (int j = 0; j < NS; ++j) { st.dpc[j] = da[NG + j]; st.dd[j] = da[NG + NS + j]; }
+      {  // the epigraph variables follow their flows
+        double du[pos(NC)];
+        ANM_UFOR (int g = 0; g < NG; ++g) du[g] = ln.wd[g] * st.dxi[g];
+        ANM_UFOR (int j = 0; j < NS; ++j) du[NG + j] = st.dd[j] - st.dpc[j];
+        ANM_UFOR (int e = 0; e < NBR; ++e) {
+          double al = 0.0;
+          ANM_UFOR (int c = 0; c < NC; ++c) al = fma(C[S::T_PHC + e * NC + c], du[c], al);
+          st.dt[e] = fma(-st.gt[e], ln.htt[e], -ln.hut[e] * al);
+        }
       }
     };
-    // largest step in [0, 1] keeping  v + a dv > 0  over this lane's rows
-    auto max_step = [&](const double (&v)[NR], const double (&dv)[NR]) {
-      double a = 1e300;
-      ANM_UFOR (int r = 0; r < NR; ++r) a = dv[r] < 0.0 ? fmin(a, -v[r] / dv[r]) : a;
-      return a;
-    };
-    // ---- predictor:  s dz + z ds = -s z  ->  zh = w rp ----
-    double zh[NR], ds[NR], dz[NR];
-    ANM_UFOR (int r = 0; r < NR; ++r) zh[r] = ln.w[r] * ln.rp[r];
-    newton(zh);
-    ANM_UFOR (int r = 0; r < NR; ++r) {
-      ds[r] = -ln.rp[r] - gv[r];
-      dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
-    }
-    double ap = fmin(1.0, x.min(on ? max_step(ln.s, ds) : 1e300));
-    double ad = fmin(1.0, x.min(on ? max_step(ln.z, dz) : 1e300));
-    double a_aff = 0.0;
-    ANM_UFOR (int r = 0; r < NR; ++r) {
-      a_aff = fma(fma(ap, ds[r], ln.s[r]), fma(ad, dz[r], ln.z[r]), a_aff);
-      ln.cross[r] = ds[r] * dz[r];
-    }
-    const double mu_aff = x.sum(on ? a_aff : 0.0) / m_rows;
+    // ---- predictor:  s dz + z ds = -s z  ->  zh = 0:  ds = -g.dv,  dz = -z + w g.dv ----
+    newton([](int) { return 0.0; });
+    double ms = 0.0, mz = 0.0, sdz = 0.0, zds = 0.0, dsdz = 0.0;  // largest -ds/s, -dz/z; sums for the predictor's mu
+    st.rows(C, ln, [&](int r, double gv) {
+      const double ds = -gv, dz = fma(ln.w(r), gv, -ln.z[r]);
+      ms = fmax(ms, -ds * ln.is(r));
+      mz = fmax(mz, -dz * recip(ln.z[r]));
+      sdz = fma(ln.s[r], dz, sdz);
+      zds = fma(ln.z[r], ds, zds);
+      dsdz = fma(ds, dz, dsdz);
+      ln.cross(r) = ds * dz;
+    });
+    ms = x.max(on ? ms : 0.0);
+    mz = x.max(on ? mz : 0.0);
+    double ap = ms > 1.0 ? 1.0 / ms : 1.0, ad = mz > 1.0 ? 1.0 / mz : 1.0;
+    const double mu_aff = x.sum(on ? a_mu + ap * zds + ad * sdz + ap * ad * dsdz : 0.0) / m_rows;
     const double ratio = mu_aff / n_mu;
     // centring: Mehrotra's cube, not below what keeps mu from undershooting the target in one step
     const double sg = fmin(1.0, fmax(ratio * ratio * ratio, 0.1 * opt.tol * (1.0 + fabs(n_obj)) / n_mu));
     const double smu = sg * n_mu;
-    // ---- corrector:  s dz + z ds = sigma mu - s z - ds dz ----
-    ANM_UFOR (int r = 0; r < NR; ++r) zh[r] = fma(ln.w[r], ln.rp[r], (smu - ln.cross[r]) / ln.s[r]);
+    // ---- corrector:  s dz + z ds = sigma mu - s z - ds dz  ->  zh = (sigma mu - ds dz) / s ----
+    auto zh = [&](int r) { return (smu - ln.cross(r)) * ln.is(r); };
     newton(zh);
-    ANM_UFOR (int r = 0; r < NR; ++r) {
-      ds[r] = -ln.rp[r] - gv[r];
-      dz[r] = fma(ln.w[r], gv[r], zh[r] - ln.z[r]);
-    }
-    const double my_ap = on ? max_step(ln.s, ds) : 1e300;
-    const double grp_ap = x.min(my_ap);
-    ap = fmin(1.0, 0.995 * grp_ap);
-    ad = fmin(1.0, 0.995 * x.min(on ? max_step(ln.z, dz) : 1e300));
-    if (trg && my_ap == grp_ap) {
-      int rb = -1;
-      ANM_UFOR (int r = 0; r < NR; ++r) rb = (ds[r] < 0.0 && -ln.s[r] / ds[r] == my_ap) ? r : rb;
-      trg[8] = double(i); trg[9] = double(rb);
-      ANM_UFOR (int r = 0; r < NR; ++r) if (r == rb) { trg[10] = ln.s[r]; trg[11] = ds[r]; }
-    }
-#if defined(ANM_MPC_DEBUG) && !defined(__HIPCC__)
-    {  // residual of the Newton system just solved: gradient of the Lagrangian at the multipliers z + dz (full step)
-      double zf[NR], g_in[pos(NA)], g_st[pos(NS)], gt[pos(NBR)];
-      for (int r = 0; r < NR; ++r) zf[r] = fma(ln.w[r], gv[r], zh[r]);
-      ln.gradient(C, zf, false, g_in, g_st, gt);
-      double worst = 0.0;
-      for (int j = 0; j < NS; ++j) {
-        const double lam = x.sum(g_st[j]) - x.scan(g_st[j]) + g_st[j];
-        g_in[NG + j] += C[S::T_BC + j] * lam;
-        g_in[NG + NS + j] -= C[S::T_BD + j] * lam;
-      }
-      for (int a = 0; a < NA; ++a) worst = fmax(worst, fabs(g_in[a]));
-      double wm = 0.0;
-      for (int r = 0; r < NR; ++r) wm = fmax(wm, ln.w[r]);
-      const double res = x.max(worst), wmx = x.max(wm);
-      if (i == 0) printf("it %d mu %.2e rd %.2e newton residual %.2e wmax %.1e P %.2e ap %.3f ad %.3f\n", it, n_mu, n_rd, res, wmx, ln.Pm[0], ap, ad);
-    }
-#endif
+    ms = 0.0;
+    mz = 0.0;
+    int rb = -1;
+    st.rows(C, ln, [&](int r, double gv) {
+      const double ds = -gv, dz = fma(ln.w(r), gv, zh(r) - ln.z[r]);
+      const double q = -ds * ln.is(r);
+      rb = q > ms ? r : rb;
+      ms = fmax(ms, q);
+      mz = fmax(mz, -dz * recip(ln.z[r]));
+    });
+    const double my_ms = on ? ms : 0.0;
+    ms = x.max(my_ms);
+    mz = x.max(on ? mz : 0.0);
+    ap = ms > 0.995 ? 0.995 / ms : 1.0;   // min(1, 0.995 x the step to the nearest row)
+    ad = mz > 0.995 ? 0.995 / mz : 1.0;
     if (tr) { tr[4] = ap; tr[5] = ad; tr[6] = sg; tr[7] = mu_aff; }
+    if (trg && my_ms == ms && rb >= 0) { trg[8] = double(i); trg[9] = double(rb); trg[10] = 0.0; trg[11] = 0.0; }
+    st.forget_all();
+    double smu2 = smu;
+    forget(smu2);
+    auto zh2 = [&](int r) { return (smu2 - ln.cross(r)) * ln.is(r); };
     if (!done) {
-      ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = fma(ap, dxi[g], ln.xi[g]);
-      ANM_UFOR (int j = 0; j < NS; ++j) { ln.pc[j] = fma(ap, dpc[j], ln.pc[j]); ln.d[j] = fma(ap, dd[j], ln.d[j]); }
-      ANM_UFOR (int e = 0; e < NBR; ++e) ln.t[e] = fma(ap, dt[e], ln.t[e]);
-      ANM_UFOR (int r = 0; r < NR; ++r) {
-        ln.s[r] = fma(ap, ds[r], ln.s[r]);
-        ln.z[r] = fma(ad, dz[r], ln.z[r]);
-      }
+      ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = fma(ap, st.dxi[g], ln.xi[g]);
+      ANM_UFOR (int j = 0; j < NS; ++j) { ln.pc[j] = fma(ap, st.dpc[j], ln.pc[j]); ln.d[j] = fma(ap, st.dd[j], ln.d[j]); }
+      ANM_UFOR (int e = 0; e < NBR; ++e) ln.t[e] = fma(ap, st.dt[e], ln.t[e]);
+      st.rows(C, ln, [&](int r, double gv) {
+        const double dz = fma(ln.w(r), gv, zh2(r) - ln.z[r]);
+        ln.s[r] = fma(-ap, gv, ln.s[r]);
+        ln.z[r] = fma(ad, dz, ln.z[r]);
+      });
     }
   }
 }
@@ -774,27 +809,42 @@ struct WaveGroup {
     const double r = __shfl_down(v, 1, G);
     return st == G - 1 ? 0.0 : r;
   }
+  // butterflies of a fixed six steps (a step beyond the group adds the neutral element): no loop whose trip count
+  // depends on G -- with such loops between them the row arrays of the lane no longer fit its registers
   __device__ double sum(double v) const {
-    if (!SINGLE)
-      for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    if (!SINGLE) {
+      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_xor(v, o, 64);
+        v += o < G ? t : 0.0;
+      }
+    }
     return v;
   }
   __device__ double max(double v) const {
-    if (!SINGLE)
-      for (int o = G >> 1; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, G));
+    if (!SINGLE) {
+      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_xor(v, o, 64);
+        v = o < G ? fmax(v, t) : v;
+      }
+    }
     return v;
   }
   __device__ double min(double v) const {
-    if (!SINGLE)
-      for (int o = G >> 1; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, G));
+    if (!SINGLE) {
+      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_xor(v, o, 64);
+        v = o < G ? fmin(v, t) : v;
+      }
+    }
     return v;
   }
   __device__ double scan(double v) const {
-    if (!SINGLE)
-      for (int o = 1; o < G; o <<= 1) {
-        const double r = __shfl_up(v, o, G);
-        if (st >= o) v += r;
+    if (!SINGLE) {
+      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        v += (o < G && st >= o) ? t : 0.0;
       }
+    }
     return v;
   }
   __device__ bool all_done(bool d) const { return __all(d); }
@@ -806,7 +856,8 @@ __global__ __launch_bounds__(64) void k_mpc(cptr_t C, IO io, Opts opt, int64_t n
     const int lane = threadIdx.x;
     const int64_t env = int64_t(blockIdx.x) * (64 / G) + lane / G;
     WaveGroup<SINGLE> x{G, lane % G};
-    solve<T>(C, io, opt, env, env < n_envs, N, x);
+    extern __shared__ double mpc_lds[];   // [2 NR][64]: 1/s and the predictor's ds*dz of every row of every lane
+    solve<T>(C, io, opt, env, env < n_envs, N, x, mpc_lds + lane);
   }
 }
 #endif

@@ -279,10 +279,11 @@ typedef struct anm_mpc_dims {
 } anm_mpc_dims;
 
 typedef struct anm_mpc_opts {
-  double tol;        /* stop when the complementarity gap per row mu <= tol (1 + |objective|) and the row residuals
-                        are <= 1e-9; 0 = default 1e-11 (values within ~1e-8 relative of the optimum).  info[., 2] reports the dual residual reached */
+  double tol;        /* stop when the complementarity gap per row mu <= tol (1 + |objective|); 0 = default 1e-11 (values
+                        within ~1e-8 relative of the optimum).  The iterate satisfies every row throughout (the
+                        method starts strictly inside and stays there); info[., 2] reports the dual residual reached */
   int32_t max_iter;  /* interior-point iterations; 0 = default 40 */
-  double* trace;     /* NULL, or dev [num_envs, max_iter + 1, 12]: per iteration mu, row residual, dual residual, objective,
+  double* trace;     /* NULL, or dev [num_envs, max_iter + 1, 12]: per iteration mu, 0, dual residual, objective,
                         then, of the step taken from there: primal / dual step length, centring parameter, predictor mu,
                         and the row that limited the primal step (stage, row, its slack, its slack step) */
 } anm_mpc_opts;
@@ -296,7 +297,8 @@ int anm_mpc_get_tables(const anm_mpc* m, double* out /* [table_doubles] host */)
 /* p_load_forecast [num_envs, N, n_load], p_gen_forecast [num_envs, N, n_gen] (mpc.py:348-372: forecast(), here
  * stage-major), soc [num_envs, n_des] (mpc.py:417).  Out: u0 [num_envs, n_ctrl] the first-stage P_gen / P_des
  * (mpc.py:383-388, before the scaling to MW), objective [num_envs] (the value of the reference's program),
- * iters [num_envs], info [num_envs, 3] (final mu, largest row residual, largest dual residual; may be NULL), solution
+ * iters [num_envs], info [num_envs, 3] (final mu; 1 if some stage has no interior starting point -- reported as not converged --
+ * else 0; largest dual residual; may be NULL), solution
  * [num_envs, N, n_stage_vars] (may be NULL).  All dev.  An environment whose solve does not reach the tolerance
  * within max_iter reports iters = max_iter (not an error, like a non-"optimal" status in the reference, :377-379). */
 int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
