@@ -126,12 +126,85 @@ def case30_side_figure(dev, E=16384, n=20):
     return out
 
 
+def throughput_side_figure(dev, args, E=524288, n=60):
+    """BASELINE config 5's per-GPU load when 524 288 environments sit on ONE GPU (the strong-scaling N = 1 point):
+    the two-launch step (stragglers of the whole batch packed into a second launch), same workload as the headline."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    env = ANM6EasyVec(num_envs=E, device=dev, seed=77, tol=args.tol, max_iter=args.max_iter, precision=args.precision,
+                      autoreset=True)  # fmt: skip
+    env.check_actions = False
+    env.reset(seed=77)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    lo, hi = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
+    pool = [lo + (hi - lo) * torch.rand((E, 6), generator=gen, dtype=torch.float64, device=dev) for _ in range(4)]
+    for i in range(10):
+        env.step(pool[i % 4])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(n):
+        env.step(pool[i % 4])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = (time.perf_counter() - t0) / n
+    kern = ev0.elapsed_time(ev1) * 1e-3 / n
+    nbytes = algorithmic_bytes_per_env_step(6, 18, 1, 1)
+    return {"anm6easy_524288_1gpu": {
+        "env_steps_per_s": E / wall, "us_per_step": wall * 1e6, "us_per_step_events": kern * 1e6,
+        "launches_per_step": 3 if env._ws is not None else 1,
+        "roofline": {"bound": "hbm", "achieved": nbytes * E / kern / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": nbytes * E / kern / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_env_step": nbytes,
+                     "note": "k_step_rows + k_step_stragglers + k_step_scatter per step; HIP events over %d steps" % n}}}
+
+
+def mpc_side_figure(dev):
+    """the batched MPC DC-OPF policy (gym_anm/agents/mpc.py), all environments' programs in one launch of
+    k_mpc.  Algorithmic bytes per program: forecasts in, first-stage set-points + value + iteration count out."""
+    from gym_anm_amd.agents import MPCAgentPerfect
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    out = {}
+    E = 65536
+    env = ANM6EasyVec(num_envs=E, device=dev, seed=3)
+    env.reset(seed=3)
+    for N in (1, 10):
+        ag = MPCAgentPerfect(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=N)
+        pl, pg = ag.forecast(env)
+        soc = ag._soc(env)
+        sol = ag.solver
+        for _ in range(3):
+            sol.solve(pl, pg, soc)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        ev0.record()
+        for _ in range(10):
+            sol.solve(pl, pg, soc)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        ms = ev0.elapsed_time(ev1) / 10
+        d = sol.dims
+        nbytes = 8 * (N * (d.n_load + d.n_gen) + d.n_des + d.n_ctrl + 1 + 3) + 4
+        out["mpc_dcopf_anm6_65536_N%d" % N] = {
+            "programs_per_s": E / (ms * 1e-3), "ms_per_solve": ms, "mean_iterations": float(sol.iters.double().mean()),
+            "max_iterations": int(sol.iters.max()), "rows_per_stage": int(d.n_stage_rows),
+            "roofline": {"bound": "hbm", "achieved": nbytes * E / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": nbytes * E / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_program": nbytes,
+                         "note": "an interior-point solve per program: fp64-issue bound by nature (~%d iterations of a few "
+                                 "thousand instructions per lane), the HBM figure is the contract's" % round(float(sol.iters.double().mean()))}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--num-envs", type=int, default=65536, help="environments per GPU")
+    ap.add_argument("--num-envs", type=int, default=65536, help="environments per GPU (weak scaling: the default)")
+    ap.add_argument("--global-envs", type=int, default=0,
+                    help="strong scaling: this many environments in total, split evenly over the GPUs (BASELINE config 5: "
+                         "524288); overrides --num-envs")
     ap.add_argument("--tol", type=float, default=1e-6, help="Newton stop: ||F||inf <= tol (metric: 1e-6; reference: 1e-5)")
     ap.add_argument("--max-iter", type=int, default=100, help="Newton iteration cap (reference: 100)")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64", help="Jacobian/LU precision (F, x always fp64)")
@@ -169,6 +242,12 @@ def main():
 
     from gym_anm_amd.envs import ANM6EasyVec
 
+    scaling = "weak"
+    if args.global_envs:
+        if args.global_envs % world:
+            raise SystemExit("--global-envs %d is not a multiple of the %d ranks" % (args.global_envs, world))
+        args.num_envs = args.global_envs // world
+        scaling = "strong"
     E = args.num_envs
     env = ANM6EasyVec(num_envs=E, device=dev, seed=1234, tol=args.tol, max_iter=args.max_iter,
                       precision=args.precision, autoreset=True, env_offset=rank * E)  # fmt: skip
@@ -270,10 +349,12 @@ def main():
     # Simulator.transition with the full electrical-state dump, lane-group kernel family.
     other = None
     if rank == 0 and world == 1 and not args.headline_only:
-        try:
-            other = case30_side_figure(dev)
-        except Exception as ex:  # never let the side figure break the headline line
-            other = {"error": str(ex)[:200]}
+        other = {}
+        for fig in (lambda: case30_side_figure(dev), lambda: throughput_side_figure(dev, args), lambda: mpc_side_figure(dev)):
+            try:
+                other.update(fig())
+            except Exception as ex:  # never let a side figure break the headline line
+                other.setdefault("errors", []).append(str(ex)[:200])
 
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(6, 18, 1, 1)
@@ -282,11 +363,13 @@ def main():
         # bench.py cannot collect counters itself, so the committed figure is attached when it was
         # measured on this very configuration, else null.
         traffic = None
+        traffic_source = None
         valu = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt["num_envs"] == E and pt["nr_max_iter"] == args.max_iter and pt["precision"] == args.precision:
                 traffic = pt["hbm_bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic.json (%s): PMC passes of an earlier run of this configuration, not of this run" % pt.get("source", "?")
                 # what really bounds the kernel: fp64 VALU issue.  A wave64 fp64 instruction occupies its
                 # SIMD for 4 cycles, so the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 of them per s.
                 peak_issue = 256 * 4 * 2.4e9 / 4
@@ -297,7 +380,8 @@ def main():
         except Exception:
             pass
         out = {
-            "metric": "env-steps/sec (whole node) at num_envs=65536, ANM6Easy; NR iters to 1e-6",
+            "metric": "env-steps/sec (whole node) at num_envs=%s, ANM6Easy; NR iters to 1e-6"
+                      % ("65536" if (scaling == "weak" and E == 65536) else ("%d in total" % (E * world) if scaling == "strong" else "%d per GPU" % E)),
             "value": total_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -305,7 +389,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f64 (f32 Jacobian/LU)",
             "data": "synthetic",
@@ -323,7 +407,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "k_step_rows<double, false>" if args.precision == "f64" else "k_step_rows<float, false>",
                 "kernel_ms": kernel_s * 1e3, "launches_timed": args.steps,
                 "kernel_ms_back_to_back": ms.value, "launches_back_to_back": n_launch,

@@ -256,6 +256,20 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
   std::string err, err_topo;
   m->tpe_ok = pack_constants<Topo>(*desc, m->h_const, m->ybus, err_topo);
   if (m->tpe_ok) {
+    // k_step_general's dynamic LDS: the electrical-state rows (at most 60 KB, GenLds::FULL_OK) plus the state rows can
+    // exceed the default 64 KB per workgroup (an 8-bus tree with 9 devices: 68 KB).  The attribute is set here, once,
+    // not in a launch path that may be under stream capture
+    typedef GenLds<Topo> GL;
+    constexpr size_t worst = (size_t(GL::FULL_OK ? (64 * GL::FSP > GL::B_DOUBLES ? 64 * GL::FSP : GL::B_DOUBLES) : GL::B_DOUBLES) +
+                              size_t(64) * size_t(GL::SP)) * sizeof(double);
+    if (worst > 64 * 1024) {
+      hipError_t a1 = hipFuncSetAttribute((const void*)k_step_general<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipError_t a2 = hipFuncSetAttribute((const void*)k_step_general<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (a1 != hipSuccess || a2 != hipSuccess) {
+        delete m;
+        return fail_hip(a1 != hipSuccess ? a1 : a2, "k_step_general: LDS size attribute");
+      }
+    }
     hipError_t e = hipMalloc(&m->d_const, m->h_const.size() * sizeof(double));
     if (e != hipSuccess) {
       delete m;

@@ -140,6 +140,7 @@ class BatchedANMEnv(GymEnv):
         self._term_bool = self._term_u8.view(torch.bool)  # zero-copy: the kernel only writes 0 / 1
         self.timestep = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
+        self._conv_bool = None
         self._reset_count = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._truncated = torch.zeros(E_, dtype=torch.bool, device=self.device)
         # key of the device-side sampler (reset(options={"sampler": "device"}), autoreset).  Unseeded
@@ -384,7 +385,7 @@ class BatchedANMEnv(GymEnv):
         """Convergence of the last power flow of every environment (simulator.pfe_converged in the
         reference): that of the reset right after a reset; after a step an environment has converged iff
         it is not terminated (anm_env.py:421)."""
-        return ~self._term_bool if self._after_step else self._conv_u8.bool()
+        return self._conv_bool
 
     # ---- reset (anm_env.py:235-311) --------------------------------------------------------------------------
     def _launch_reset(self, init_state, mask_u8):
@@ -405,9 +406,16 @@ class BatchedANMEnv(GymEnv):
             else:
                 self._state_same.mul_(1 - mask_u8)
         self._after_step = False
+        # convergence per environment: the environments this reset touched report the reset's power flow, the others
+        # keep what their last step left (not terminated <=> converged, anm_env.py:421)
+        conv = self._conv_u8.bool()
+        if mask_u8 is None or self._conv_bool is None:
+            self._conv_bool = conv
+        else:
+            self._conv_bool = torch.where(mask_u8.bool(), conv, self._conv_bool)
         if self._need_full_reset or self._need_full:
             sim.state = StateView(sim, sim.full)
-            sim.pfe_converged = self._conv_u8.bool()
+            sim.pfe_converged = self._conv_bool
 
     def reset(self, *, seed=None, options=None):
         """Reset every environment (or those selected by ``options["mask"]``).
@@ -546,9 +554,10 @@ class BatchedANMEnv(GymEnv):
             exo_ptr, aux_ptr = exo.data_ptr(), (aux.data_ptr() if self.K > 0 else None)
         self._step_call(action.data_ptr(), exo_ptr, aux_ptr)
         self._after_step = True
+        self._conv_bool = ~self._term_bool
         if self._need_full:
             sim.state = StateView(sim, sim.full)
-            sim.pfe_converged = ~self._term_bool
+            sim.pfe_converged = self._conv_bool
         if self._obs_is_state:
             obs = self._state_obs
         elif self._obs_fused:

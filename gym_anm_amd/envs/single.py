@@ -55,6 +55,10 @@ class ANMEnv(GymEnv):  # gymnasium.Env when gymnasium is installed (wrappers, gy
         # the attributes a constructor hook of the user (observation_bounds) may read exist before the batched
         # environment calls it
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
+        # (anm_env.py:122-130: aux_bounds and costs_clipping exist before observation_bounds() is called -- the
+        # reference's own default implementation reads aux_bounds)
+        self.aux_bounds = aux_bounds
+        self.costs_clipping = costs_clipping
         kw.setdefault("track_full", True)  # `simulator.state` / `.devices[i].p` follow every step, as in the reference
         self.vec = self._make_vec(_Vec, network, batched_obs if obs_fn is not None else observation, K, delta_t, gamma,
                                   lamb, aux_bounds, costs_clipping, seed, device, kw)

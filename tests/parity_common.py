@@ -618,13 +618,32 @@ def single_env_with_callable_observation(kw):
     o, _ = env.reset()
     npt.assert_array_equal(env.observation_space.high, [150.0, 1.0, 1.0])
     npt.assert_allclose(o, np.clip(fn(env.state), env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-12)
+    # the oracle's environment with the same hooks drawing from a twin of the task's generator: same draws in the
+    # same order (init_state until the reset converges, anm_env.py:266-289, then one next_vars per step)
+    twin = np.random.default_rng(17)
+
+    def twin_next_vars(s_t):
+        return np.array([-3 * twin.uniform(), 40 * twin.uniform(), 60 * twin.uniform(), (s_t[-2] + 1) % 50, -s_t[-1]])
+
+    orc = O.OracleEnv(net, delta_t=0.5, gamma=0.95, lamb=100, costs_clipping=(10, 200), aux_bounds=((0, 50), (-1, 1)),
+                      next_vars=twin_next_vars, sparse=False)
+    for _ in range(100):
+        s0 = twin.uniform(size=env.state_N)
+        s0[-2:] = [3.0, 0.5]
+        _, ok = orc.reset_to(s0)
+        if ok:
+            break
+    npt.assert_allclose(env.state, orc.state, rtol=0, atol=1e-9)
     rng = np.random.default_rng(2)
     for t in range(25):
         a = rng.uniform(env.action_space.low, env.action_space.high) * 0.2
         o, r, term, trunc, _ = env.step(a)
+        _, r_o, term_o = orc.step(a)
         assert isinstance(o, np.ndarray) and o.shape == (3,) and isinstance(r, float) and trunc is False
+        assert term == term_o and abs(r - r_o) <= 1e-9 * (1 + abs(r_o)), (t, r, r_o, term, term_o)
         if term:
             break
-        npt.assert_allclose(o, np.clip(fn(env.state), env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-12)
+        npt.assert_allclose(env.state, orc.state, rtol=0, atol=1e-9)          # the state follows the oracle's, step by step
+        npt.assert_allclose(o, np.clip(fn(orc.state), env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-9)
         assert abs(env.state[-2] - (3.0 + t + 1) % 50) < 1e-12          # the aux variables follow next_vars
     return env
