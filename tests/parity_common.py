@@ -647,3 +647,135 @@ def single_env_with_callable_observation(kw):
         npt.assert_allclose(o, np.clip(fn(orc.state), env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-9)
         assert abs(env.state[-2] - (3.0 + t + 1) % 50) < 1e-12          # the aux variables follow next_vars
     return env
+
+
+def bounds_hook_reads_aux_bounds(kw):
+    """anm_env.py:122-139: aux_bounds and costs_clipping are attributes BEFORE observation_bounds() runs -- the
+    reference's own default implementation reads aux_bounds, and so may a user's override."""
+    from gym_anm_amd import ANMEnv
+    from gym_anm_amd.spaces import Box
+
+    net = networks.three_bus_loop_network(base_mva=10, gen_max=100.0)
+    seen = {}
+
+    class Task(ANMEnv):
+        def __init__(self):
+            super().__init__(net, lambda s: s[-1:], 1, 0.5, 0.95, 100, np.array([[2, 9]]), (10, 200), 4, **kw(net))
+
+        def init_state(self):
+            s = np.full(self.state_N, 0.3)
+            s[-1] = 4.0
+            return s
+
+        def next_vars(self, s_t):
+            return np.array([-1.0, 5.0, 5.0, s_t[-1]])
+
+        def observation_bounds(self):
+            seen["aux"], seen["clip"] = np.array(self.aux_bounds), tuple(self.costs_clipping)
+            return Box(low=np.array([self.aux_bounds[0][0]], dtype=float), high=np.array([self.aux_bounds[0][1]], dtype=float))
+
+    env = Task()
+    npt.assert_array_equal(seen["aux"], [[2, 9]])
+    assert seen["clip"] == (10, 200)
+    npt.assert_array_equal(env.observation_space.low, [2.0])
+    o, _ = env.reset()
+    assert o[0] == 4.0
+
+
+def convergence_flags_after_a_masked_reset(kw, E_=512):
+    """BatchedANMEnv.pfe_converged / simulator.pfe_converged after a reset of SOME environments: the ones the reset
+    touched report the reset's power flow, the others what their last step left (converged <=> not terminated)."""
+    import torch
+
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    net = networks.anm6_network()
+    env = ANM6EasyVec(num_envs=E_, seed=11, track_full=True, **kw(net))
+    env.reset(seed=11)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    lo, hi = torch.as_tensor(env.action_space.low), torch.as_tensor(env.action_space.high)
+    for _ in range(40):
+        a = (lo + (hi - lo) * torch.rand((E_, 6), generator=g, dtype=torch.float64)).to(env.device)
+        env.step(a)
+        if int(env.terminated.sum()) >= 2:
+            break
+    term = env.terminated.clone()
+    assert int(term.sum()) >= 2, "the random agent collapses ~0.5 % of the environments per step"
+    idx = torch.nonzero(term).flatten()
+    mask = torch.zeros(E_, dtype=torch.bool, device=env.device)
+    mask[idx[0]] = True          # reset ONE of the collapsed environments (and one healthy one)
+    healthy = torch.nonzero(~term).flatten()[0]
+    mask[healthy] = True
+    env.reset(options={"mask": mask})
+    conv = env.pfe_converged
+    assert bool(conv[idx[0]]) and bool(conv[healthy])                       # freshly reset: converged
+    assert not bool(conv[idx[1]])                                           # still collapsed, not touched by the reset
+    others = ~mask
+    assert torch.equal(conv[others], ~term[others])
+    assert torch.equal(env.simulator.pfe_converged[others], ~term[others])
+
+
+def general_step_with_wide_rows(kw):
+    """8 buses, 9 devices: the electrical-state rows of 64 environments (113 doubles each) plus their state rows are
+    69 632 bytes of dynamic LDS for k_step_general -- more than the 64 KB a workgroup gets by default.  A list
+    observation with the dump (the default of the single-environment class) against the oracle."""
+    import anm_oracle as O
+    import torch
+
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+    from gym_anm_amd.model import NetworkModel
+
+    net = networks.synthetic_radial_network(8, 3)
+    dev = [list(r) for r in net["device"]]
+    N_ = None
+    while len(dev) < 9:   # more loads until the rows are wide enough
+        dev.append([len(dev), 2 + len(dev) % 5, -1, 0.2, 0, -4.0 - len(dev), N_, N_, N_, N_, N_, N_, N_, N_, N_])
+    net["device"] = np.array(dev, dtype=object)
+    E_ = 192
+    spec = [("bus_v_magn", "all", "pu"), ("branch_s", "all", "MVA"), ("dev_p", "all", "MW"), ("bus_v_ang", "all", "rad")]
+    m = NetworkModel(net, 0.25, 100)
+    n_exo = len(m.load_idx) + len(m.gen_idx)
+
+    class Task(BatchedANMEnv):
+        def __init__(self):
+            super().__init__(net, spec, 0, 0.25, 0.99, 100, None, (1, 100), 5, num_envs=E_, track_full=True, **kw(net))
+            self._g = torch.Generator(device="cpu").manual_seed(9)
+
+        def init_state(self):
+            s = torch.zeros((E_, self.state_N), dtype=torch.float64)
+            s[:, : 2 * m.N_device] = 0.0
+            return s.numpy()
+
+        def next_vars(self, s_t):
+            u = torch.rand((E_, n_exo), generator=self._g, dtype=torch.float64)
+            lo = torch.as_tensor(np.concatenate((m.dev_p_min[m.load_idx], 0 * m.dev_p_max[m.gen_idx])) * m.baseMVA)
+            hi = torch.as_tensor(np.concatenate((0 * m.dev_p_min[m.load_idx], m.dev_p_max[m.gen_idx])) * m.baseMVA)
+            self.last_exo = (lo + (hi - lo) * u).numpy()
+            return self.last_exo
+
+    env = Task()
+    dims_full = env.simulator.full_dim
+    assert (64 * ((dims_full + 8) | 1) + 64 * ((env.state_N + 8) | 1)) * 8 > 64 * 1024   # the case this test is about
+    env.reset()
+    n = O.parse_network(net, 0.25, 100)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    lo, hi = torch.as_tensor(env.action_space.low), torch.as_tensor(env.action_space.high)
+    soc = env.simulator.soc.cpu().numpy().copy()
+    for t in range(3):
+        a = lo + (hi - lo) * torch.rand((E_, len(lo)), generator=g, dtype=torch.float64) * 0.5
+        o, r, term, _, _ = env.step(a.to(env.device))
+        full = env.simulator.state
+        vm = full.tensor("bus_v_magn", "pu").cpu().numpy()
+        for e in range(0, E_, 37):
+            ng, nd = len(m.gen_idx), len(m.des_idx)
+            P_set = {k: a[e, j].item() for j, k in enumerate(list(m.gen_idx))}
+            P_set.update({k: a[e, 2 * ng + j].item() for j, k in enumerate(list(m.des_idx))})
+            Q_set = {k: a[e, ng + j].item() for j, k in enumerate(list(m.gen_idx))}
+            Q_set.update({k: a[e, 2 * ng + nd + j].item() for j, k in enumerate(list(m.des_idx))})
+            out = O.transition(n, env.last_exo[e, : len(m.load_idx)], env.last_exo[e, len(m.load_idx):],
+                               [P_set[k] for k in n.setp], [Q_set[k] for k in n.setp], soc[e], sparse=False)
+            if out["converged"] and not bool(term[e]):
+                npt.assert_allclose(vm[e], np.abs(out["V"]), rtol=0, atol=1e-9)
+                npt.assert_allclose(o[e, : m.N_bus].cpu().numpy(), np.clip(np.abs(out["V"]), env.observation_space.low[: m.N_bus],
+                                                                          env.observation_space.high[: m.N_bus]), rtol=0, atol=1e-9)
+        soc = env.simulator.soc.cpu().numpy().copy()

@@ -332,3 +332,15 @@ def test_mesh_random_meshed_networks_against_oracle(n_bus, seed, n_chords):
         npt.assert_allclose(full[e, sl["branch_s"]], ref["br_s"], rtol=0, atol=1e-9)
         npt.assert_allclose(float(sim.reward[e]), ref["reward"], rtol=1e-9, atol=1e-9)
     assert n_conv >= M // 2
+
+
+def test_bounds_hook_reads_aux_bounds():
+    pc.bounds_hook_reads_aux_bounds(KW)
+
+
+def test_convergence_flags_after_a_masked_reset():
+    pc.convergence_flags_after_a_masked_reset(KW, E_=4096)
+
+
+def test_general_step_with_rows_wider_than_the_default_lds_limit():
+    pc.general_step_with_wide_rows(KW)

@@ -753,3 +753,15 @@ def test_bad_observation_specs_fail_like_the_live_reference():
 
 def test_single_environment_class_with_callable_observation():
     pc.single_env_with_callable_observation(_KW)
+
+
+def test_bounds_hook_reads_aux_bounds():
+    pc.bounds_hook_reads_aux_bounds(_KW)
+
+
+def test_convergence_flags_after_a_masked_reset():
+    pc.convergence_flags_after_a_masked_reset(_KW)
+
+
+def test_general_step_with_rows_wider_than_the_default_lds_limit():
+    pc.general_step_with_wide_rows(_KW)
