@@ -48,7 +48,7 @@ class EnvConfig(C.Structure):
 
 
 class StepWs(C.Structure):
-    _fields_ = [("buf", C.c_void_p), ("n_doubles", C.c_int64), ("iter_cap", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("buf", C.c_void_p), ("n_doubles", C.c_int64), ("iter_cap", C.c_int32), ("mid_cap", C.c_int32)]
 
 
 class MpcDims(C.Structure):

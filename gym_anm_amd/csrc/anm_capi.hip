@@ -41,6 +41,9 @@ int fail_hip(hipError_t e, const char* where) {
 #ifndef ANM_HANDOFF_DEFAULT
 #define ANM_HANDOFF_DEFAULT 6
 #endif
+#ifndef ANM_MID_CAP_DEFAULT
+#define ANM_MID_CAP_DEFAULT 12  // where the first straggler launch leaves the solves still running to the second
+#endif
 #ifndef ANM_ROWS_WAVES
 #define ANM_ROWS_WAVES 1  // min. waves per SIMD the step kernel is compiled for (register budget 512 / waves)
 #endif
@@ -78,9 +81,9 @@ __global__ __launch_bounds__(BLOCK) void k_step_general(cptr_t C0, EnvIO io, Sol
 }
 
 template <class JT, bool GROUPS>
-__global__ __launch_bounds__(BLOCK) void k_step_stragglers(cptr_t C, EnvIO io, SolverOpts so) {
+__global__ __launch_bounds__(BLOCK) void k_step_stragglers(cptr_t C, EnvIO io, SolverOpts so, int level) {
   __shared__ double lds[GROUPS ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
-  op_step_stragglers<Topo, JT, GROUPS>(C, io, so, lds);
+  op_step_stragglers<Topo, JT, GROUPS>(C, io, so, lds, level);
 }
 
 __global__ void k_step_scatter(EnvIO io) { op_step_scatter<Topo>(io); }
@@ -796,11 +799,15 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   }
   io.ws = nullptr;
   if (ws && ws->buf && m->tpe_ok && !m->d_env_class) {  // (the straggler launch packs records of all blocks together)
-    const int64_t cap = (ws->n_doubles - Rec<Topo>::HEADER) / Rec<Topo>::SIZE;
+    // records, then the int32 list of the records the first straggler launch leaves to the second
+    const int64_t cap = 2 * (ws->n_doubles - Rec<Topo>::HEADER) / (2 * Rec<Topo>::SIZE + 1);
     if (cap < 1 || ws->iter_cap < 1) return fail("anm_step_f64: step workspace too small or iter_cap < 1");
     io.ws = ws->buf;
     io.ws_cap = cap;
     io.iter_cap = ws->iter_cap;
+    io.ws_list2 = reinterpret_cast<int32_t*>(ws->buf + Rec<Topo>::HEADER + cap * Rec<Topo>::SIZE);
+    io.mid_cap = ws->mid_cap == 0 ? ANM_MID_CAP_DEFAULT : (ws->mid_cap < 0 ? 0 : ws->mid_cap);
+    if (io.mid_cap > 0 && io.mid_cap <= io.iter_cap) io.mid_cap = 0;
   }
   return 0;
 }
@@ -835,22 +842,26 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
       const bool groups = CAN_GROUP && so.handoff >= 0;
       const int per_block = groups ? group::Shape<Topo>::NG : BLOCK;
       const unsigned g2 = unsigned((io.ws_cap + per_block - 1) / per_block);  // covers every record
-      if constexpr (CAN_GROUP) {
-        if (groups) {
-          if (prec == ANM_SOLVE_F32)
-            hipLaunchKernelGGL((k_step_stragglers<float, true>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
-          else
-            hipLaunchKernelGGL((k_step_stragglers<double, true>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
+      const bool two_level = groups && io.mid_cap > 0 && io.mid_cap < so.max_iter;
+      for (int level = 1; level <= (two_level ? 2 : 1); ++level) {
+        const unsigned g = g2;  // (level 2: most wavefronts find nothing and leave)
+        if constexpr (CAN_GROUP) {
+          if (groups) {
+            if (prec == ANM_SOLVE_F32)
+              hipLaunchKernelGGL((k_step_stragglers<float, true>), dim3(g), dim3(BLOCK), 0, s, C, io, so, level);
+            else
+              hipLaunchKernelGGL((k_step_stragglers<double, true>), dim3(g), dim3(BLOCK), 0, s, C, io, so, level);
+          }
         }
+        if (!groups) {
+          if (prec == ANM_SOLVE_F32)
+            hipLaunchKernelGGL((k_step_stragglers<float, false>), dim3(g), dim3(BLOCK), 0, s, C, io, so, level);
+          else
+            hipLaunchKernelGGL((k_step_stragglers<double, false>), dim3(g), dim3(BLOCK), 0, s, C, io, so, level);
+        }
+        e2 = hipGetLastError();
+        if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_stragglers");
       }
-      if (!groups) {
-        if (prec == ANM_SOLVE_F32)
-          hipLaunchKernelGGL((k_step_stragglers<float, false>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
-        else
-          hipLaunchKernelGGL((k_step_stragglers<double, false>), dim3(g2), dim3(BLOCK), 0, s, C, io, so);
-      }
-      e2 = hipGetLastError();
-      if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_stragglers");
       const unsigned g3 = unsigned((io.ws_cap + 255) / 256);
       hipLaunchKernelGGL(k_step_scatter, dim3(g3), dim3(256), 0, s, io);
       e2 = hipGetLastError();

@@ -152,6 +152,8 @@ struct EnvIO {
   double* ws;               // two-phase step: workspace (counters + straggler records) or null
   int64_t ws_cap;           // number of straggler records the workspace can hold
   int iter_cap;             // two-phase step: Newton iterations done by the first launch
+  int mid_cap;              // ... by the first straggler launch (0: it runs every record to the end, one level)
+  int32_t* ws_list2;        // records the first straggler launch did not finish (count: counter 2 of the header)
 };
 
 // Split an init_state row (anm_env.py / simulator.py:248-268) into transition inputs.
@@ -879,8 +881,15 @@ __device__ void op_step_general(cptr_t C, const EnvIO& io, SolverOpts so, int64_
 // lane group is half as long as a thread's, and these solves are the ones that run ~94 more of them; the
 // records of a million environments still fill the chip 8 per wavefront.  Otherwise: 64 records per
 // wavefront, one per thread.
+// Two levels (GROUPS, io.mid_cap > 0).  A wavefront runs until its LAST group is done, and of the solves handed
+// over, most are slow convergers (a few more iterations) while the diverging ones run to the reference's cap: one
+// of those among its eight records keeps a wavefront for ~94 trips.  So the first straggler launch (level 1) stops
+// at mid_cap iterations, saves the iterates of the records still running back into their records and lists them;
+// a second launch (level 2) takes the listed records, again 8 per wavefront -- now all long runners -- to the end.
+// 1 M environments: ~20 000 records at hand-over, ~5 000 of them diverging: 2 500 wavefronts x 94 trips become
+// 2 500 x 6 + 625 x 88.  Restarting from a saved iterate is bit-transparent (the first trip evaluates F of it).
 template <class T, class JT, bool GROUPS>
-__device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so, double* lds) {
+__device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so, double* lds, int level) {
   constexpr int S = T::SDIM + 1;
   int* cnt = reinterpret_cast<int*>(io.ws);
   int n_rec = cnt[0];
@@ -888,52 +897,67 @@ __device__ void op_step_stragglers(cptr_t C, const EnvIO& io, SolverOpts so, dou
   // The count is handed to the scatter launch in cnt[1] so that the scatter launch can zero cnt[0] for the
   // next step: every step leaves the counters as it found them (no host-side parity, no memset), which is
   // what makes one captured step replayable from a HIP graph any number of times.
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[1] = n_rec;
-  StepCtx<T> ctx;
-  PFState<T> st;
-  EnvWork<T> w;
-  StepOut<T, 1> out;
-  int64_t j, e = 0;
-  bool mine;
-  if constexpr (GROUPS) {
-    constexpr int NG = group::Shape<T>::NG;
-    const int lane = threadIdx.x & 63;
-    j = int64_t(blockIdx.x) * NG + lane;
-    mine = lane < NG && j < n_rec;
-    if (!ANM_WAVE_ANY(mine)) return;
-  } else {
-    // Dense packing: 64 consecutive records per wavefront.  Measured alternatives (MI355X): dealing the
-    // records one per wavefront makes every thread-mode iteration 2-3x slower once several sparse wavefronts
-    // share a CU (issue stalls, SQ_WAIT_INST_ANY 60 %), although each wave then only runs the sin/cos tier its
-    // own solve needs.  One record per thread, no loop: the Newton loop keeps every value in registers.
-    j = int64_t(blockIdx.x) * 64 + threadIdx.x;
-    mine = j < n_rec;
-    if (!mine) return;
-  }
-  double* r = io.ws + Rec<T>::HEADER + (mine ? j : 0) * Rec<T>::SIZE;
-  if (mine) e = load_record<T>(r, ctx, w, st);
-  if constexpr (GROUPS) {
-    // (the first trip of newton_groups evaluates F of the saved iterate before anything else)
-    st.active = mine;
-    group::continue_in_groups<T, JT>(C, w, st, mine, so.tol, so.max_iter, lds);
-    if (!mine) return;
-    w.vr[0] = 1.0;   // the slack bus: what eval_mismatch leaves there (continue_in_groups restores the others)
-    w.vi[0] = 0.0;
-  } else {
-    st.fresh = true;  // F and diff of the saved iterate are recomputed (same code, same inputs, same bits)
-    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
-  }
-  step_end<T, 1>(C, io, so, e, ctx, w, st, out);
-  // The results go back into the record (r[0] keeps the environment index); the scatter launch
-  // writes them to the batch arrays.  Keeping the dozen output pointers out of this kernel keeps its
-  // Newton loop free of scalar-register spills.
-  typedef ResRec<T> Q;
-  static_for<0, S>([&](auto K) { r[Q::STATE + K] = out.state[K]; r[Q::OBS + K] = out.obs[K]; });
-  static_for<0, T::NDES>([&](auto I) { r[Q::SOC + I] = out.soc[I]; });
-  r[Q::REWARD] = out.reward; r[Q::ELOSS] = out.e_loss; r[Q::PENALTY] = out.penalty;
-  r[Q::NITER] = double(out.n_iter); r[Q::TERM] = double(out.terminated); r[Q::TSOP] = double(out.timestep_op);
-  r[Q::FLAGS] = double((out.write_state ? 1 : 0) | (out.write_obs ? 2 : 0) | (out.write_costs ? 4 : 0) |
-                       (out.write_soc ? 8 : 0) | (out.inc_reset ? 16 : 0));
+  if (level == 1 && blockIdx.x == 0 && threadIdx.x == 0) cnt[1] = n_rec;
+  const bool two_level = GROUPS && io.mid_cap > 0 && io.mid_cap < so.max_iter;
+  const int n_work = level == 2 ? cnt[2] : n_rec;
+  const int cap = (level == 1 && two_level) ? io.mid_cap : so.max_iter;
+  constexpr int PER = GROUPS ? group::Shape<T>::NG : 64;
+  // (one pass: the grid covers the workspace; a loop over passes costs the kernel its second wavefront per SIMD)
+  const int64_t base = int64_t(blockIdx.x) * PER;
+  if (base >= n_work) return;
+  do {
+    StepCtx<T> ctx;
+    PFState<T> st;
+    EnvWork<T> w;
+    StepOut<T, 1> out;
+    int64_t j, e = 0;
+    bool mine;
+    if constexpr (GROUPS) {
+      const int lane = threadIdx.x & 63;
+      j = base + lane;
+      mine = lane < PER && j < n_work;
+    } else {
+      // Dense packing: 64 consecutive records per wavefront.  Measured alternatives (MI355X): dealing the
+      // records one per wavefront makes every thread-mode iteration 2-3x slower once several sparse wavefronts
+      // share a CU (issue stalls, SQ_WAIT_INST_ANY 60 %), although each wave then only runs the sin/cos tier its
+      // own solve needs.  One record per thread: the Newton loop keeps every value in registers.
+      j = base + threadIdx.x;
+      mine = j < n_work;
+    }
+    if (level == 2 && mine) j = io.ws_list2[j];
+    double* r = io.ws + Rec<T>::HEADER + (mine ? j : 0) * Rec<T>::SIZE;
+    if (mine) e = load_record<T>(r, ctx, w, st);
+    if constexpr (GROUPS) {
+      // (the first trip of newton_groups evaluates F of the saved iterate before anything else)
+      st.active = mine;
+      group::continue_in_groups<T, JT>(C, w, st, mine, so.tol, cap, lds);
+      if (!mine) continue;
+      if (cap < so.max_iter && st.diff == INFINITY) {  // stopped by mid_cap, still running: level 2 takes it
+        typedef Rec<T> R;
+        r[R::IT] = double(st.it);
+        static_for<0, T::NB>([&](auto I) { r[R::VM + I] = w.vm[I]; r[R::CS + I] = st.cs[I]; r[R::SN + I] = st.sn[I]; });
+        io.ws_list2[atomicAdd(cnt + 2, 1)] = int32_t(j);
+        continue;
+      }
+      w.vr[0] = 1.0;   // the slack bus: what eval_mismatch leaves there (continue_in_groups restores the others)
+      w.vi[0] = 0.0;
+    } else {
+      if (!mine) continue;
+      st.fresh = true;  // F and diff of the saved iterate are recomputed (same code, same inputs, same bits)
+      pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
+    }
+    step_end<T, 1>(C, io, so, e, ctx, w, st, out);
+    // The results go back into the record (r[0] keeps the environment index); the scatter launch
+    // writes them to the batch arrays.  Keeping the dozen output pointers out of this kernel keeps its
+    // Newton loop free of scalar-register spills.
+    typedef ResRec<T> Q;
+    static_for<0, S>([&](auto K) { r[Q::STATE + K] = out.state[K]; r[Q::OBS + K] = out.obs[K]; });
+    static_for<0, T::NDES>([&](auto I) { r[Q::SOC + I] = out.soc[I]; });
+    r[Q::REWARD] = out.reward; r[Q::ELOSS] = out.e_loss; r[Q::PENALTY] = out.penalty;
+    r[Q::NITER] = double(out.n_iter); r[Q::TERM] = double(out.terminated); r[Q::TSOP] = double(out.timestep_op);
+    r[Q::FLAGS] = double((out.write_state ? 1 : 0) | (out.write_obs ? 2 : 0) | (out.write_costs ? 4 : 0) |
+                         (out.write_soc ? 8 : 0) | (out.inc_reset ? 16 : 0));
+  } while (false);
 }
 
 // third launch: scatter the straggler results to the batch arrays
@@ -943,7 +967,10 @@ __device__ void op_step_scatter(const EnvIO& io) {
   typedef ResRec<T> Q;
   int* cnt = reinterpret_cast<int*>(io.ws);
   const int n_rec = cnt[1];  // written by the straggler launch (already clamped to the workspace)
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[0] = 0;  // nobody reads cnt[0] in this launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // nobody reads these in this launch
+    cnt[0] = 0;
+    cnt[2] = 0;
+  }
   const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (j >= n_rec) return;
   const double* r = io.ws + Rec<T>::HEADER + j * Rec<T>::SIZE;

@@ -89,7 +89,7 @@ def check_env_args(K, delta_t, lamb, gamma, observation, aux_bounds, state_bound
 class BatchedANMEnv(GymEnv):
     def __init__(self, network, observation, K, delta_t, gamma, lamb, aux_bounds=None, costs_clipping=None, seed=None,
                  num_envs=1, device="cuda", tol=1e-5, max_iter=100, precision="f64", autoreset=False, series=None,
-                 env_offset=0, impl=None, straggler_after="auto", handoff_after="auto", track_full=False,
+                 env_offset=0, impl=None, straggler_after="auto", straggler_mid="auto", handoff_after="auto", track_full=False,
                  fuse_observation=True, variants=None, env_variant=None, _backend=None):  # fmt: skip
         GymEnv.reset(self, seed=seed)
         self.K, self.gamma, self.lamb, self.delta_t = K, gamma, lamb, delta_t
@@ -222,8 +222,16 @@ class BatchedANMEnv(GymEnv):
             # records for 1/16 of the batch (~1.5 % of the solves are still running after 6 iterations; a solve
             # that finds no record continues on a lane group of its own wavefront)
             n_rec = min(self.num_envs, max(4096, self.num_envs // 16))
-            self._ws_buf = torch.zeros(8 + n_rec * rec, dtype=torch.float64, device=self.device)
-            self._ws = _lib.StepWs(self._ws_buf.data_ptr(), self._ws_buf.numel(), int(straggler_after), 0)
+            self._ws_buf = torch.zeros(8 + n_rec * rec + (n_rec + 1) // 2, dtype=torch.float64, device=self.device)
+            # straggler_mid: where the first straggler launch leaves the solves still running to a second one (None:
+            # one level).  Measured (profiles/r03_f_throughput.txt): the straggler launch is bound by the 94-trip
+            # chain of a diverging solve up to 524 288 environments -- a second level only adds a launch there (132 /
+            # 158 / 206 us against 121 / 146 / 194) -- and by instruction issue at 1 M, where repacking the long
+            # runners 8 per wavefront pays (298 against 318 us): "auto" = two levels from 1 M environments on
+            if straggler_mid == "auto":
+                straggler_mid = 12 if self.num_envs >= 1000000 else None
+            mid = -1 if straggler_mid is None else int(straggler_mid)
+            self._ws = _lib.StepWs(self._ws_buf.data_ptr(), self._ws_buf.numel(), int(straggler_after), mid)
             self._ws_ref = C.byref(self._ws)
         self._opts_ref = C.byref(sim.opts)
 

@@ -198,14 +198,16 @@ int anm_reset_f64(anm_model* m, int64_t num_envs, const double* init_state, cons
  * handoff_after), else one record per thread (bit-identical to the one-launch step without hand-over).
  * An environment that finds no free record is finished by the first launch itself.
  * buf: device memory, zero-initialised once by the caller; n_doubles >= 8 + records * record size
- * (anm_step_ws_record_doubles()).  Every step leaves the record counters at the head of the buffer as
+ * (anm_step_ws_record_doubles(); half a double per record of it holds the second level's list).  Every step leaves the record counters at the head of the buffer as
  * it found them (the last launch of a step zeroes the count), so a captured step can be replayed from
  * a HIP graph any number of times; one workspace serves one stream at a time. */
 typedef struct anm_step_ws {
   double* buf;
   int64_t n_doubles;
   int32_t iter_cap;
-  int32_t reserved;
+  int32_t mid_cap;   /* lane-group stragglers in two levels: the first straggler launch stops at mid_cap iterations and
+                        leaves the solves still running (the diverging ones, which run to the cap) to a second one that
+                        packs them 8 per wavefront again.  0 = library default (12), < 0 = one level */
 } anm_step_ws;
 int anm_step_ws_record_doubles(void);
 
