@@ -99,6 +99,7 @@ ABI = {
     "anm_step_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 13 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,
                                                                       C.POINTER(StepWs), C.POINTER(SolverOpts), _P]),
     "anm_model_set_classes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(NetworkDesc))]),
+    "anm_model_set_class_obs_bounds": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p]),
     "anm_model_bind_env_classes": (C.c_int, [C.c_void_p, _P, C.c_int64]),
     "anm_model_bind_state_same": (C.c_int, [C.c_void_p, _P]),
     "anm_model_obs_fusable": (C.c_int, [C.c_void_p]),

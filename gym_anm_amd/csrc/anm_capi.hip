@@ -545,6 +545,27 @@ int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_des
   return upload_const(m);
 }
 
+int anm_model_set_class_obs_bounds(anm_model* m, int32_t cls, const double* low, const double* high) {
+  if (!m || !low || !high) return fail("anm_model_set_class_obs_bounds: null argument");
+  if (!m->env_set) return fail("anm_model_set_class_obs_bounds: call anm_model_set_env first (it writes every class)");
+  const int n_cls = 1 + int(std::max(std::max(m->x_const.size(), m->x_hd.size()), m->x_md.size()));
+  if (cls < 0 || cls >= n_cls) return fail("anm_model_set_class_obs_bounds: no such class");
+  if (m->tpe_ok) {
+    typedef Layout<Topo> L;
+    std::vector<double>& c = cls == 0 ? m->h_const : m->x_const[cls - 1];
+    for (int k = 0; k < Topo::SDIM + m->K; ++k) { c[L::OBS_LO + k] = low[k]; c[L::OBS_HI + k] = high[k]; }
+  }
+  if (m->radial_ok) {
+    std::vector<double>& h = cls == 0 ? m->plan.hd : m->x_hd[cls - 1];
+    for (int k = 0; k < m->plan.d.SDIM + m->K; ++k) { h[m->plan.d.off_obs_lo + k] = low[k]; h[m->plan.d.off_obs_hi + k] = high[k]; }
+  }
+  if (m->mesh_ok) {
+    std::vector<double>& h = cls == 0 ? m->mplan.hd : m->x_md[cls - 1];
+    for (int k = 0; k < m->mplan.d.SDIM + m->K; ++k) { h[m->mplan.d.off_obs_lo + k] = low[k]; h[m->mplan.d.off_obs_hi + k] = high[k]; }
+  }
+  return upload_const(m);
+}
+
 int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t num_envs) {
   if (!m) return fail("anm_model_bind_env_classes: null model");
   if (!env_class) {

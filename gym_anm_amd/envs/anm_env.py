@@ -167,6 +167,24 @@ class BatchedANMEnv(GymEnv):
         self._cfg_keep = (slo, shi)
         with sim._device_ctx():
             sim.backend.check(sim.backend.lib.anm_model_set_env(sim._handle, C.byref(cfg)), "anm_model_set_env")
+        # parameter classes: the reference builds one environment per network, each clipping its observation to the
+        # Box of ITS network (anm_env.py:193-233, 313-331).  For the "state" observation every class gets its own
+        # bounds; `class_observation_bounds` has them ([n_classes, state_N] each).  (observation_space itself, one
+        # Box for the batch, stays that of class 0; list-form observations keep one Box.)
+        self.class_observation_bounds = None
+        vms = getattr(sim, "variant_models", [sim.model])
+        if len(vms) > 1 and self._obs_is_state and type(self).observation_bounds is BatchedANMEnv.observation_bounds:
+            los, his = [slo], [shi]
+            with sim._device_ctx():
+                for k, vm in enumerate(vms[1:], start=1):
+                    lo_k, hi_k = self._state_bounds_vectors(vm.state_bounds())
+                    a_lo, p_lo = _lib.as_c(lo_k, np.float64)
+                    a_hi, p_hi = _lib.as_c(hi_k, np.float64)
+                    sim.backend.check(sim.backend.lib.anm_model_set_class_obs_bounds(sim._handle, k, p_lo, p_hi),
+                                      "anm_model_set_class_obs_bounds")
+                    los.append(lo_k)
+                    his.append(hi_k)
+            self.class_observation_bounds = (np.stack(los), np.stack(his))
         # list-form observations (anm_env.py:497-521): gathered, scaled and clipped inside the step kernel when
         # the library can (anm_model_set_obs), else by anm_gather_obs_f64 from the electrical-state dump
         self._gather = None  # (index, scale, low, high) device tensors
@@ -304,10 +322,11 @@ class BatchedANMEnv(GymEnv):
                 values[idx] = (o[0], ids, o[2])
         return values
 
-    def _state_bounds_vectors(self):
-        """Box bounds of the *state* vector, used when the observation is the state."""
+    def _state_bounds_vectors(self, bounds=None):
+        """Box bounds of the *state* vector, used when the observation is the state (``bounds``: the state bounds of
+        another network of the same topology: a parameter class)."""
         lo, hi = [], []
-        bounds = self.simulator.state_bounds
+        bounds = self.simulator.state_bounds if bounds is None else bounds
         for key, nodes, unit in self.state_values:
             for n in nodes:
                 if key == "aux":

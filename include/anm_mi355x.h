@@ -136,6 +136,11 @@ int anm_model_get_ybus(const anm_model* m, double* y_host);
  * scalar loads, so classes cost nothing in the kernels.  NULL unbinds (all environments: class 0).  The
  * two-launch step (anm_step_ws) is not used while classes are bound. */
 int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_desc* const* descs);
+/* anm_model_set_env gives every class the same observation Box (that of the cfg).  The reference builds one
+ * environment per network, each with the Box of ITS network (anm_env.py:193-233, simulator.py:382-462): this
+ * call sets the bounds of one class (host arrays of state_base_dim + K entries, the "state" observation;
+ * list-form observations keep one Box, anm_model_set_obs).  After anm_model_set_env. */
+int anm_model_set_class_obs_bounds(anm_model* m, int32_t cls, const double* low, const double* high);
 int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t num_envs);
 
 /* The observation of the "state" form is clip(state, Box): the same numbers as the state row except when a

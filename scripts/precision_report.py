@@ -23,10 +23,11 @@ def inputs(sim, seed):
     return pl, pp, ps, qs, soc
 
 
-def run(net, E, tol, name):
+def run(net, E, tol, name, impl=None):
     out = {}
     for prec in ("f64", "f32"):
-        sim = BatchedSimulator(net, 0.25, 100, num_envs=E, device=DEV, tol=tol, precision=prec)
+        sim = BatchedSimulator(net, 0.25, 100, num_envs=E, device=DEV, tol=tol, precision=prec, impl=impl)
+        family = sim.impl
         pl, pp, ps, qs, soc = inputs(sim, 0)
         sim.soc.copy_(soc)
         sim.transition(pl, pp, ps, qs)
@@ -42,7 +43,7 @@ def run(net, E, tol, name):
                          conv=conv.clone(), it=sim.nr_iters.clone(), r=r.clone(), dt=dt)
     a, b = out["f64"], out["f32"]
     both = a["conv"] & b["conv"]
-    print("== %s: %d envs, tol %.0e, full-state transition kernel" % (name, E, tol))
+    print("== %s: %d envs, tol %.0e, full-state transition kernel, %s family" % (name, E, tol, family))
     print("   converged: f64 %d  f32 %d  flag mismatches %d" % (int(a["conv"].sum()), int(b["conv"].sum()), int((a["conv"] != b["conv"]).sum())))
     for k, lab in (("vm", "|V| (p.u.)"), ("va", "theta (rad)"), ("bp", "branch P (p.u.)"), ("bs", "branch S (p.u.)")):
         d = (a[k] - b[k]).abs()[both]
@@ -54,8 +55,12 @@ def run(net, E, tol, name):
         print("   %s iterations histogram (converged): %s   kernel+copy %.1f us/launch" % (prec, dict(zip(*np.unique(it, return_counts=True))), out[prec]["dt"] * 1e6))
 
 
-run(networks.anm6_network(), 65536, 1e-5, "ANM6 (reference stop rule)")
-run(networks.anm6_network(), 65536, 1e-6, "ANM6 (metric stop rule)")
-run(networks.anm6_network(), 65536, 1e-9, "ANM6 (tight)")
-run(networks.synthetic_radial_network(30, 0), 16384, 1e-5, "30-bus radial feeder")
-run(networks.synthetic_radial_network(30, 0), 16384, 1e-9, "30-bus radial feeder (tight)")
+for impl in ("thread", "radial", "mesh"):   # the three kernel families (round 2: lane-group continuation, mesh family)
+    run(networks.anm6_network(), 65536, 1e-5, "ANM6 (reference stop rule)", impl)
+    run(networks.anm6_network(), 65536, 1e-6, "ANM6 (metric stop rule)", impl)
+run(networks.anm6_network(), 65536, 1e-9, "ANM6 (tight)", "thread")
+for impl in ("radial", "mesh"):
+    run(networks.synthetic_radial_network(30, 0), 16384, 1e-5, "30-bus radial feeder", impl)
+    run(networks.synthetic_radial_network(30, 0), 16384, 1e-9, "30-bus radial feeder (tight)", impl)
+run(networks.synthetic_meshed_network(30, 0, 4), 16384, 1e-5, "meshed 30-bus network", "mesh")
+run(networks.synthetic_meshed_network(30, 0, 4), 16384, 1e-9, "meshed 30-bus network (tight)", "mesh")

@@ -197,6 +197,9 @@ int anm_time_step_launches(anm_model*, int64_t, const double*, double*, double*,
 int anm_model_set_classes(anm_model*, int32_t n_classes, const anm_network_desc* const*) {
   return n_classes > 1 ? fail("the host test double has no parameter classes") : 0;
 }
+int anm_model_set_class_obs_bounds(anm_model*, int32_t cls, const double*, const double*) {
+  return cls > 0 ? fail("the host test double has no parameter classes") : 0;
+}
 int anm_model_bind_env_classes(anm_model*, const int32_t* env_class, int64_t) {
   return env_class ? fail("the host test double has no parameter classes") : 0;
 }

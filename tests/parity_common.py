@@ -470,10 +470,13 @@ def heterogeneous_networks(kw, n_variants=64, per_variant=64, n_check=2, impl=No
     for e in picks:
         o = O.OracleEnv(nets[e // per_variant], sparse=False)
         o.load_state(s0[e], c0[e])
-        # the observation Box of the batch is that of the base network (documented): clip like it
-        o.obs_low, o.obs_high = env.observation_space.low, env.observation_space.high
+        # every environment clips its observation to the Box of ITS network, like the reference's one environment per
+        # network (anm_env.py:193-233, 313-331): the oracle's own bounds are the class's
+        npt.assert_array_equal(env.class_observation_bounds[0][e // per_variant], o.obs_low)
+        npt.assert_array_equal(env.class_observation_bounds[1][e // per_variant], o.obs_high)
         oracles[e] = o
     gen = torch.Generator(device=env.device).manual_seed(6)
+    n_bites = 0
     for t in range(4):
         a = uniform_actions(env, gen)
         obs, rew, term, _, _ = env.step(a)
@@ -482,6 +485,10 @@ def heterogeneous_networks(kw, n_variants=64, per_variant=64, n_check=2, impl=No
             assert tt == bool(term[e])
             npt.assert_allclose(obs[e].cpu().numpy(), oo, rtol=0, atol=1e-8)
             npt.assert_allclose(float(rew[e]), rr, rtol=1e-9, atol=1e-9)
+            if not tt:  # a bound of the class's own Box that class 0's Box would not have applied (or the reverse)
+                base_clip = np.clip(o.state, env.observation_space.low, env.observation_space.high)
+                n_bites += int(np.abs(base_clip - oo).max() > 1e-6)
+    assert n_bites > 0, "no environment was clipped differently by its own Box than by the Box of class 0"
     return sim
 
 
