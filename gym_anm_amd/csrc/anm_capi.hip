@@ -138,6 +138,7 @@ struct anm_model {
   std::vector<std::vector<double>> x_const;   // thread-per-environment constants of each extra class
   std::vector<std::vector<double>> x_hd;      // lane-group tables of each extra class
   const int32_t* d_env_class = nullptr;       // caller's device array [num_envs] (anm_model_bind_env_classes)
+  bool class_per_env = false;                 // the classes do not come in aligned blocks of 64 environments
   uint8_t* d_state_same = nullptr;            // caller's device array [num_envs] (anm_model_bind_state_same)
   int32_t* d_zero = nullptr;                  // one zero: the class of every environment when no classes are bound
   std::vector<cplx> ybus;
@@ -178,8 +179,8 @@ int upload_const(anm_model* m) {
 }
 
 ClassSel class_sel(const anm_model* m, bool radial) {
-  if (!m->d_env_class) return ClassSel{m->d_zero, 0, 0};
-  return ClassSel{m->d_env_class, radial ? int(m->plan.hd.size()) : int(m->h_const.size()), 1};
+  if (!m->d_env_class) return ClassSel{m->d_zero, 0, 0, 0};
+  return ClassSel{m->d_env_class, radial ? int(m->plan.hd.size()) : int(m->h_const.size()), 1, m->class_per_env ? 1 : 0};
 }
 
 int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
@@ -188,8 +189,13 @@ int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const rad
   const int per_block = waves * (64 / d.G);
   const unsigned grid = unsigned((n + per_block - 1) / per_block);
   const size_t lds = mesh::lds_bytes(d, waves);
-  const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1} : ClassSel{m->d_zero, 0, 0};
-  if (precision == ANM_SOLVE_F32)
+  const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1, m->class_per_env ? 1 : 0} : ClassSel{m->d_zero, 0, 0, 0};
+  if (cs.per_group) {
+    if (precision == ANM_SOLVE_F32)
+      hipLaunchKernelGGL((mesh::k_mesh<float, true>), dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    else
+      hipLaunchKernelGGL((mesh::k_mesh<double, true>), dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+  } else if (precision == ANM_SOLVE_F32)
     hipLaunchKernelGGL(mesh::k_mesh<float>, dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   else
     hipLaunchKernelGGL(mesh::k_mesh<double>, dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
@@ -204,17 +210,18 @@ int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const r
   // the model is the compiled tree: the specialised Newton loop; else (generic mode) the table-driven one
   bool spec = false;
   if constexpr (Topo::TREE != 0) spec = m->tpe_ok && m->plan.d.G == Topo::GRP && !getenv("ANM_RADIAL_GENERIC");
+  const ClassSel cs = class_sel(m, true);
+  const bool f32 = precision == ANM_SOLVE_F32;
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, cs); };
   if (spec) {
     if constexpr (Topo::TREE != 0) {
-      if (precision == ANM_SOLVE_F32)
-        hipLaunchKernelGGL((radial::k_radial<float, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
-      else
-        hipLaunchKernelGGL((radial::k_radial<double, Topo>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
+      if (cs.per_group) { if (f32) go(radial::k_radial<float, Topo, true>); else go(radial::k_radial<double, Topo, true>); }
+      else { if (f32) go(radial::k_radial<float, Topo>); else go(radial::k_radial<double, Topo>); }
     }
-  } else if (precision == ANM_SOLVE_F32) {
-    hipLaunchKernelGGL((radial::k_radial<float, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
+  } else if (cs.per_group) {
+    if (f32) go(radial::k_radial<float, void, true>); else go(radial::k_radial<double, void, true>);
   } else {
-    hipLaunchKernelGGL((radial::k_radial<double, void>), dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, class_sel(m, true));
+    if (f32) go(radial::k_radial<float, void>); else go(radial::k_radial<double, void>);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_radial");
@@ -570,6 +577,7 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
   if (!m) return fail("anm_model_bind_env_classes: null model");
   if (!env_class) {
     m->d_env_class = nullptr;
+    m->class_per_env = false;
     return 0;
   }
   if (num_envs <= 0) return fail("anm_model_bind_env_classes: num_envs must be positive");
@@ -577,11 +585,20 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
   std::vector<int32_t> h(static_cast<size_t>(num_envs));
   hipError_t e = hipMemcpy(h.data(), env_class, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail_hip(e, "anm_model_bind_env_classes");
+  bool blocks = true;
   for (int64_t i = 0; i < num_envs; ++i) {
     if (h[i] < 0 || h[i] >= n_classes) return fail("anm_model_bind_env_classes: class index out of range");
-    if (h[i] != h[i - i % 64]) return fail("anm_model_bind_env_classes: a class must cover whole aligned blocks of 64 environments");
+    blocks = blocks && h[i] == h[i - i % 64];
   }
+  // One class per aligned block of 64 environments: the constants of a wavefront stay wave-uniform (scalar loads) in
+  // every kernel family.  Any other assignment -- a different network in every environment -- is served by the
+  // lane-group families (one environment per lane group, its constants read by vector loads); the
+  // thread-per-environment kernels cannot (64 environments share a wavefront's scalar constants).
+  if (!blocks && !(m->radial_ok || m->mesh_ok))
+    return fail("anm_model_bind_env_classes: a class must cover whole aligned blocks of 64 environments (this network has no lane-group kernel)");
+  m->class_per_env = !blocks;
   m->d_env_class = env_class;
+  if (!blocks && m->impl == ANM_IMPL_THREAD) m->impl = m->radial_ok ? ANM_IMPL_RADIAL : ANM_IMPL_MESH;
   return 0;
 }
 
@@ -667,6 +684,9 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
     return fail("anm_model_set_impl: unknown implementation");
   if (impl == ANM_IMPL_THREAD && !m->tpe_ok)
     return fail("this library was compiled for another topology: only the generic lane-group kernel is available");
+  if (impl == ANM_IMPL_THREAD && m->class_per_env)
+    return fail("anm_model_set_impl: the bound parameter classes change inside blocks of 64 environments: only a "
+                "lane-group kernel can serve them");
   if (impl != ANM_IMPL_THREAD && m->n_obs > 0)
     return fail("anm_model_set_impl: a list-form observation is gathered inside the thread-per-environment step kernel "
                 "(anm_model_set_obs); clear it before switching to a lane-group kernel");

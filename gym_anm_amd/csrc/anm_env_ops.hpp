@@ -19,6 +19,8 @@ struct ClassSel {
   const int32_t* env_class;  // never null: without classes it points at one zero and `per_env` is 0
   int stride;
   int per_env;               // 1: index env_class by the environment, 0: always entry 0
+  int per_group;             // lane-group families: 1 = the class may change from one environment to the next (every
+                             // lane group reads its own constants: vector loads), 0 = one class per aligned block of 64
 };
 #if defined(__HIPCC__)
 // (branch-free on purpose: a conditional here keeps the selector alive in scalar registers through the whole

@@ -463,7 +463,7 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 
 #define ANM_MESH_SYNC() ANM_WAVE_SYNC()
 
-template <class JT>
+template <class JT, bool PG = false>   // PG: see k_radial
 __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0, radial::IO io,
                                               SolverOpts so, int64_t n_env, ClassSel cls) {
   // a workgroup = 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet: a lane
@@ -480,7 +480,8 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   const int64_t ee = env_ok ? e : 0;
   const int64_t first_env = int64_t(blockIdx.x) * per_block + (t >> 6) * per_wave;
   const double* __restrict__ rd =
-      rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
+      PG ? rd0 + int64_t(cls.env_class[ee]) * cls.stride
+         : rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
   double* S = sh_dyn + grp * d.lds_per_env;                 // this environment's LDS
   int* tab = reinterpret_cast<int*>(sh_dyn + per_block * d.lds_per_env);   // lists, fill ids, the program (shared)
   for (int k = t; k < d.n_stage; k += int(blockDim.x)) tab[k] = ri[d.off_lists + k];

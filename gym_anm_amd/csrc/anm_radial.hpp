@@ -246,14 +246,19 @@ enum { A_VR = 0, A_VI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N }; 
 // TT: the compiled topology (Topo) when the model IS that network and it is a tree -- the Newton loop is then
 // the compile-time specialised lane-group loop of anm_group.hpp (unrolled levels, register hand-overs) instead
 // of the table-driven one below; void: any radial network (generic mode).
-template <class JT, class TT>
+// PG: the parameter class is that of the lane group's own environment (any assignment of classes to environments;
+// the constants are then read by vector loads) instead of one class per wavefront (scalar loads).
+template <class JT, class TT, bool PG = false>
 __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0, IO io,
                                               SolverOpts so, int64_t n_env, ClassSel cls) {
   constexpr bool USE_T = !std::is_void<TT>::value;
-  // parameter class of this wavefront's environments (uniform over aligned blocks of 64 environments)
+  // parameter class of this wavefront's environments (uniform over aligned blocks of 64 environments), or, PG, of
+  // this lane group's environment
   const int64_t first_env = int64_t(blockIdx.x) * (64 / d.G);
+  const int64_t my_env = first_env + int(threadIdx.x) / d.G;
   const double* __restrict__ rd =
-      rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
+      PG ? rd0 + int64_t(cls.env_class[my_env < n_env ? my_env : 0]) * cls.stride
+         : rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
   __shared__ double sh[A_N][64];
   __shared__ int sh_lists[256];  // children / bus-device index lists (read every Newton iteration)
   const int t = threadIdx.x;

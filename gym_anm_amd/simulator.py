@@ -208,6 +208,9 @@ class BatchedSimulator:
             with self._device_ctx():
                 self.backend.check(self.backend.lib.anm_model_bind_env_classes(
                     self._handle, self.env_variant.data_ptr(), self.num_envs), "anm_model_bind_env_classes")
+            # (classes that change inside blocks of 64 environments move a thread-per-environment model to its
+            # lane-group family)
+            self.impl = {0: "thread", 1: "radial", 2: "mesh"}[self.backend.lib.anm_model_get_impl(self._handle)]
         dims = _lib.Dims()
         self.backend.check(self.backend.lib.anm_model_dims(self._handle, C.byref(dims)), "anm_model_dims")
         self.dims = dims

@@ -131,10 +131,13 @@ int anm_model_get_ybus(const anm_model* m, double* y_host);
  * ratings, voltage limits, device limits, tau/rho, storage parameters.  descs[k] describes class k
  * (descs[0] is ignored); anm_model_set_env must be called (again) afterwards.  anm_model_bind_env_classes
  * names the class of every environment of the batch the model steps: env_class is a DEVICE int32 array of
- * num_envs entries that stays alive and unchanged while bound, constant over every aligned block of 64
- * environments (checked here) -- the constants of a wavefront then remain one wave-uniform buffer read by
- * scalar loads, so classes cost nothing in the kernels.  NULL unbinds (all environments: class 0).  The
- * two-launch step (anm_step_ws) is not used while classes are bound. */
+ * num_envs entries that stays alive and unchanged while bound.  Constant over every aligned block of 64
+ * environments: the constants of a wavefront remain one wave-uniform buffer read by scalar loads, classes cost
+ * nothing, every kernel family serves them.  ANY other assignment (a different network in every environment, like
+ * the reference's one Simulator per environment): served by the lane-group families (radial / mesh: one environment
+ * per lane group, its constants read by vector loads); a model on the thread-per-environment family switches to
+ * its lane-group family (anm_model_get_impl tells), a network without one is refused.  NULL unbinds (all
+ * environments: class 0).  The two-launch step (anm_step_ws) is not used while classes are bound. */
 int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_desc* const* descs);
 /* anm_model_set_env gives every class the same observation Box (that of the cfg).  The reference builds one
  * environment per network, each with the Box of ITS network (anm_env.py:193-233, simulator.py:382-462): this

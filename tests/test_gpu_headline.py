@@ -242,15 +242,23 @@ def test_heterogeneous_networks_64_parameter_classes(impl):
     assert sim.impl == impl and len(sim.variant_models) == 64
 
 
-def test_parameter_classes_must_cover_aligned_blocks():
+def test_parameter_classes_inside_a_block_of_64_move_the_model_to_a_lane_group_family():
+    """One class per aligned block of 64 environments: every family (scalar constants per wavefront).  A class change
+    inside a block: only the lane-group families can (test_a_different_network_in_every_environment); a model on the
+    thread-per-environment family moves there, and cannot be moved back."""
     from gym_anm_amd import errors, networks
     from gym_anm_amd.simulator import BatchedSimulator
 
     base = networks.anm6_network()
     ev = np.zeros(128, dtype=np.int32)
     ev[70:] = 1  # class changes in the middle of a 64-environment block
-    with pytest.raises(errors.HipExtensionError, match="aligned blocks of 64"):
-        BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.perturbed_network(base, 1)], env_variant=ev)
+    sim = BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.perturbed_network(base, 1)], env_variant=ev)
+    assert sim.impl == "radial"
+    rc = sim.backend.lib.anm_model_set_impl(sim._handle, 0)
+    assert rc != 0 and b"lane-group" in sim.backend.lib.anm_last_error()
+    aligned = BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.perturbed_network(base, 1)],
+                               env_variant=np.repeat([0, 1], 64))
+    assert aligned.impl == "thread"
     with pytest.raises(errors.UnsupportedNetworkError):
         BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.two_bus_network()])
 
@@ -344,3 +352,8 @@ def test_convergence_flags_after_a_masked_reset():
 
 def test_general_step_with_rows_wider_than_the_default_lds_limit():
     pc.general_step_with_wide_rows(KW)
+
+
+@pytest.mark.parametrize("impl", ["radial", "mesh"])
+def test_a_different_network_in_every_environment(impl):
+    pc.per_environment_networks(KW, impl)
