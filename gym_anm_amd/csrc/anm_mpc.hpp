@@ -559,18 +559,22 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
   bool inside = true;
   {
     double sig[pos(NS)];
-    ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = 0.5;
-    ANM_UFOR (int j = 0; j < NS; ++j) {
-      const double bc = C[S::T_BC + j], bd = C[S::T_BD + j], pmax = C[S::T_SPMAX + j], pmin = C[S::T_SPMIN + j];
-      const double base = 0.05 * (pmax - pmin);
-      const double mid = 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
-      double dsig = 0.2 * (mid - soc0[j]) / double(N);
-      dsig = fmin(fmax(dsig, -0.25 * pmax * bd), -0.25 * pmin * bc);   // (a quarter of the power limits at most)
-      ln.pc[j] = base + fmax(dsig, 0.0) / bc;
-      ln.d[j] = base * (bc / bd) + fmax(-dsig, 0.0) / bd;
-      sig[j] = soc0[j] + double(i + 1) * dsig;
-    }
-    {
+    // The angle rows |theta| <= pi are the only ones such a point may violate (networks whose per-unit injections
+    // are tens of p.u.): the whole start is then scaled towards "generators at P_min, storage idle", halving until
+    // every stage of the environment is inside (20 times at most: then only the loads are left)
+    double f = 1.0;
+    for (int pass = 0; pass < 20; ++pass) {
+      ANM_UFOR (int g = 0; g < NG; ++g) ln.xi[g] = 0.5 * f;
+      ANM_UFOR (int j = 0; j < NS; ++j) {
+        const double bc = C[S::T_BC + j], bd = C[S::T_BD + j], pmax = C[S::T_SPMAX + j], pmin = C[S::T_SPMIN + j];
+        const double base = 0.05 * f * (pmax - pmin);
+        const double mid = 0.5 * (C[S::T_SOCMIN + j] + C[S::T_SOCMAX + j]);
+        double dsig = 0.2 * (mid - soc0[j]) / double(N);
+        dsig = f * fmin(fmax(dsig, -0.25 * pmax * bd), -0.25 * pmin * bc);   // (a quarter of the power limits at most)
+        ln.pc[j] = base + fmax(dsig, 0.0) / bc;
+        ln.d[j] = base * (bc / bd) + fmax(-dsig, 0.0) / bd;
+        sig[j] = soc0[j] + double(i + 1) * dsig;
+      }
       double u[pos(NC)];
       ln.phys(C, u);
       ANM_UFOR (int e = 0; e < NBR; ++e) {
@@ -578,12 +582,17 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         ANM_UFOR (int c = 0; c < NC; ++c) fl = fma(C[S::T_PHC + e * NC + c], u[c], fl);
         ln.t[e] = fmax(fabs(fl) - C[S::T_LIM + e], 0.0) + 0.1;
       }
+      double val[NR];
+      ln.row_values(C, sig, val);
+      inside = true;
+      ANM_UFOR (int r = 0; r < NR; ++r) {
+        inside = inside && (-val[r] > 0.0);
+        ln.s[r] = -val[r] > 0.0 ? -val[r] : 1.0;
+      }
+      if (x.min(on ? (inside ? 1.0 : 0.0) : 1.0) > 0.5) break;
+      f *= 0.5;
     }
-    double val[NR];
-    ln.row_values(C, sig, val);
     ANM_UFOR (int r = 0; r < NR; ++r) {
-      inside = inside && (-val[r] > 0.0);
-      ln.s[r] = -val[r] > 0.0 ? -val[r] : 1.0;
       ln.z[r] = r >= S::R_FL1 ? ln.ct * (1.0 / 3.0) : 1.0;  // dual feasible for the epigraph variables
       ln.cross(r) = 0.0;
     }

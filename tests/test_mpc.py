@@ -287,6 +287,19 @@ def test_two_storage_units_and_a_classical_generator_host():
     check_random_programs(_host_sim(net), net, 5, 3, horizons=(1, 3, 8))
 
 
+def check_other_stock_networks(make_sim, n_cases):
+    """the other networks the package ships that fit the kernel's register budget.  The 3-bus loop in its own
+    per-unit base (base_mva = 1: injections of tens of p.u.) is the case whose ANGLE rows |theta| <= pi bind at the
+    optimum and are violated at the centred start: the start is scaled back until it is interior"""
+    for net, horizons in [(networks.two_bus_network(), (1, 4)), (networks.three_bus_loop_network(), (1, 2, 5, 12)),
+                          (networks.three_bus_loop_network(base_mva=10), (1, 5)), (networks.synthetic_radial_network(8, seed=1), (1, 3))]:
+        check_random_programs(make_sim(net), net, n_cases, 3, horizons=horizons)
+
+
+def test_other_stock_networks_host():
+    check_other_stock_networks(_host_sim, 4)
+
+
 def test_closed_loop_on_the_host_double():
     from hostsim_backend import hostsim_backend
 
@@ -354,6 +367,11 @@ def test_solver_vs_highs_random_programs_gpu():
 def test_two_storage_units_and_a_classical_generator_gpu():
     net = two_storage_network()
     check_random_programs(_gpu_sim(net), net, 16, 3, horizons=(1, 3, 8, 16))
+
+
+@pytest.mark.gpu
+def test_other_stock_networks_gpu():
+    check_other_stock_networks(_gpu_sim, 12)
 
 
 @pytest.mark.gpu
