@@ -92,6 +92,7 @@ ABI = {
     "anm_step_ws_record_doubles": (C.c_int, []),
     "anm_model_set_impl": (C.c_int, [C.c_void_p, C.c_int32]),
     "anm_model_get_impl": (C.c_int, [C.c_void_p]),
+    "anm_model_lanes_per_env": (C.c_int, [C.c_void_p]),
     "anm_model_full_layout": (C.c_int, [C.c_void_p, C.POINTER(FullLayout)]),
     "anm_transition_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 11 + [C.POINTER(SolverOpts), _P]),
     "anm_reset_f64": (C.c_int, [C.c_void_p, C.c_int64, _P, _P, C.c_uint64, C.c_uint64] + [_P] * 10
@@ -170,7 +171,8 @@ def load_for_topology(topo, impl=None) -> Backend:
 
     * a library specialised for this topology (thread-per-environment kernels + the generic
       lane-group kernel) when it exists or when it is worth building (networks up to 12 buses);
-    * otherwise, for networks that fit a wavefront (radial: impl "radial"; any topology: impl "mesh"), any
+    * otherwise, for networks that fit a wavefront (radial: impl "radial") or a workgroup of 512 lanes (any
+      topology: impl "mesh"), any
       already-built library in *generic* mode: the lane-group kernels are table-driven and need no
       per-topology compilation;
     * otherwise build the specialised library with hipcc."""
@@ -178,7 +180,7 @@ def load_for_topology(topo, impl=None) -> Backend:
     if name in _CACHE:
         return _CACHE[name]
     path = codegen.lib_path(name)
-    fits_group = topo[0] - 1 <= 64 and len(topo[1]) <= 128 and len(topo[2]) <= 64   # mesh::fits (anm_mesh.hpp)
+    fits_group = topo[0] - 1 <= 512 and len(topo[1]) <= 1024 and len(topo[2]) <= 512   # mesh::fits (anm_mesh.hpp)
     generic = (_is_tree(topo) and (impl == "radial" or (impl is None and topo[0] > 12))) or \
               (fits_group and (impl == "mesh" or (impl is None and topo[0] > 12)))
     if not os.path.exists(path) and generic:
@@ -197,8 +199,8 @@ def load_for_topology(topo, impl=None) -> Backend:
         # compiling the thread-per-environment kernels for a network of this size takes hipcc minutes to hours and
         # yields a spilling kernel: only on explicit request
         raise E.UnsupportedNetworkError(
-            "a %d-bus network with %d branches and %d devices fits neither lane-group kernel (at most 65 buses, "
-            "128 branches, 64 devices) and is too large for the thread-per-environment kernels; pass "
+            "a %d-bus network with %d branches and %d devices fits neither lane-group kernel (at most 513 buses, "
+            "1024 branches, 512 devices) and is too large for the thread-per-environment kernels; pass "
             "impl='thread' to compile them anyway" % (topo[0], len(topo[1]), len(topo[2])))
     # build_library returns at once when the library's content stamp matches this tree's sources; a
     # stale library (edited kernels, changed C ABI) is rebuilt, or refused when hipcc is unavailable:

@@ -183,22 +183,30 @@ ClassSel class_sel(const anm_model* m, bool radial) {
   return ClassSel{m->d_env_class, radial ? int(m->plan.hd.size()) : int(m->h_const.size()), 1, m->class_per_env ? 1 : 0};
 }
 
+template <bool WG>
+void launch_mesh_as(anm_model* m, int precision, unsigned grid, unsigned threads, size_t lds, hipStream_t s, const radial::IO& io,
+                    SolverOpts so, int64_t n, const ClassSel& cs) {
+  const mesh::Dims& d = m->mplan.d;
+  if (cs.per_group) {
+    if (precision == ANM_SOLVE_F32)
+      hipLaunchKernelGGL((mesh::k_mesh<float, true, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    else
+      hipLaunchKernelGGL((mesh::k_mesh<double, true, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+  } else if (precision == ANM_SOLVE_F32)
+    hipLaunchKernelGGL((mesh::k_mesh<float, false, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+  else
+    hipLaunchKernelGGL((mesh::k_mesh<double, false, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+}
+
 int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
   const mesh::Dims& d = m->mplan.d;
   const int waves = mesh::waves_per_block(d);
-  const int per_block = waves * (64 / d.G);
+  const int per_block = mesh::envs_per_block(d);
   const unsigned grid = unsigned((n + per_block - 1) / per_block);
   const size_t lds = mesh::lds_bytes(d, waves);
   const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1, m->class_per_env ? 1 : 0} : ClassSel{m->d_zero, 0, 0, 0};
-  if (cs.per_group) {
-    if (precision == ANM_SOLVE_F32)
-      hipLaunchKernelGGL((mesh::k_mesh<float, true>), dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
-    else
-      hipLaunchKernelGGL((mesh::k_mesh<double, true>), dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
-  } else if (precision == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(mesh::k_mesh<float>, dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
-  else
-    hipLaunchKernelGGL(mesh::k_mesh<double>, dim3(grid), dim3(64 * waves), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+  if (mesh::is_workgroup(d)) launch_mesh_as<true>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
+  else launch_mesh_as<false>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_mesh");
   return 0;
@@ -311,9 +319,12 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
         if (mesh::lds_bytes(m->mplan.d, mesh::waves_per_block(m->mplan.d)) > 64 * 1024) {
           // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, here: an
           // attribute call has no place in a launch path that may be under stream capture)
-          hipError_t a1 = hipFuncSetAttribute((const void*)mesh::k_mesh<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          hipError_t a2 = hipFuncSetAttribute((const void*)mesh::k_mesh<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          if (a1 != hipSuccess || a2 != hipSuccess) m->mesh_ok = false;
+          const void* fns[8] = {(const void*)mesh::k_mesh<float, false, false>, (const void*)mesh::k_mesh<double, false, false>,
+                                (const void*)mesh::k_mesh<float, true, false>,  (const void*)mesh::k_mesh<double, true, false>,
+                                (const void*)mesh::k_mesh<float, false, true>,  (const void*)mesh::k_mesh<double, false, true>,
+                                (const void*)mesh::k_mesh<float, true, true>,   (const void*)mesh::k_mesh<double, true, true>};
+          for (const void* fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) m->mesh_ok = false;
         }
       }
       if (m->mesh_ok) {
@@ -695,6 +706,10 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
 }
 
 int anm_model_get_impl(const anm_model* m) { return m ? m->impl : -1; }
+int anm_model_lanes_per_env(const anm_model* m) {
+  if (!m) return -1;
+  return m->impl == ANM_IMPL_MESH ? m->mplan.d.G : (m->impl == ANM_IMPL_RADIAL ? m->plan.d.G : 1);
+}
 
 int anm_model_get_ybus(const anm_model* m, double* y) {
   if (!m || !y) return fail("anm_model_get_ybus: null argument");
@@ -1037,7 +1052,7 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
                       const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
                       const anm_mpc_opts* opts, void* stream) {
   typedef mpc::Sz<Topo> S;
-  if (!m || !u0 || !objective || !iters) return fail("anm_mpc_solve_f64: null argument");
+  if (!m || (S::NC > 0 && !u0) || !objective || !iters) return fail("anm_mpc_solve_f64: null argument");
   if ((S::NL > 0 && !p_load_forecast) || (S::NG > 0 && !p_gen_forecast) || (S::NS > 0 && !soc))
     return fail("anm_mpc_solve_f64: a forecast / state-of-charge array is missing");
   if (num_envs <= 0) return 0;

@@ -82,7 +82,7 @@ struct Dims {
   int off_lists, n_lists, off_fill;                        // ints: [IF_COUNT][G], lists, fill ids (staged in LDS) ...
   int n_steps, off_stype, off_desc, n_stage, max_deg;      // ... step types (| run length << 8) [n_steps], descriptors [n_steps][G][4]
   int off_lane, off_dev, off_obs_lo, off_obs_hi, n_double;  // doubles
-  int l_v, l_x, l_blk, l_r, l_dinv, l_zero, l_bw, l_m, n_m, l_dev, lds_per_env;   // LDS layout of one environment (doubles)
+  int l_v, l_x, l_blk, l_r, l_dinv, l_zero, l_bw, l_m, n_m, l_dev, l_red, lds_per_env;   // LDS layout of one environment (doubles)
   int f_bus_p, f_bus_q, f_bus_vm, f_bus_va, f_bus_im, f_bus_ia, f_dev_p, f_dev_q, f_des_soc, f_gen_pmax, f_br_p,
       f_br_q, f_br_s, f_br_im, f_br_ia;
 };
@@ -93,13 +93,23 @@ struct Plan {
   std::vector<double> hd;
 };
 
+// Groups above a wavefront (networks of more than 65 buses): the environment IS the workgroup (2 ... 8 wavefronts,
+// k_mesh<.., WG = true>): workgroup barriers instead of wavefront fences, the tables are read from global memory
+// (the program of a 300-bus network is larger than the LDS), reductions and the stop test go through RED_DOUBLES
+// doubles of LDS
+constexpr int MAX_GROUP = 512;   // (a 1024-lane workgroup would leave 128 registers per lane: the kernel needs 186)
+constexpr int RED_DOUBLES = 64;
+inline bool is_workgroup(const Dims& d) { return d.G > 64; }
+
 // LDS of a workgroup of `waves` wavefronts: the environments' own areas + the staged tables (shared)
 inline size_t lds_bytes(const Dims& d, int waves) {
+  if (is_workgroup(d)) return size_t(d.lds_per_env) * sizeof(double);
   return size_t(waves) * (64 / d.G) * d.lds_per_env * sizeof(double) + size_t(d.n_stage) * sizeof(int);
 }
 // wavefronts per workgroup (they share one copy of the tables): what puts most wavefronts on a compute unit's
 // 160 KB of LDS, the larger workgroup on a tie
 inline int waves_per_block(const Dims& d) {
+  if (is_workgroup(d)) return d.G / 64;
   if (const char* ev = getenv("ANM_MESH_WAVES")) {   // tuning experiments
     const int w = atoi(ev);
     if ((w == 1 || w == 2 || w == 4) && lds_bytes(d, w) <= 160 * 1024) return w;
@@ -112,14 +122,15 @@ inline int waves_per_block(const Dims& d) {
   }
   return best;
 }
+inline int envs_per_block(const Dims& d) { return is_workgroup(d) ? 1 : waves_per_block(d) * (64 / d.G); }
 
 inline bool fits(const anm_network_desc& n) {
-  return n.n_bus >= 2 && n.n_bus - 1 <= 64 && n.n_dev <= 64 && n.n_branch <= 64 * BR_SLOTS;
+  return n.n_bus >= 2 && n.n_bus - 1 <= MAX_GROUP && n.n_dev <= MAX_GROUP && n.n_branch <= MAX_GROUP * BR_SLOTS;
 }
 
 // Symbolic analysis + per-lane tables for one network.
 inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
-  if (!fits(n)) { err = "the general lane-group kernel takes networks of at most 65 buses, 128 branches, 64 devices"; return false; }
+  if (!fits(n)) { err = "the general lane-group kernel takes networks of at most 513 buses, 1024 branches, 512 devices"; return false; }
   Dims& d = P.d;
   d.NB = n.n_bus; d.ND = n.n_dev; d.NBR = n.n_branch;
   d.NLOAD = d.NGEN = d.NDES = 0;
@@ -399,7 +410,8 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   // 16-byte aligned (blocks and vector pairs move as ds_read_b128 / ds_write_b128), and = 2 (mod 4) doubles: the
   // environments of a wavefront execute the same descriptors, so their areas must not start on the same banks --
   // with this size equal offsets of neighbouring environments are 4 banks (one b128 access) apart
-  d.lds_per_env = d.l_dev + 2 * d.ND + 1;
+  d.l_red = d.l_dev + 2 * d.ND;
+  d.lds_per_env = d.l_red + (G > 64 ? RED_DOUBLES : 0) + 1;
   while (d.lds_per_env % 4 != 2) ++d.lds_per_env;
   if (d.lds_per_env >= 65536) { err = "network too large for the general lane-group kernel (LDS)"; return false; }
   for (auto& st : steps)
@@ -461,31 +473,66 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 
 #if defined(__HIPCC__)
 
-#define ANM_MESH_SYNC() ANM_WAVE_SYNC()
+// one environment's lanes meet: a wavefront fence, or (WG) the workgroup's barrier
+#define ANM_MESH_SYNC()                        \
+  do {                                         \
+    if constexpr (WG) __syncthreads();         \
+    else ANM_WAVE_SYNC();                      \
+  } while (0)
 
-template <class JT, bool PG = false>   // PG: see k_radial
-__global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0, radial::IO io,
-                                              SolverOpts so, int64_t n_env, ClassSel cls) {
+template <class JT, bool PG = false, bool WG = false>   // PG: see k_radial; WG: the environment is the workgroup
+__global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,
+                                                          radial::IO io, SolverOpts so, int64_t n_env, ClassSel cls) {
   // a workgroup = 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet: a lane
-  // group lies within one wavefront, whose LDS operations complete in program order (fences only)
+  // group lies within one wavefront, whose LDS operations complete in program order (fences only).
+  // WG: the workgroup (2 ... 8 wavefronts) is ONE environment; every place where lanes of an environment hand
+  // something over is a workgroup barrier, and the tables stay in global memory
   extern __shared__ __align__(16) double sh_dyn[];
   const int t = threadIdx.x;
   const int G = d.G;
   const int l = t & (G - 1);
-  const int per_wave = 64 / G;
-  const int per_block = int(blockDim.x) / G;
-  const int grp = t / G;
+  const int per_wave = WG ? 0 : 64 / G;
+  const int per_block = WG ? 1 : int(blockDim.x) / G;
+  const int grp = WG ? 0 : t / G;
+  const int wave = t >> 6, n_waves = int(blockDim.x) >> 6;
   const int64_t e = int64_t(blockIdx.x) * per_block + grp;
   const bool env_ok = e < n_env;
   const int64_t ee = env_ok ? e : 0;
-  const int64_t first_env = int64_t(blockIdx.x) * per_block + (t >> 6) * per_wave;
+  const int64_t first_env = int64_t(blockIdx.x) * per_block + (WG ? 0 : (t >> 6) * per_wave);
   const double* __restrict__ rd =
       PG ? rd0 + int64_t(cls.env_class[ee]) * cls.stride
          : rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
   double* S = sh_dyn + grp * d.lds_per_env;                 // this environment's LDS
-  int* tab = reinterpret_cast<int*>(sh_dyn + per_block * d.lds_per_env);   // lists, fill ids, the program (shared)
-  for (int k = t; k < d.n_stage; k += int(blockDim.x)) tab[k] = ri[d.off_lists + k];
-  __syncthreads();
+  double* RED = S + d.l_red;                                // WG: flags and partial sums of the wavefronts
+  const int* tab;                                           // lists, fill ids, the program
+  if constexpr (WG) {
+    tab = ri + d.off_lists;
+  } else {
+    int* stage = reinterpret_cast<int*>(sh_dyn + per_block * d.lds_per_env);   // (shared by the workgroup)
+    for (int k = t; k < d.n_stage; k += int(blockDim.x)) stage[k] = ri[d.off_lists + k];
+    __syncthreads();
+    tab = stage;
+  }
+  // sums over the lanes of the environment, the same value in every lane: butterflies; WG: per wavefront, then the
+  // wavefronts' partial sums in wavefront order
+  auto group_sum2 = [&](double& a, double& b) {
+    if constexpr (WG) {
+      for (int m = 1; m < 64; m <<= 1) {
+        a += __shfl_xor(a, m, 64);
+        b += __shfl_xor(b, m, 64);
+      }
+      __syncthreads();
+      if ((t & 63) == 0) { RED[32 + 2 * wave] = a; RED[33 + 2 * wave] = b; }
+      __syncthreads();
+      a = 0.0; b = 0.0;
+      for (int w = 0; w < n_waves; ++w) { a += RED[32 + 2 * w]; b += RED[33 + 2 * w]; }
+    } else {
+      for (int m = 1; m < G; m <<= 1) {
+        a += __shfl_xor(a, m, G);
+        b += __shfl_xor(b, m, G);
+      }
+    }
+  };
   const int* lists = tab;
   const int* fills = tab + (d.off_fill - d.off_lists);
   auto RI = [&](int f) { return ri[f * G + l]; };
@@ -644,7 +691,7 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
   bool g_bad = false, g_nan = false;   // the group's ||F||inf > tol / F has a NaN, as of its last evaluation
   bool active = true;
   const unsigned long long busm = __builtin_amdgcn_uicmp(isbus ? 1u : 0u, 0u, group::ICMP_NE);
-  const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << G) - 1ull)) << ((t & 63) - l);
+  const unsigned long long gmask = (G >= 64) ? ~0ull : (((1ull << G) - 1ull) << ((t & 63) - l));
   const unsigned glo = unsigned(gmask), ghi = unsigned(gmask >> 32);
   if (l < 6) S[d.l_zero + l] = 0.0;
   for (int k = l; k < 4 * NB; k += G) LR[k] = 0.0;                // second column of the right-hand-side blocks
@@ -715,8 +762,16 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
     // reference's loop and flags need; a group that stopped keeps its verdict
     const unsigned long long badm = __builtin_amdgcn_fcmp(isbus ? fmax(fabs(fr), fabs(fi)) : 0.0, so.tol, group::FCMP_UGT);
     const unsigned long long nanm = __builtin_amdgcn_fcmp(fr, fi, group::FCMP_UNO) & busm;
-    const bool nb = ((unsigned(badm) & glo) | (unsigned(badm >> 32) & ghi)) != 0u;
-    const bool nn = ((unsigned(nanm) & glo) | (unsigned(nanm >> 32) & ghi)) != 0u;
+    bool nb = ((unsigned(badm) & glo) | (unsigned(badm >> 32) & ghi)) != 0u;
+    bool nn = ((unsigned(nanm) & glo) | (unsigned(nanm >> 32) & ghi)) != 0u;
+    if constexpr (WG) {   // the verdicts of the other wavefronts (the flags are next written a barrier later at least)
+      if ((t & 63) == 0) { RED[2 * wave] = nb ? 1.0 : 0.0; RED[2 * wave + 1] = nn ? 1.0 : 0.0; }
+      __syncthreads();
+      double fb = 0.0, fn = 0.0;
+      for (int w = 0; w < n_waves; ++w) { fb += RED[2 * w]; fn += RED[2 * w + 1]; }
+      nb = fb > 0.0;
+      nn = fn > 0.0;
+    }
     if (it == 0 || active) { g_bad = nb; g_nan = nn; }
     active = g_bad && !g_nan && (it < so.max_iter);       // NaN > tol is false, like the reference
     if (!__any(active && env_ok && !skip)) break;
@@ -805,8 +860,10 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
       ANM_MESH_SYNC();
     }
     // ---- update (group-uniform `active`); d1 is the relative magnitude step
+    double dth = 0.0, d1 = 0.0;
+    if (active && isbus) { dth = LX[2 * bus]; d1 = LX[2 * bus + 1]; }
+    if constexpr (WG) __syncthreads();   // x and V share their place: every wavefront has read x before V is published
     if (active && isbus) {
-      const double dth = LX[2 * bus], d1 = LX[2 * bus + 1];
       vm = fma(-d1, fabs(vm), vm);
       double sd_, cd_;
       if (fabs(dth) <= 0.78) {
@@ -857,10 +914,7 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
     if (isbr[sl] && br_f[sl] == 0) { s0r += LBW[b]; s0i += LBW[NBR + b]; }
     if (isbr[sl] && br_t[sl] == 0) { s0r += LBW[2 * NBR + b]; s0i += LBW[3 * NBR + b]; }
   }
-  for (int m = 1; m < G; m <<= 1) {
-    s0r += __shfl_xor(s0r, m, G);
-    s0i += __shfl_xor(s0i, m, G);
-  }
+  group_sum2(s0r, s0i);
   const double i0r = rd[SF_Y00_RE] + s0r, i0i = rd[SF_Y00_IM] + s0i;
   const double slack_p = (i0r != i0r) ? INFINITY : i0r;
   const double slack_q = (i0i != i0i) ? INFINITY : -i0i;
@@ -901,10 +955,7 @@ __global__ __launch_bounds__(256) void k_mesh(Dims d, const int* __restrict__ ri
     const double curt = p_pot - dev_p;
     el += (curt != curt) ? NAN : fmax(0.0, curt);
   }
-  for (int m = 1; m < G; m <<= 1) {
-    pen += __shfl_xor(pen, m, G);
-    el += __shfl_xor(el, m, G);
-  }
+  group_sum2(pen, el);
   const double e_loss = el * dt, penalty = pen * (dt * rd[SF_LAMB]);
   const double reward = -(e_loss + penalty);
 

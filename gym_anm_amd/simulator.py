@@ -211,6 +211,8 @@ class BatchedSimulator:
             # (classes that change inside blocks of 64 environments move a thread-per-environment model to its
             # lane-group family)
             self.impl = {0: "thread", 1: "radial", 2: "mesh"}[self.backend.lib.anm_model_get_impl(self._handle)]
+        # lanes that carry one environment: 1 (thread), 8 ... 64 lanes of a wavefront, or a workgroup of 128 ... 512
+        self.lanes_per_env = int(self.backend.lib.anm_model_lanes_per_env(self._handle))
         dims = _lib.Dims()
         self.backend.check(self.backend.lib.anm_model_dims(self._handle, C.byref(dims)), "anm_model_dims")
         self.dims = dims

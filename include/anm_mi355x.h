@@ -115,12 +115,17 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg);
 #define ANM_IMPL_RADIAL 1
 /*   ANM_IMPL_MESH    the same lane-group mapping for ANY topology (loops, several feeders off the slack): the
  *                    2x2-block Jacobian lives in LDS and is eliminated level by level with the static
- *                    step program scheduled at anm_model_create; networks up to 65 buses / 128 branches /
- *                    64 devices (default for non-radial networks above 12 buses, and for non-radial networks
+ *                    step program scheduled at anm_model_create; networks up to 513 buses / 1024 branches /
+ *                    512 devices as long as the blocks of one environment fit the 160 KB of LDS (default for non-radial networks above 12 buses, and for non-radial networks
  *                    no library was compiled for). */
 #define ANM_IMPL_MESH 2
 int anm_model_set_impl(anm_model* m, int32_t impl);
 int anm_model_get_impl(const anm_model* m);
+/* lanes that carry one environment under the current family: 1 (ANM_IMPL_THREAD), 8 ... 64 lanes of a wavefront
+ * (ANM_IMPL_RADIAL, ANM_IMPL_MESH up to 65 buses), or a whole workgroup of 128 / 256 / 512 lanes (ANM_IMPL_MESH for
+ * networks of 66 ... 513 buses, up to 1024 branches and 512 devices: barriers instead of wavefront fences, the step
+ * program read from global memory).  Diagnostic. */
+int anm_model_lanes_per_env(const anm_model* m);
 
 /* copy the nodal admittance matrix the library built (simulator.py:183-199) to host memory:
  * y[n_bus*n_bus*2] row-major (re, im). */

@@ -123,6 +123,7 @@ int anm_model_set_impl(anm_model*, int32_t impl) {
   return 0;
 }
 int anm_model_get_impl(const anm_model*) { return ANM_IMPL_THREAD; }
+int anm_model_lanes_per_env(const anm_model*) { return 1; }
 int anm_model_get_ybus(const anm_model* m, double* y) {
   for (size_t k = 0; k < m->ybus.size(); ++k) { y[2 * k] = m->ybus[k].real(); y[2 * k + 1] = m->ybus[k].imag(); }
   return 0;

@@ -656,6 +656,75 @@ def single_env_with_callable_observation(kw):
     return env
 
 
+def large_network_env(kw, n_bus=150, seed=21, n_chords=16, n_steps=12):
+    """`gym_anm_amd.ANMEnv` over a network larger than a wavefront (the reference takes any size: simulator.py:113-181),
+    reset and stepped next to the oracle's environment with the same hooks: state, reward and termination step by step."""
+    import anm_oracle as O
+    from gym_anm_amd import ANMEnv
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords)
+    extra = kw(net)
+    light = 40.0 / n_bus   # (the synthetic feeders carry the same load per bus whatever their size)
+
+    def hooks(gen, model):
+        lo = model.dev_p_min[model.load_idx] * model.baseMVA
+        hi = model.dev_p_max[model.gen_idx] * model.baseMVA
+
+        def init_state(n):
+            s = np.zeros(n)
+            D = model.N_device
+            s[:D] = gen.uniform(-1.0, 1.0, D) * light
+            s[D : 2 * D] = gen.uniform(-0.2, 0.2, D) * light
+            s[2 * D : 2 * D + len(model.des_idx)] = gen.uniform(0.0, 5.0, len(model.des_idx))
+            s[2 * D + len(model.des_idx) : -1] = gen.uniform(0.0, 1.0, len(model.gen_idx)) * hi
+            s[-1] = 7.0
+            return s
+
+        def next_vars(s_t):
+            return np.concatenate((lo * light * 0.6 * gen.uniform(size=lo.size), hi * gen.uniform(size=hi.size), [(s_t[-1] + 1) % 24]))
+
+        return init_state, next_vars
+
+    class Task(ANMEnv):
+        def __init__(self):
+            super().__init__(net, "state", 1, 0.25, 0.99, 100, np.array([[0, 24]]), (10, 500), 3, **extra)
+            self._init, self._next = hooks(np.random.default_rng(31), self.simulator.model)
+
+        def init_state(self):
+            return self._init(self.state_N)
+
+        def next_vars(self, s_t):
+            return self._next(s_t)
+
+    env = Task()
+    assert env.simulator.impl == "mesh"
+    o, _ = env.reset()
+    model = env.simulator.model
+    t_init, t_next = hooks(np.random.default_rng(31), model)
+    orc = O.OracleEnv(net, delta_t=0.25, gamma=0.99, lamb=100, costs_clipping=(10, 500), aux_bounds=((0, 24),), next_vars=t_next,
+                      sparse=False)
+    for _ in range(100):
+        _, ok = orc.reset_to(t_init(env.state_N))
+        if ok:
+            break
+    npt.assert_allclose(env.state, orc.state, rtol=0, atol=1e-9)
+    npt.assert_allclose(o, np.clip(orc.state, env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-9)
+    rng = np.random.default_rng(4)
+    n_ok = 0
+    for t in range(n_steps):
+        a = rng.uniform(env.action_space.low, env.action_space.high) * light
+        o, r, term, trunc, _ = env.step(a)
+        _, r_o, term_o = orc.step(a)
+        assert term == term_o and abs(r - r_o) <= 1e-9 * (1 + abs(r_o)), (t, r, r_o, term, term_o)
+        if term:
+            break
+        n_ok += 1
+        npt.assert_allclose(env.state, orc.state, rtol=0, atol=1e-9)
+        npt.assert_allclose(o, np.clip(orc.state, env.observation_space.low, env.observation_space.high), rtol=0, atol=1e-9)
+    assert n_ok >= n_steps // 2
+    return env
+
+
 def bounds_hook_reads_aux_bounds(kw):
     """anm_env.py:122-139: aux_bounds and costs_clipping are attributes BEFORE observation_bounds() runs -- the
     reference's own default implementation reads aux_bounds, and so may a user's override."""

@@ -295,14 +295,27 @@ def test_mesh_random_meshed_networks_against_oracle(n_bus, seed, n_chords):
     for: generic mode of the general lane-group kernel against the oracle, case by case.  (14, 3, 6), (33, 4, 8),
     (64, 10, 24): more branches than lanes in the group -- a lane plays two; the last one also needs more than the
     default 64 KB of LDS per workgroup.)"""
+    _mesh_network_against_oracle(n_bus, seed, n_chords, 96, 1.0, 4)
+
+
+@pytest.mark.parametrize("n_bus,seed,n_chords,group", [(66, 11, 10, 128), (100, 12, 12, 128), (130, 16, 0, 256), (200, 13, 30, 256),
+                                                       (300, 14, 40, 512), (513, 15, 40, 512)])
+def test_mesh_networks_larger_than_a_wavefront_against_oracle(n_bus, seed, n_chords, group):
+    """The reference takes a network of any size (simulator.py:113-181, solve_load_flow.py:123-164).  Above 65 buses
+    the environment is a WORKGROUP of 128 ... 512 lanes (k_mesh<.., WG>): barriers instead of wavefront fences, the
+    step program read from global memory.  (130, 16, 0): a tree too large for the radial family.)"""
+    sim = _mesh_network_against_oracle(n_bus, seed, n_chords, 24, 40.0 / n_bus, 2)
+    assert sim.backend.lib.anm_model_lanes_per_env(sim._handle) == group
+
+
+def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeless):
     import anm_oracle as O
     from gym_anm_amd import networks
     from gym_anm_amd.model import NetworkModel
     from gym_anm_amd.simulator import BatchedSimulator
 
-    net = networks.synthetic_meshed_network(n_bus, seed, n_chords)
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if n_chords else networks.synthetic_radial_network(n_bus, seed)
     model = NetworkModel(net, 0.25, 100)
-    M = 96
     sim = BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl="mesh" if n_bus <= 12 else None)
     assert sim.impl == "mesh"
     npt.assert_allclose(sim.device_ybus(), model.Y_bus, rtol=1e-15, atol=0)
@@ -313,12 +326,13 @@ def test_mesh_random_meshed_networks_against_oracle(n_bus, seed, n_chords):
         lo, hi = np.asarray(lo, float) * scale, np.asarray(hi, float) * scale
         return lo + (hi - lo) * rng.uniform(size=(M, lo.size))
 
-    pl = U(model.dev_p_min[model.load_idx], 0 * model.dev_p_min[model.load_idx], 0.6 * b)
+    # (the synthetic feeders carry the same load per bus whatever their size: the large ones are loaded lightly)
+    pl = U(model.dev_p_min[model.load_idx], 0 * model.dev_p_min[model.load_idx], 0.6 * b * load_scale)
     pp = U(0 * model.dev_p_max[model.gen_idx], model.dev_p_max[model.gen_idx], b)
-    ps = U(model.dev_p_min[model.setp_idx], model.dev_p_max[model.setp_idx], 1.2 * b)
-    qs = U(model.dev_q_min[model.setp_idx], model.dev_q_max[model.setp_idx], 1.2 * b)
+    ps = U(model.dev_p_min[model.setp_idx], model.dev_p_max[model.setp_idx], 1.2 * b * load_scale)
+    qs = U(model.dev_q_min[model.setp_idx], model.dev_q_max[model.setp_idx], 1.2 * b * load_scale)
     soc = U(model.dev_soc_min[model.des_idx], model.dev_soc_max[model.des_idx])
-    pl[-4:] *= 40.0  # a few hopeless cases: both sides must give up the same way
+    pl[-n_hopeless:] *= 40.0 / load_scale  # a few hopeless cases: both sides must give up the same way
     sim.soc.copy_(torch.as_tensor(soc))
     sim.transition(pl, pp, ps, qs)
     full, sl = sim.full.cpu().numpy(), pc.full_slices(sim)
@@ -340,6 +354,12 @@ def test_mesh_random_meshed_networks_against_oracle(n_bus, seed, n_chords):
         npt.assert_allclose(full[e, sl["branch_s"]], ref["br_s"], rtol=0, atol=1e-9)
         npt.assert_allclose(float(sim.reward[e]), ref["reward"], rtol=1e-9, atol=1e-9)
     assert n_conv >= M // 2
+    return sim
+
+
+def test_environment_over_a_network_larger_than_a_wavefront():
+    env = pc.large_network_env(KW)
+    assert env.simulator.lanes_per_env == 256
 
 
 def test_bounds_hook_reads_aux_bounds():

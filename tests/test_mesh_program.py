@@ -53,3 +53,12 @@ def test_stock_networks(checker):
 def test_random_meshed_networks(checker, n_bus, seed, n_chords):
     for s in range(3):
         _check(checker, networks.synthetic_meshed_network(n_bus, seed, n_chords), 10 * seed + s)
+
+
+@pytest.mark.parametrize("n_bus,seed,n_chords,group", [(66, 11, 10, 128), (130, 16, 0, 256), (200, 13, 30, 256), (300, 14, 40, 512),
+                                                       (513, 15, 40, 512)])
+def test_networks_larger_than_a_wavefront(checker, n_bus, seed, n_chords, group):
+    """above 65 buses the environment is a workgroup of 128 ... 512 lanes: the same program, more lanes per step"""
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if n_chords else networks.synthetic_radial_network(n_bus, seed)
+    steps, levels, g = _check(checker, net, seed)
+    assert g == group and levels <= 24
