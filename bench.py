@@ -82,47 +82,62 @@ def cpu_baseline(budget_s=12.0, all_cores=True):
     return out
 
 
+def transition_figure(dev, net, E, cap, n, load_scale=1.0, note=""):
+    """Simulator.transition launches on a fixed batch of random inputs (the SoC is restored before every launch so that
+    each launch does the same work), with the HBM roofline of the launch"""
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=E, device=dev, tol=1e-6, max_iter=cap)
+    m, b = sim.model, sim.model.baseMVA
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def U(lo, hi, scale=1.0):
+        lo, hi = torch.as_tensor(lo, device=dev) * scale, torch.as_tensor(hi, device=dev) * scale
+        return lo + (hi - lo) * torch.rand((E, lo.numel()), generator=g, dtype=torch.float64, device=dev)
+
+    pl = U(m.dev_p_min[m.load_idx] * b, 0 * m.dev_p_min[m.load_idx], load_scale)
+    pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * b)
+    ps = U(m.dev_p_min[m.setp_idx] * b, m.dev_p_max[m.setp_idx] * b, load_scale)
+    qs = U(m.dev_q_min[m.setp_idx] * b, m.dev_q_max[m.setp_idx] * b, load_scale)
+    soc = U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx])
+    if load_scale != 1.0:
+        pl[-max(1, E // 1024):] *= 40.0 / load_scale   # the diverging solves a large batch always holds
+    for _ in range(3):
+        sim.soc.copy_(soc)
+        sim.transition(pl, pp, ps, qs)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        sim.soc.copy_(soc)
+        sim.transition(pl, pp, ps, qs)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n
+    # HBM roofline of this launch (Simulator.transition with the electrical-state dump): compulsory bytes per
+    # transition = inputs (P_load, P_pot, P/Q set-points) + SoC in/out + dump + reward/e_loss/penalty +
+    # converged + nr_iters
+    nbytes = 8 * (m.N_load + m.N_non_slack_gen + 2 * len(m.setp_idx)) + 16 * m.N_des + 8 * sim.full_dim + 24 + 1 + 4
+    return {
+        "env_steps_per_s": E / dt, "us_per_launch": dt * 1e6, "impl": sim.impl, "lanes_per_env": sim.lanes_per_env,
+        "converged_frac": float(sim.pfe_converged.double().mean()),
+        "roofline": {"bound": "hbm", "algorithmic_bytes_per_transition": nbytes, "achieved": nbytes * E / dt / 1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes * E / dt / 1e9 / HBM_PEAK_GBPS,
+                     "note": "wall clock per launch incl. the SoC restore copy; lane-group kernel, fp64" + note},
+    }
+
+
 def case30_side_figure(dev, E=16384, n=20):
     from gym_anm_amd import networks
-    from gym_anm_amd.simulator import BatchedSimulator
 
     out = {}
     for cap in (100, 20):
-        sim = BatchedSimulator(networks.synthetic_radial_network(30, 0), 0.25, 100, num_envs=E, device=dev,
-                               tol=1e-6, max_iter=cap)  # fmt: skip
-        m, b = sim.model, sim.model.baseMVA
-        g = torch.Generator(device=dev).manual_seed(0)
-
-        def U(lo, hi):
-            lo, hi = torch.as_tensor(lo, device=dev), torch.as_tensor(hi, device=dev)
-            return lo + (hi - lo) * torch.rand((E, lo.numel()), generator=g, dtype=torch.float64, device=dev)
-
-        pl = U(m.dev_p_min[m.load_idx] * b, 0 * m.dev_p_min[m.load_idx])
-        pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * b)
-        ps = U(m.dev_p_min[m.setp_idx] * b, m.dev_p_max[m.setp_idx] * b)
-        qs = U(m.dev_q_min[m.setp_idx] * b, m.dev_q_max[m.setp_idx] * b)
-        soc = U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx])
-        for _ in range(3):
-            sim.soc.copy_(soc)
-            sim.transition(pl, pp, ps, qs)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            sim.soc.copy_(soc)
-            sim.transition(pl, pp, ps, qs)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / n
-        # HBM roofline of this launch (Simulator.transition with the electrical-state dump): compulsory bytes per
-        # transition = inputs (P_load, P_pot, P/Q set-points) + SoC in/out + dump + reward/e_loss/penalty +
-        # converged + nr_iters
-        nbytes = 8 * (m.N_load + m.N_non_slack_gen + 2 * len(m.setp_idx)) + 16 * m.N_des + 8 * sim.full_dim + 24 + 1 + 4
-        out["case30_radial_16384_cap%d" % cap] = {
-            "env_steps_per_s": E / dt, "us_per_launch": dt * 1e6, "impl": sim.impl,
-            "converged_frac": float(sim.pfe_converged.double().mean()),
-            "roofline": {"bound": "hbm", "algorithmic_bytes_per_transition": nbytes, "achieved": nbytes * E / dt / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes * E / dt / 1e9 / HBM_PEAK_GBPS,
-                         "note": "wall clock per launch incl. the SoC restore copy; lane-group kernel, fp64"},
-        }
+        out["case30_radial_16384_cap%d" % cap] = transition_figure(dev, networks.synthetic_radial_network(30, 0), E, cap, n)
+    # the general lane-group family: a meshed 30-bus network inside a wavefront, a meshed 200-bus network as one
+    # workgroup of 256 lanes per environment (loads scaled with 40 / n_bus: the synthetic feeders carry the same load
+    # per bus whatever their size)
+    out["mesh30_16384_cap100"] = transition_figure(dev, networks.synthetic_meshed_network(30, 6, 4), E, 100, n,
+                                                   note="; LDS-bound (block-sparse Jacobian in LDS), see DESIGN.md 4.6")
+    out["mesh200_4096_cap100"] = transition_figure(dev, networks.synthetic_meshed_network(200, 13, 30), 4096, 100, max(4, n // 4), 40.0 / 200,
+                                                   note="; one workgroup of 256 lanes per environment, see DESIGN.md 4.6")
     return out
 
 

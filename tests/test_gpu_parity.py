@@ -589,6 +589,40 @@ def test_two_phase_step_with_lane_group_stragglers_equals_the_in_wave_hand_over(
     assert n_term > 100
 
 
+@pytest.mark.parametrize("small_workspace,mid", [(False, 12), (True, 12), (False, 7), (False, 40)])
+def test_two_level_straggler_continuation_is_bit_identical(small_workspace, mid):
+    """Round 3: the first straggler launch stops at `straggler_mid` iterations and leaves the records still running
+    to a second, smaller launch (anm_step_ws.mid_cap).  Same lane-group code, same inputs as the one-level two-launch
+    step and as the in-wave hand-over: bit-identical, also with an overflowing workspace."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    E_ = 65536
+    envs = [ANM6EasyVec(num_envs=E_, device=DEV, seed=13, autoreset=True, tol=1e-6, straggler_after=sa, straggler_mid=sm, handoff_after=6)
+            for sa, sm in ((None, None), (6, None), (6, mid))]  # fmt: skip
+    assert envs[0]._ws is None and envs[1]._ws.mid_cap == -1 and envs[2]._ws.mid_cap == mid
+    if small_workspace:
+        rec = envs[2].simulator.backend.lib.anm_step_ws_record_doubles()
+        envs[2]._ws.n_doubles = 8 + 100 * rec + 50
+    for env in envs:
+        env.check_actions = False
+        env.reset(seed=13)
+    gen = torch.Generator(device=DEV).manual_seed(10)
+    lo = torch.as_tensor(envs[0].action_space.low, device=DEV)
+    hi = torch.as_tensor(envs[0].action_space.high, device=DEV)
+    n_term = 0
+    for t in range(8):
+        a = lo + (hi - lo) * torch.rand((E_, 6), generator=gen, dtype=torch.float64, device=DEV)
+        outs = [env.step(a) for env in envs]
+        n_term += int(outs[0][2].sum())
+        for k in (1, 2):
+            for x0, x1 in ((outs[0][0], outs[k][0]), (outs[0][1], outs[k][1]), (outs[0][2], outs[k][2]), (envs[0].state, envs[k].state),
+                           (envs[0].e_loss, envs[k].e_loss), (envs[0].penalty, envs[k].penalty), (envs[0].simulator.soc, envs[k].simulator.soc),
+                           (envs[0].simulator.nr_iters, envs[k].simulator.nr_iters), (envs[0].timestep, envs[k].timestep),
+                           (envs[0]._reset_count, envs[k]._reset_count), (envs[0]._aux_index, envs[k]._aux_index)):  # fmt: skip
+                assert torch.equal(x0, x1), (t, k)
+    assert n_term > 100
+
+
 def test_long_run_invariants():
     """3 000 steps of 65 536 autoresetting environments under a random agent: observations stay finite
     and inside the Box, rewards inside the clipping range, every environment keeps cycling through
