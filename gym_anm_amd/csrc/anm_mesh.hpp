@@ -69,11 +69,18 @@ constexpr int BR_SLOTS = 2;
 //                                      (products, sums, two back substitutions) the last two levels would take.
 //                                      s1 = D_a, s2 = A_ab, s3 = A_ba, s4 = D_b, s5 = r_a, s6 = r_b (x_a, x_b: where
 //                                      the r's index says)
+//   step ST_FUSE  OP_FUSE1 (i, j; k)   s1 = A_ij (or r_i) -= A_ik D_k^-1 A_kj with s2 = D_k, s3 = A_ik, s4 = A_kj (or r_k):
+//                 OP_FUSE2 (.; k, k')  product and subtraction by ONE lane in ONE step (round 3, experimental: a level is one step instead
+//                                      of a products step + a sums step; nothing is parked in LDS in between); FUSE2: a
+//                                      second contribution (s5, s6, s7), subtracted after the first.  A destination
+//                                      with more than two contributions takes further steps (same order).  With fused
+//                                      levels the inverted pivots are not stored: the back substitution inverts D_k
+//                                      itself (OP_INVBACK), D_k being intact.
 // s0 = the operation (0: the lane idles in this step).  Nothing a step reads is written in the same step, and
 // D_k, A_ik, A_kj stay as they are (the factor L_ik = A_ik D_k^-1 is never stored: every product recomputes it,
 // lanes are plentiful), so the operations of a level may be dealt to the lanes in any number of rounds.
-enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_BACK, OP_INVBACK, OP_ACC, OP_TAIL2 };
-enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_BACK = 2, ST_ACC = 3, ST_TAIL = 4 };
+enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_BACK, OP_INVBACK, OP_ACC, OP_TAIL2, OP_FUSE1, OP_FUSE2 };
+enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_BACK = 2, ST_ACC = 3, ST_TAIL = 4, ST_FUSE = 5 };
 enum DField : int { DF_YII_RE = 0, DF_YII_IM, DF_VMIN, DF_VMAX, DF_YFT_RE, DF_YFT_IM, DF_YTF_RE, DF_YTF_IM, DF_BRC,
                     DF_BR_FIELDS = DF_BRC + 9 - DF_YFT_RE, DF_COUNT = DF_YFT_RE + 2 * DF_BR_FIELDS };
 
@@ -243,12 +250,17 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   // place: the branch products W (written and summed before the step program starts) with the products of the
   // elimination, and V (read by the branch lanes at the start of a trip) with the Newton step x (written by the
   // back substitution, read by the update at the end of the trip)
+  // ANM_MESH_FUSED_LEVELS: product and subtraction of a level in one step (ST_FUSE).  Fewer steps (mesh30 12 -> 10,
+  // case30 11 -> 8, a 64-bus network 59 -> 46), no products parked in LDS, and no faster: a step's time is the
+  // dependent fp64 chain of its 2x2 block operations (inverse, two products), which the fused step strings together
+  // (profiles/r03_n_mesh_fused_levels.txt, r03_o_large_fused_levels.txt: within +-5 % everywhere).  Off by default.
+  const bool fuse = getenv("ANM_MESH_FUSED_LEVELS") != nullptr;
   d.l_v = 0;
   d.l_x = d.l_v;                         // x[NB][2] / vr[NB], vi[NB]
   d.l_blk = d.l_v + 2 * NB;
   d.l_r = d.l_blk + 4 * d.NBLK;          // r[NB] as blocks (r0, 0; r1, 0)
-  d.l_dinv = d.l_r + 4 * NB;             // inverted pivots [NB][4]
-  d.l_zero = d.l_dinv + 4 * NB;          // 6 zeros nobody writes: what an unused operand slot of a descriptor reads
+  d.l_dinv = d.l_r + 4 * NB;             // inverted pivots [NB][4] (split levels only)
+  d.l_zero = d.l_dinv + (fuse ? 0 : 4 * NB);   // 6 zeros nobody writes: what an unused operand slot of a descriptor reads
   d.l_bw = d.l_zero + 6;                 // W entries [2 NBR][2] / I = Y V terms [4][NBR] ...
   d.l_m = d.l_bw;                        // ... / products [n_m][4]
 
@@ -338,6 +350,36 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
           contrib[dst_of[i][j]].push_back(Contribution{i, k, j});
         }
     if (dsts.empty()) continue;
+    if (fuse) {
+      // fused levels: a destination's contributions two at a time, in pivot order
+      size_t n_r = 0;
+      for (const auto& c : contrib) n_r = std::max(n_r, (c.size() + 1) / 2);
+      for (size_t r = 0; r < n_r; ++r) {
+        std::vector<Desc> ops;
+        for (size_t q = 0; q < dsts.size(); ++q) {
+          const auto& c = contrib[q];
+          if (c.size() <= 2 * r) continue;
+          const int dst = dsts[q].second == NB ? oR + 4 * dsts[q].first : oB + 4 * blk[dsts[q].first][dsts[q].second];
+          Desc op = {OP_FUSE1, dst, 0, 0, 0, 0, 0, 0};
+          for (size_t u = 2 * r; u < std::min(c.size(), 2 * r + 2); ++u) {
+            const Contribution& x = c[u];
+            const int o = 2 + 3 * int(u - 2 * r);
+            op[o] = oB + 4 * blk[x.k][x.k];
+            op[o + 1] = oB + 4 * blk[x.i][x.k];
+            op[o + 2] = x.j == NB ? oR + 4 * x.k : oB + 4 * blk[x.k][x.j];
+            if (u > 2 * r) op[0] = OP_FUSE2;
+          }
+          ops.push_back(op);
+        }
+        for (size_t q = 0; q < ops.size(); q += G) {
+          int run = 1;
+          for (size_t u = q; u < std::min(ops.size(), q + G); ++u) run = std::max(run, ops[u][0] == OP_FUSE2 ? 2 : 1);
+          const int st = new_step(ST_FUSE | (run << 8));
+          for (size_t u = q; u < std::min(ops.size(), q + G); ++u) steps[st].push_back(ops[u]);
+        }
+      }
+      continue;
+    }
     // summation rounds: up to four products per destination and round (an unused operand is the zero block);
     // the products of a level are all alive at once, the next level reuses their places
     size_t n_rounds = 0;
@@ -400,7 +442,7 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
         steps[acc[max_acc - n_acc + a]].push_back(dsc);
       }
       Desc dsc = {OP_BACK, oR + 4 * k, oDI + 4 * k, oX + 2 * k, oZ, oZ + 4, oZ, oZ + 4};
-      if (up.empty()) { dsc[0] = OP_INVBACK; dsc[2] = oB + 4 * blk[k][k]; }
+      if (up.empty() || fuse) { dsc[0] = OP_INVBACK; dsc[2] = oB + 4 * blk[k][k]; }
       for (int c = 0; u < up.size(); ++c, ++u) { dsc[4 + 2 * c] = oB + 4 * blk[k][up[u]]; dsc[5 + 2 * c] = oX + 2 * up[u]; }
       steps[fin].push_back(dsc);
     }
@@ -810,6 +852,21 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
             const Blk<JT> M2 = ld4(o4), M3 = ld4(o5);
             Z.a -= M2.a; Z.b -= M2.b; Z.c -= M2.c; Z.d -= M2.d;
             Z.a -= M3.a; Z.b -= M3.b; Z.c -= M3.c; Z.d -= M3.d;
+          }
+          st4(o1, Z);
+        }
+      } else if ((ty & 0xff) == ST_FUSE) {
+        if (kind != OP_NONE) {
+          Blk<JT> Z = ld4(o1);
+          {
+            const Blk<JT> M = blk_mul(blk_mul(ld4(o3), blk_inv(ld4(o2))), ld4(o4));
+            Z.a -= M.a; Z.b -= M.b; Z.c -= M.c; Z.d -= M.d;
+          }
+          if ((ty >> 8) > 1) {
+            if (kind == OP_FUSE2) {
+              const Blk<JT> M = blk_mul(blk_mul(ld4(o6), blk_inv(ld4(o5))), ld4(o7));
+              Z.a -= M.a; Z.b -= M.b; Z.c -= M.c; Z.d -= M.d;
+            }
           }
           st4(o1, Z);
         }

@@ -71,7 +71,8 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
       // an operation may only ride in a step of its own type
       const int want = (kind == mesh::OP_PROD) ? mesh::ST_PROD : (kind == mesh::OP_SUM) ? mesh::ST_SUM
                        : (kind == mesh::OP_BACK || kind == mesh::OP_INVBACK) ? mesh::ST_BACK
-                       : (kind == mesh::OP_TAIL2) ? mesh::ST_TAIL : mesh::ST_ACC;
+                       : (kind == mesh::OP_TAIL2) ? mesh::ST_TAIL
+                       : (kind == mesh::OP_FUSE1 || kind == mesh::OP_FUSE2) ? mesh::ST_FUSE : mesh::ST_ACC;
       if (want != ty) return -5;
       if (ty == mesh::ST_PROD) {
         double D[4], Di[4], Aik[4], L[4], X[4], M[4];
@@ -80,6 +81,17 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
         if (o4 < d.l_m || o4 + 4 > d.l_m + 4 * d.n_m) return -6;
         product_written[o4] = 1;
         if (o5) for (int u = 0; u < 4; ++u) writes.push_back(W{o5 + u, Di[u]});
+      } else if (ty == mesh::ST_FUSE) {
+        if (run < 1 || run > 2 || (kind == mesh::OP_FUSE2 && run < 2)) return -8;
+        double Z[4];
+        ld4(o1, Z);
+        const int trip[2][3] = {{o2, o3, o4}, {o5, o6, o7}};
+        for (int c = 0; c < (kind == mesh::OP_FUSE2 ? 2 : 1); ++c) {
+          double D[4], Di[4], Aik[4], L[4], X[4], M[4];
+          ld4(trip[c][0], D); inv(D, Di); ld4(trip[c][1], Aik); mul(Aik, Di, L); ld4(trip[c][2], X); mul(L, X, M);
+          for (int u = 0; u < 4; ++u) Z[u] -= M[u];
+        }
+        for (int u = 0; u < 4; ++u) writes.push_back(W{o1 + u, Z[u]});
       } else if (ty == mesh::ST_TAIL) {
         double Da[4], Dai[4], Aab[4], Aba[4], Db[4], Dbi[4], L[4], M[4];
         ld4(o1, Da); inv(Da, Dai); ld4(o2, Aab); ld4(o3, Aba); ld4(o4, Db);

@@ -62,3 +62,16 @@ def test_networks_larger_than_a_wavefront(checker, n_bus, seed, n_chords, group)
     net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if n_chords else networks.synthetic_radial_network(n_bus, seed)
     steps, levels, g = _check(checker, net, seed)
     assert g == group and levels <= 24
+
+
+def test_fused_levels_schedule(checker, monkeypatch):
+    """ANM_MESH_FUSED_LEVELS: the experimental schedule with product and subtraction of a level in one step"""
+    monkeypatch.setenv("ANM_MESH_FUSED_LEVELS", "1")
+    split = {}
+    for name, net in (("mesh30", networks.synthetic_meshed_network(30, 6, 4)), ("case30", networks.synthetic_radial_network(30, 0)),
+                      ("mesh200", networks.synthetic_meshed_network(200, 13, 30))):
+        split[name] = _check(checker, net, 5)[0]
+    monkeypatch.delenv("ANM_MESH_FUSED_LEVELS")
+    for name, net in (("mesh30", networks.synthetic_meshed_network(30, 6, 4)), ("case30", networks.synthetic_radial_network(30, 0)),
+                      ("mesh200", networks.synthetic_meshed_network(200, 13, 30))):
+        assert _check(checker, net, 5)[0] > split[name]
