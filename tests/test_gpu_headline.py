@@ -357,6 +357,43 @@ def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeles
     return sim
 
 
+@pytest.mark.parametrize("n_bus,seed,n_chords", [(30, 6, 4), (64, 10, 24), (200, 13, 30)])
+def test_mesh_fused_levels_schedule_equals_the_default(monkeypatch, n_bus, seed, n_chords):
+    """ANM_MESH_FUSED_LEVELS (read when the model is created): product and subtraction of an elimination level in one
+    step.  Same operations on the same operands in the same order as the default schedule: bit-identical outputs."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords)
+    M = 256
+    sims = []
+    for fused in (False, True):
+        if fused:
+            monkeypatch.setenv("ANM_MESH_FUSED_LEVELS", "1")
+        sims.append(BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl="mesh"))
+    monkeypatch.delenv("ANM_MESH_FUSED_LEVELS")
+    model, rng = sims[0].model, np.random.default_rng(seed)
+    b, f = model.baseMVA, min(1.0, 40.0 / n_bus)
+
+    def U(lo, hi, scale=1.0):
+        lo, hi = np.asarray(lo, float) * scale, np.asarray(hi, float) * scale
+        return lo + (hi - lo) * rng.uniform(size=(M, lo.size))
+
+    pl = U(model.dev_p_min[model.load_idx], 0 * model.dev_p_min[model.load_idx], 0.6 * b * f)
+    pp = U(0 * model.dev_p_max[model.gen_idx], model.dev_p_max[model.gen_idx], b)
+    ps = U(model.dev_p_min[model.setp_idx], model.dev_p_max[model.setp_idx], 1.2 * b * f)
+    qs = U(model.dev_q_min[model.setp_idx], model.dev_q_max[model.setp_idx], 1.2 * b * f)
+    soc = U(model.dev_soc_min[model.des_idx], model.dev_soc_max[model.des_idx])
+    pl[-4:] *= 40.0 / f
+    for sim in sims:
+        sim.soc.copy_(torch.as_tensor(soc))
+        sim.transition(pl, pp, ps, qs)
+    assert int(sims[0].pfe_converged.sum()) >= M // 2
+    assert torch.equal(sims[0].pfe_converged, sims[1].pfe_converged) and torch.equal(sims[0].nr_iters, sims[1].nr_iters)
+    conv = sims[0].pfe_converged
+    assert torch.equal(sims[0].full[conv], sims[1].full[conv]) and torch.equal(sims[0].reward[conv], sims[1].reward[conv])
+
+
 def test_environment_over_a_network_larger_than_a_wavefront():
     env = pc.large_network_env(KW)
     assert env.simulator.lanes_per_env == 256
