@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash scripts/r03_profile.sh <stage> [what...]
 # kernel traces + PMC passes (one counter group per pass, kernel-trace only); summaries land in
-# gpurun_out/r03_<stage>_*.txt ready to be copied to profiles/.  what: head mpc thr c30 (default: all)
+# gpurun_out/r03_<stage>_*.txt ready to be copied to profiles/.  what: head mpc thr c30 wg (default: head mpc thr c30)
 stage=$1; shift
 what="${@:-head mpc thr c30}"
 R=$GRAFT_REPO_ROOT
@@ -45,6 +45,14 @@ thr)
     for k in k_step_rows k_step_stragglers k_step_scatter; do
       ANM_PMC_KERNEL=$k python $R/scripts/pmc_summary.py $out/pmc_thr$E "throughput regime: ANM6Easy $E envs on one GPU, two-launch step; kernel $k"
     done > $R/gpurun_out/r03_${stage}_pmc_throughput_$E.txt
+  done
+  ;;
+wg)
+  for NB in 30 200; do
+    CMD="python $R/scripts/large_network_workload.py $NB 4096 12"
+    trace mesh$NB "command: scripts/large_network_workload.py $NB 4096 12 (general lane-group family; 200 buses: one workgroup of 256 lanes per environment)" $CMD
+    pmc $out/pmc_mesh$NB $CMD
+    ANM_PMC_KERNEL=k_mesh python $R/scripts/pmc_summary.py $out/pmc_mesh$NB "k_mesh: synthetic meshed network of $NB buses, 4096 transitions per launch, cap 100" > $R/gpurun_out/r03_${stage}_pmc_mesh$NB.txt
   done
   ;;
 c30)
