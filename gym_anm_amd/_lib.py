@@ -53,11 +53,12 @@ class StepWs(C.Structure):
 
 class MpcDims(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ["planning_steps", "n_load", "n_gen", "n_des", "n_branch", "n_ctrl",
-                                         "n_stage_vars", "n_stage_rows", "table_doubles"]]  # fmt: skip
+                                         "n_stage_vars", "n_stage_rows", "table_doubles", "angle_rows"]] + \
+               [("angle_bound", C.c_double)]  # fmt: skip
 
 
 class MpcOpts(C.Structure):
-    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("trace", C.c_void_p)]
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("trace", C.c_void_p), ("angle_rows", C.c_int32)]
 
 
 class SolverOpts(C.Structure):

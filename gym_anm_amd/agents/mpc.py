@@ -153,7 +153,7 @@ class BatchedDCOPF:
     request, the whole primal solution stay available as tensors."""
 
     def __init__(self, simulator, gamma, safety_margin, planning_steps, tol=None, max_iter=None, keep_solution=False,
-                 keep_trace=False):
+                 keep_trace=False, angle_rows=None):
         from .. import _lib
 
         self.backend, self.device = simulator.backend, simulator.device
@@ -169,7 +169,11 @@ class BatchedDCOPF:
         d = _lib.MpcDims()
         self.backend.check(lib.anm_mpc_dims_of(self._handle, C.byref(d)), "anm_mpc_dims_of")
         self.dims = d
-        self.opts = _lib.MpcOpts(tol=0.0 if tol is None else float(tol), max_iter=0 if max_iter is None else int(max_iter))
+        # angle_rows: None = the library's choice (dims.angle_rows: the rows |theta| <= pi ride through the solve only
+        # where an angle can come near pi within the device limits); True / False force them in / out (left out, the
+        # solution's angles are checked: info[:, 1] == 2 where one exceeds pi)
+        self.opts = _lib.MpcOpts(tol=0.0 if tol is None else float(tol), max_iter=0 if max_iter is None else int(max_iter),
+                                 angle_rows=0 if angle_rows is None else (1 if angle_rows else 2))
         self.max_iter = 40 if max_iter is None else int(max_iter)
         self.keep_solution, self.keep_trace = keep_solution, keep_trace
         self._E = None

@@ -148,6 +148,8 @@ struct anm_mpc {
   int N = 0;
   std::vector<double> tab;   // host copy of the table of the reduced program (mpc::Sz<Topo>)
   double* d_tab = nullptr;
+  double theta_bound = 0.0;  // largest |angle| within the device limits
+  bool angle_rows = true;    // the automatic choice: carry the rows |theta| <= pi through the solve
 };
 
 namespace {
@@ -993,29 +995,43 @@ int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double
   return 0;
 }
 
+typedef mpc::NoTheta<Topo> TopoNoTheta;
+
+extern "C++" template <class TT>
+bool mpc_lds_attribute() {   // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, at creation)
+  if (size_t(2) * mpc::Sz<TT>::NR * 64 * sizeof(double) <= 64 * 1024) return true;
+  return hipFuncSetAttribute((const void*)mpc::k_mpc<TT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+         hipFuncSetAttribute((const void*)mpc::k_mpc<TT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+}
+
 int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps, anm_mpc** out) {
   if (!desc || !out) return fail("anm_mpc_create: null argument");
-  if constexpr (!mpc::Sz<Topo>::FITS) {
+  constexpr bool FITS_FULL = mpc::Sz<Topo>::FITS, FITS_RELAXED = mpc::Sz<TopoNoTheta>::FITS;
+  if constexpr (!FITS_RELAXED) {
     return fail("anm_mpc_create: this network has too many rows per stage for the register-resident MPC kernel");
   } else {
     std::string err;
     if (!check_topology<Topo>(*desc, err)) { g_err = err; return -3; }
     anm_mpc* m = new (std::nothrow) anm_mpc();
     if (!m) return fail("out of host memory");
-    if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err)) {
+    if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err, &m->theta_bound)) {
       delete m;
       g_err = err;
       return -3;
     }
     m->N = planning_steps;
-    if (size_t(2) * mpc::Sz<Topo>::NR * 64 * sizeof(double) > 64 * 1024) {
-      // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, here, not in a launch path)
-      hipError_t a1 = hipFuncSetAttribute((const void*)mpc::k_mpc<Topo, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipError_t a2 = hipFuncSetAttribute((const void*)mpc::k_mpc<Topo, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (a1 != hipSuccess || a2 != hipSuccess) {
-        delete m;
-        return fail_hip(a1 != hipSuccess ? a1 : a2, "anm_mpc_create: LDS size attribute");
-      }
+    // the angle rows ride along only where an angle could come near pi while the devices stay inside their limits
+    m->angle_rows = m->theta_bound >= 0.98 * 3.14159265358979323846;
+    if (m->angle_rows && !FITS_FULL) {
+      delete m;
+      return fail("anm_mpc_create: this network needs its angle rows (an angle can reach pi within the device limits) and has too "
+                  "many rows per stage with them for the register-resident MPC kernel");
+    }
+    bool ok = mpc_lds_attribute<TopoNoTheta>();
+    if constexpr (FITS_FULL) ok = ok && mpc_lds_attribute<Topo>();
+    if (!ok) {
+      delete m;
+      return fail("anm_mpc_create: LDS size attribute");
     }
     hipError_t e = hipMalloc(&m->d_tab, m->tab.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(m->d_tab, m->tab.data(), m->tab.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -1038,7 +1054,10 @@ int anm_mpc_dims_of(const anm_mpc* m, anm_mpc_dims* o) {
   if (!m || !o) return fail("anm_mpc_dims_of: null argument");
   typedef mpc::Sz<Topo> S;
   o->planning_steps = m->N; o->n_load = S::NL; o->n_gen = S::NG; o->n_des = S::NS; o->n_branch = S::NBR;
-  o->n_ctrl = S::NC; o->n_stage_vars = S::NV; o->n_stage_rows = S::NR; o->table_doubles = S::T_TOTAL;
+  o->n_ctrl = S::NC; o->n_stage_vars = S::NV; o->table_doubles = S::T_TOTAL;
+  o->n_stage_rows = m->angle_rows ? S::NR : mpc::Sz<TopoNoTheta>::NR;
+  o->angle_rows = m->angle_rows ? 1 : 0;
+  o->angle_bound = m->theta_bound;
   return 0;
 }
 
@@ -1062,16 +1081,31 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
     if (opts->max_iter > 0) o.max_iter = opts->max_iter;
   }
   mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, opts ? opts->trace : nullptr};
+  bool full = m->angle_rows;
+  if (opts && opts->angle_rows == 1) full = true;
+  if (opts && opts->angle_rows == 2) full = false;
   int G = 1;
   while (G < m->N) G *= 2;
   const int per_wave = 64 / G;
   const unsigned grid = unsigned((num_envs + per_wave - 1) / per_wave);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds_bytes = size_t(2) * S::NR * 64 * sizeof(double);
-  if (G == 1)
-    hipLaunchKernelGGL((mpc::k_mpc<Topo, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
-  else
-    hipLaunchKernelGGL((mpc::k_mpc<Topo, false>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+  if (full) {
+    if constexpr (S::FITS) {
+      const size_t lds_bytes = size_t(2) * S::NR * 64 * sizeof(double);
+      if (G == 1)
+        hipLaunchKernelGGL((mpc::k_mpc<Topo, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+      else
+        hipLaunchKernelGGL((mpc::k_mpc<Topo, false>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+    } else {
+      return fail("anm_mpc_solve_f64: with its angle rows this network has too many rows per stage for the MPC kernel");
+    }
+  } else {
+    const size_t lds_bytes = size_t(2) * mpc::Sz<TopoNoTheta>::NR * 64 * sizeof(double);
+    if (G == 1)
+      hipLaunchKernelGGL((mpc::k_mpc<TopoNoTheta, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+    else
+      hipLaunchKernelGGL((mpc::k_mpc<TopoNoTheta, false>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_mpc");
   return 0;

@@ -30,6 +30,7 @@
 #include <complex>
 #include <cstdint>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/anm_mi355x.h"
@@ -48,14 +49,29 @@ constexpr int pos(int n) { return n > 0 ? n : 1; }
 #define ANM_UFOR for
 #endif
 
+// The angle rows |theta_b| <= pi (mpc.py:291-292) are redundant for most networks: over the whole box of the device
+// limits no angle comes near pi (ANM6: 0.2 rad).  NoTheta<Topo> is the topology WITHOUT those rows in the program: the
+// solver then checks the angles of its solution instead (a solution of the relaxed program that satisfies the dropped
+// rows is a solution of the full one; one that does not is reported, info[1] = 2).  anm_mpc_create picks the variant
+// from a bound over the device limits (build_tables: theta_bound).
+template <class T>
+struct NoTheta : T {
+  static constexpr bool MPC_NO_THETA = true;
+};
+template <class T, class = void>
+struct has_theta_rows : std::true_type {};
+template <class T>
+struct has_theta_rows<T, std::void_t<decltype(T::MPC_NO_THETA)>> : std::false_type {};
+
 template <class T>
 struct Sz {
   static constexpr int NG = T::NGEN, NS = T::NDES, NL = T::NLOAD, NB1 = T::NB - 1, NBR = T::NBR;
   static constexpr int NC = NG + NS, NA = NG + 2 * NS, NV = NA + NBR;
+  static constexpr int NTH = has_theta_rows<T>::value ? NB1 : 0;   // angle rows carried through the solve (per side)
   // rows of one stage, in this order
   static constexpr int R_XI_UP = 0, R_XI_LO = NG, R_PD_UP = 2 * NG, R_PD_LO = R_PD_UP + NS, R_PC = R_PD_LO + NS,
                        R_D = R_PC + NS, R_SOC_UP = R_D + NS, R_SOC_LO = R_SOC_UP + NS, R_TH_UP = R_SOC_LO + NS,
-                       R_TH_LO = R_TH_UP + NB1, R_FL1 = R_TH_LO + NB1, R_FL2 = R_FL1 + NBR, R_FL3 = R_FL2 + NBR,
+                       R_TH_LO = R_TH_UP + NTH, R_FL1 = R_TH_LO + NTH, R_FL2 = R_FL1 + NBR, R_FL3 = R_FL2 + NBR,
                        NR = R_FL3 + NBR;
   // what the register-resident kernel is compiled for (slacks + multipliers + work arrays of NR rows per lane)
   static constexpr bool FITS = NR <= 72 && NS <= 2 && NA <= 8;
@@ -126,7 +142,7 @@ inline bool invert(std::vector<double>& a, int n) {  // Gauss-Jordan with partia
 
 template <class T>
 inline bool build_tables(const anm_network_desc& d, double gamma, double safety_margin, int N, std::vector<double>& tab,
-                         std::string& err) {
+                         std::string& err, double* theta_bound = nullptr) {
   typedef Sz<T> S;
   const int nb = T::NB, nd = T::ND;
   if (N < 1 || N > 64) { err = "planning_steps must be in [1, 64] (one lane per stage)"; return false; }
@@ -215,6 +231,18 @@ inline bool build_tables(const anm_network_desc& d, double gamma, double safety_
     tab[S::T_BC + j] = d.delta_t * d.dev_eff[k];
     tab[S::T_BD + j] = d.delta_t / d.dev_eff[k];
   }
+  if (theta_bound) {
+    // the largest |angle| any bus can reach while every device stays inside its limits (loads: [P_min, 0])
+    double worst = 0.0;
+    for (int r = 0; r < S::NB1; ++r) {
+      double a = 0.0;
+      for (int c = 0; c < S::NC; ++c)
+        a += std::fabs(tab[S::T_THC + r * S::NC + c]) * std::fmax(std::fabs(d.dev_pmin[ctrl[c]]), std::fabs(d.dev_pmax[ctrl[c]]));
+      for (int l = 0; l < S::NL; ++l) a += std::fabs(tab[S::T_THL + r * S::NL + l]) * std::fabs(d.dev_pmin[loads[l]]);
+      worst = std::fmax(worst, a);
+    }
+    *theta_bound = worst;
+  }
   tab[S::T_LAMB] = d.lamb;
   double w = 1.0;
   for (int i = 0; i < 64; ++i) {
@@ -293,7 +321,7 @@ struct Lane {
       val[S::R_SOC_LO + j] = C[S::T_SOCMIN + j] - sig[j];
     }
     const double PI = 3.14159265358979323846;
-    ANM_UFOR (int b = 0; b < NB1; ++b) {
+    ANM_UFOR (int b = 0; b < S::NTH; ++b) {
       double th = th0[b];
       ANM_UFOR (int c = 0; c < NC; ++c) th = fma(C[S::T_THC + b * NC + c], u[c], th);
       val[S::R_TH_UP + b] = th - PI;
@@ -326,7 +354,7 @@ struct Lane {
                        double (&gt)[pos(NBR)]) const {
     double gu[pos(NC)];
     ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = wgt * C[S::T_COST + c];
-    ANM_UFOR (int b = 0; b < NB1; ++b) {
+    ANM_UFOR (int b = 0; b < S::NTH; ++b) {
       const double dz = zh(S::R_TH_UP + b) - zh(S::R_TH_LO + b);
       ANM_UFOR (int c = 0; c < NC; ++c) gu[c] = fma(dz, C[S::T_THC + b * NC + c], gu[c]);
     }
@@ -353,7 +381,7 @@ struct Lane {
   ANM_HD void factor_stage(cptr_t C) {
     double Hu[pos(NC * (NC + 1) / 2)];
     ANM_UFOR (int k = 0; k < NC * (NC + 1) / 2; ++k) Hu[k] = 0.0;
-    ANM_UFOR (int b = 0; b < NB1; ++b) {
+    ANM_UFOR (int b = 0; b < S::NTH; ++b) {
       const double wb = w(S::R_TH_UP + b) + w(S::R_TH_LO + b);
       ANM_UFOR (int i = 0; i < NC; ++i) {
         const double wi = wb * C[S::T_THC + b * NC + i];
@@ -487,7 +515,7 @@ struct Step {
       f(S::R_SOC_UP + j, xs[j]);
       f(S::R_SOC_LO + j, -xs[j]);
     }
-    ANM_UFOR (int b = 0; b < NB1; ++b) {
+    ANM_UFOR (int b = 0; b < S::NTH; ++b) {
       double a = 0.0;
       ANM_UFOR (int c = 0; c < NC; ++c) a = fma(C[S::T_THC + b * NC + c], du[c], a);
       f(S::R_TH_UP + b, a);
@@ -631,10 +659,22 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
     if (!done) { mu = n_mu; rdmax = n_rd; obj = n_obj; }
     if (!done && (mu <= opt.tol * (1.0 + fabs(obj)) || it >= opt.max_iter || !(mu == mu) || !startable)) {
       done = true;
+      bool relaxed_ok = true;
+      if constexpr (S::NTH == 0 && NB1 > 0) {   // the angle rows were left out: the solution must satisfy them
+        double u[pos(NC)];
+        ln.phys(C, u);
+        bool viol = false;
+        ANM_UFOR (int b = 0; b < NB1; ++b) {
+          double th = ln.th0[b];
+          ANM_UFOR (int c = 0; c < NC; ++c) th = fma(C[S::T_THC + b * NC + c], u[c], th);
+          viol = viol || !(fabs(th) <= 3.14159265358979323846);
+        }
+        relaxed_ok = x.max(on && viol ? 1.0 : 0.0) < 0.5;
+      }
       if (valid && i == 0) {
         io.objective[env] = obj;
-        io.iters[env] = startable ? it : opt.max_iter;
-        if (io.info) { io.info[env * 3] = mu; io.info[env * 3 + 1] = startable ? 0.0 : 1.0; io.info[env * 3 + 2] = rdmax; }
+        io.iters[env] = (startable && relaxed_ok) ? it : opt.max_iter;
+        if (io.info) { io.info[env * 3] = mu; io.info[env * 3 + 1] = !startable ? 1.0 : (relaxed_ok ? 0.0 : 2.0); io.info[env * 3 + 2] = rdmax; }
         double u[pos(NC)];
         ln.phys(C, u);
         ANM_UFOR (int c = 0; c < NC; ++c) io.u0[env * NC + c] = u[c];

@@ -289,8 +289,12 @@ typedef struct anm_mpc_dims {
   int32_t n_load, n_gen, n_des, n_branch;
   int32_t n_ctrl;          /* n_gen + n_des: width of u0 = [P_gen.., P_des..] */
   int32_t n_stage_vars;    /* n_gen + 2 n_des + n_branch: width of one stage of `solution` (P_g.., p_c.., d.., t_e..) */
-  int32_t n_stage_rows;    /* inequality rows per stage of the reduced program */
+  int32_t n_stage_rows;    /* inequality rows per stage of the reduced program as it is solved by default */
   int32_t table_doubles;
+  int32_t angle_rows;      /* 1: the rows |theta_b| <= pi (mpc.py:291-292) ride through the solve by default; 0: no angle
+                              can come near pi while the devices stay inside their limits (angle_bound < 0.98 pi), the rows
+                              are left out and the solution's angles are checked instead */
+  double angle_bound;      /* largest |theta_b| (rad) any bus can reach within the device limits */
 } anm_mpc_dims;
 
 typedef struct anm_mpc_opts {
@@ -301,6 +305,8 @@ typedef struct anm_mpc_opts {
   double* trace;     /* NULL, or dev [num_envs, max_iter + 1, 12]: per iteration mu, 0, dual residual, objective,
                         then, of the step taken from there: primal / dual step length, centring parameter, predictor mu,
                         and the row that limited the primal step (stage, row, its slack, its slack step) */
+  int32_t angle_rows; /* 0: as anm_mpc_dims.angle_rows says; 1: carry the angle rows; 2: leave them out and check the
+                        solution (info[., 1] = 2 and iters = max_iter where an angle of the solution exceeds pi) */
 } anm_mpc_opts;
 
 int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps,
@@ -312,8 +318,9 @@ int anm_mpc_get_tables(const anm_mpc* m, double* out /* [table_doubles] host */)
 /* p_load_forecast [num_envs, N, n_load], p_gen_forecast [num_envs, N, n_gen] (mpc.py:348-372: forecast(), here
  * stage-major), soc [num_envs, n_des] (mpc.py:417).  Out: u0 [num_envs, n_ctrl] the first-stage P_gen / P_des
  * (mpc.py:383-388, before the scaling to MW), objective [num_envs] (the value of the reference's program),
- * iters [num_envs], info [num_envs, 3] (final mu; 1 if some stage has no interior starting point -- reported as not converged --
- * else 0; largest dual residual; may be NULL), solution
+ * iters [num_envs], info [num_envs, 3] (final mu; 1 if some stage has no interior starting point, 2 if the angle rows
+ * were left out and the solution violates one -- both reported as not converged -- else 0; largest dual residual; may be
+ * NULL), solution
  * [num_envs, N, n_stage_vars] (may be NULL).  All dev.  An environment whose solve does not reach the tolerance
  * within max_iter reports iters = max_iter (not an error, like a non-"optimal" status in the reference, :377-379). */
 int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,

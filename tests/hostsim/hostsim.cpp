@@ -37,6 +37,8 @@ struct anm_model {
 struct anm_mpc {
   int N = 0;
   std::vector<double> tab;
+  double theta_bound = 0.0;
+  bool angle_rows = true;
 };
 
 // the lanes of one group as host threads
@@ -206,15 +208,18 @@ int anm_model_bind_env_classes(anm_model*, const int32_t* env_class, int64_t) {
 }
 // ---- MPC DC-OPF: the solver of gym_anm_amd/csrc/anm_mpc.hpp with one HOST THREAD per lane (= stage); what the
 // wavefront shuffles do on the GPU goes through an exchange array between two barriers
+typedef mpc::NoTheta<Topo> TopoNoTheta;
 int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps, anm_mpc** out) {
-  if constexpr (!mpc::Sz<Topo>::FITS) {
+  if constexpr (!mpc::Sz<TopoNoTheta>::FITS) {
     return fail("anm_mpc_create: this network has too many rows per stage for the register-resident MPC kernel");
   } else {
     std::string err;
     if (!check_topology<Topo>(*desc, err)) { g_err = err; return -3; }
     anm_mpc* m = new anm_mpc();
-    if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err)) { delete m; g_err = err; return -3; }
+    if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err, &m->theta_bound)) { delete m; g_err = err; return -3; }
     m->N = planning_steps;
+    m->angle_rows = m->theta_bound >= 0.98 * 3.14159265358979323846;   // (as anm_capi.hip)
+    if (m->angle_rows && !mpc::Sz<Topo>::FITS) { delete m; return fail("anm_mpc_create: too many rows per stage with the angle rows"); }
     *out = m;
     return 0;
   }
@@ -223,33 +228,45 @@ void anm_mpc_destroy(anm_mpc* m) { delete m; }
 int anm_mpc_dims_of(const anm_mpc* m, anm_mpc_dims* o) {
   typedef mpc::Sz<Topo> S;
   o->planning_steps = m->N; o->n_load = S::NL; o->n_gen = S::NG; o->n_des = S::NS; o->n_branch = S::NBR;
-  o->n_ctrl = S::NC; o->n_stage_vars = S::NV; o->n_stage_rows = S::NR; o->table_doubles = S::T_TOTAL;
+  o->n_ctrl = S::NC; o->n_stage_vars = S::NV; o->table_doubles = S::T_TOTAL;
+  o->n_stage_rows = m->angle_rows ? S::NR : mpc::Sz<TopoNoTheta>::NR;
+  o->angle_rows = m->angle_rows ? 1 : 0;
+  o->angle_bound = m->theta_bound;
   return 0;
 }
 int anm_mpc_get_tables(const anm_mpc* m, double* out) {
   std::memcpy(out, m->tab.data(), m->tab.size() * sizeof(double));
   return 0;
 }
-int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
-                      const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
-                      const anm_mpc_opts* opts, void*) {
-  if constexpr (mpc::Sz<Topo>::FITS) {
-    mpc::Opts o{1e-11, 40};
-    if (opts) {
-      if (opts->tol > 0.0) o.tol = opts->tol;
-      if (opts->max_iter > 0) o.max_iter = opts->max_iter;
-    }
-    mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, opts ? opts->trace : nullptr};
+extern "C++" template <class TT>
+void host_mpc_solve(anm_mpc* m, const mpc::IO& io, const mpc::Opts& o, int64_t num_envs) {
+  if constexpr (mpc::Sz<TT>::FITS) {
     const int N = m->N;
     HostGroupShared sh(N);
     std::vector<std::thread> th;
     for (int st = 0; st < N; ++st)
       th.emplace_back([&, st]() {
         HostGroup x{&sh, st};
-        for (int64_t e = 0; e < num_envs; ++e) mpc::solve<Topo>(m->tab.data(), io, o, e, true, N, x);
+        for (int64_t e = 0; e < num_envs; ++e) mpc::solve<TT>(m->tab.data(), io, o, e, true, N, x);
       });
     for (auto& t : th) t.join();
   }
+}
+int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
+                      const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
+                      const anm_mpc_opts* opts, void*) {
+  mpc::Opts o{1e-11, 40};
+  if (opts) {
+    if (opts->tol > 0.0) o.tol = opts->tol;
+    if (opts->max_iter > 0) o.max_iter = opts->max_iter;
+  }
+  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, opts ? opts->trace : nullptr};
+  bool full = m->angle_rows;
+  if (opts && opts->angle_rows == 1) full = true;
+  if (opts && opts->angle_rows == 2) full = false;
+  if (full && !mpc::Sz<Topo>::FITS) return fail("anm_mpc_solve_f64: too many rows per stage with the angle rows");
+  if (full) host_mpc_solve<Topo>(m, io, o, num_envs);
+  else host_mpc_solve<TopoNoTheta>(m, io, o, num_envs);
   return 0;
 }
 int anm_model_bind_state_same(anm_model*, uint8_t* p) { return p ? fail("the host test double writes every state row") : 0; }

@@ -130,7 +130,14 @@ def check_tables(sim, gamma=0.97, margin=0.93, N=5):
     tab = sol.tables()
     sl, total = _table_slices(red)
     assert total == sol.dims.table_doubles == len(tab)
-    assert sol.dims.n_stage_rows == red.nr and sol.dims.n_stage_vars == red.nv and sol.dims.n_ctrl == red.nc
+    m = sim.model
+    ctrl = red.gens + red.des
+    pmin, pmax = np.asarray(m.dev_p_min, float), np.asarray(m.dev_p_max, float)
+    bound = np.max(np.abs(red.Th_c[red.theta_rows]) @ np.maximum(np.abs(pmin[ctrl]), np.abs(pmax[ctrl]))
+                   + np.abs(red.Th_l[red.theta_rows]) @ np.abs(pmin[red.loads])) if len(red.theta_rows) else 0.0
+    assert abs(sol.dims.angle_bound - bound) <= 1e-12 * (1 + bound) and sol.dims.angle_rows == int(bound >= 0.98 * np.pi)
+    assert sol.dims.n_stage_rows == red.nr - (0 if sol.dims.angle_rows else 2 * len(red.theta_rows))
+    assert sol.dims.n_stage_vars == red.nv and sol.dims.n_ctrl == red.nc
     cmp = lambda name, ref: np.testing.assert_allclose(tab[sl[name]][: np.size(ref)], np.ravel(ref), rtol=1e-12, atol=1e-14, err_msg=name)  # noqa: E731
     cmp("thc", red.Th_c[red.theta_rows])
     cmp("thl", red.Th_l[red.theta_rows])
@@ -300,6 +307,56 @@ def test_other_stock_networks_host():
     check_other_stock_networks(_host_sim, 4)
 
 
+def check_angle_rows(make_sim):
+    """the rows |theta| <= pi (mpc.py:291-292) ride through the solve only where an angle can come near pi within the
+    device limits; left out, the solution's angles are checked (a solution of the relaxed program that satisfies the
+    dropped rows solves the full one)"""
+    rng = np.random.default_rng(8)
+    # ANM6: no angle beyond 0.3 rad whatever the devices do -> relaxed by default; carrying the rows changes nothing
+    sim = make_sim(networks.anm6_network())
+    m = sim.model
+    N, E = 4, 6
+    pl = -rng.uniform(0, 1, (E, len(m.load_idx), N)) * (-m.dev_p_min[m.load_idx])[None, :, None]
+    pg = rng.uniform(0, 1, (E, len(m.gen_idx), N)) * m.dev_p_max[m.gen_idx][None, :, None]
+    soc = rng.uniform(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx], (E, len(m.des_idx)))
+    sols = {}
+    for rows in (None, True):
+        s_ = BatchedDCOPF(sim, 0.995, 0.9, N, keep_solution=True, angle_rows=rows)
+        assert s_.dims.angle_rows == 0 and s_.dims.angle_bound < 1.0
+        s_.solve(pl, pg, soc)
+        assert int(s_.iters.max()) < s_.max_iter and float(s_.info[:, 1].max()) == 0.0
+        sols[rows] = (s_.objective.cpu().numpy().copy(), s_.u0.cpu().numpy().copy())
+    np.testing.assert_allclose(sols[None][0], sols[True][0], rtol=1e-8, atol=1e-8)
+    # the 3-bus loop in its own per-unit base: angles reach pi -> the rows are carried by default; forced out, the
+    # programs whose optimum sits AT an angle limit are reported (info 2, not converged), the others agree
+    net = networks.three_bus_loop_network()
+    sim = make_sim(net)
+    m = sim.model
+    n = O.parse_network(net, 0.25, 100)
+    N, E = 2, 8
+    pl = -rng.uniform(0, 1, (E, len(m.load_idx), N)) * (-m.dev_p_min[m.load_idx])[None, :, None]
+    pg = rng.uniform(0, 1, (E, len(m.gen_idx), N)) * m.dev_p_max[m.gen_idx][None, :, None]
+    soc = rng.uniform(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx], (E, len(m.des_idx)))
+    full = BatchedDCOPF(sim, 0.995, 0.9, N)
+    assert full.dims.angle_rows == 1 and full.dims.angle_bound > np.pi
+    full.solve(pl, pg, soc)
+    relaxed = BatchedDCOPF(sim, 0.995, 0.9, N, angle_rows=False)
+    relaxed.solve(pl, pg, soc)
+    flagged = relaxed.info[:, 1].cpu().numpy() == 2.0
+    assert flagged.any() and (relaxed.iters.cpu().numpy()[flagged] == relaxed.max_iter).all()
+    for e in range(E):
+        ref = MO.solve_dcopf(n, pl[e], pg[e], soc[e], 0.995, 0.9, N)
+        assert abs(float(full.objective[e]) - ref["objective"]) <= 2e-7 * (1 + abs(ref["objective"]))
+        if not flagged[e]:
+            assert abs(float(relaxed.objective[e]) - ref["objective"]) <= 2e-7 * (1 + abs(ref["objective"]))
+        else:
+            assert float(relaxed.objective[e]) < ref["objective"] - 1e-6   # the relaxed program's value: below the full one's
+
+
+def test_angle_rows_host():
+    check_angle_rows(_host_sim)
+
+
 def test_closed_loop_on_the_host_double():
     from hostsim_backend import hostsim_backend
 
@@ -367,6 +424,11 @@ def test_solver_vs_highs_random_programs_gpu():
 def test_two_storage_units_and_a_classical_generator_gpu():
     net = two_storage_network()
     check_random_programs(_gpu_sim(net), net, 16, 3, horizons=(1, 3, 8, 16))
+
+
+@pytest.mark.gpu
+def test_angle_rows_gpu():
+    check_angle_rows(_gpu_sim)
 
 
 @pytest.mark.gpu
