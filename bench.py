@@ -203,7 +203,7 @@ def mpc_side_figure(dev):
         nbytes = 8 * (N * (d.n_load + d.n_gen) + d.n_des + d.n_ctrl + 1 + 3) + 4
         out["mpc_dcopf_anm6_65536_N%d" % N] = {
             "programs_per_s": E / (ms * 1e-3), "ms_per_solve": ms, "mean_iterations": float(sol.iters.double().mean()),
-            "max_iterations": int(sol.iters.max()), "rows_per_stage": int(d.n_stage_rows),
+            "max_iterations": int(sol.iters.max()), "rows_per_stage": int(d.n_stage_rows), "angle_rows_carried": bool(d.angle_rows),
             "roofline": {"bound": "hbm", "achieved": nbytes * E / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": nbytes * E / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_program": nbytes,
                          "note": "an interior-point solve per program: fp64-issue bound by nature (~%d iterations of a few "
