@@ -999,7 +999,7 @@ typedef mpc::NoTheta<Topo> TopoNoTheta;
 
 extern "C++" template <class TT>
 bool mpc_lds_attribute() {   // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, at creation)
-  if (size_t(2) * mpc::Sz<TT>::NR * 64 * sizeof(double) <= 64 * 1024) return true;
+  if (mpc::Sz<TT>::LDS_BYTES <= 64 * 1024) return true;
   return hipFuncSetAttribute((const void*)mpc::k_mpc<TT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
          hipFuncSetAttribute((const void*)mpc::k_mpc<TT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
 }
@@ -1091,7 +1091,7 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (full) {
     if constexpr (S::FITS) {
-      const size_t lds_bytes = size_t(2) * S::NR * 64 * sizeof(double);
+      const size_t lds_bytes = S::LDS_BYTES;
       if (G == 1)
         hipLaunchKernelGGL((mpc::k_mpc<Topo, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
       else
@@ -1100,7 +1100,7 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
       return fail("anm_mpc_solve_f64: with its angle rows this network has too many rows per stage for the MPC kernel");
     }
   } else {
-    const size_t lds_bytes = size_t(2) * mpc::Sz<TopoNoTheta>::NR * 64 * sizeof(double);
+    const size_t lds_bytes = mpc::Sz<TopoNoTheta>::LDS_BYTES;
     if (G == 1)
       hipLaunchKernelGGL((mpc::k_mpc<TopoNoTheta, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
     else

@@ -75,6 +75,12 @@ struct Sz {
                        NR = R_FL3 + NBR;
   // what the register-resident kernel is compiled for (slacks + multipliers + work arrays of NR rows per lane)
   static constexpr bool FITS = NR <= 72 && NS <= 2 && NA <= 8;
+  // the work arrays of NR rows: ds*dz always lives in LDS, 1/s above this many rows (in registers up to it: the ANM6
+  // program without its angle rows, 25 rows, then runs at 470 / 498 registers, no scratch, and 6 % faster; with both
+  // arrays in registers the compiler spills 476 B)
+  static constexpr int ROWS_IN_REGISTERS = 28;
+  static constexpr bool ROWS_IN_LDS = true;
+  static constexpr size_t LDS_BYTES = ROWS_IN_LDS ? size_t(2) * NR * 64 * sizeof(double) : 0;
   // table of constants (doubles), wave-uniform
   static constexpr int T_THC = 0, T_THL = T_THC + NB1 * NC, T_PHC = T_THL + NB1 * NL, T_PHL = T_PHC + NBR * NC,
                        T_COST = T_PHL + NBR * NL, T_SGL = T_COST + pos(NC), T_LIM = T_SGL + pos(NL),
@@ -269,21 +275,40 @@ struct Lane {
   double s[NR], z[NR];
   // 1/s and the predictor's ds*dz: on the GPU in LDS (row-major [row][lane] of the wavefront: conflict-free, and 4 NR
   // registers less per lane -- with them the kernel needs more than the 512 a lane can have), registers on the host
+  // (1/s only for programs of more than Sz::ROWS_IN_REGISTERS rows per stage)
 #if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr bool IN_LDS = S::ROWS_IN_LDS, IS_IN_LDS = S::NR > S::ROWS_IN_REGISTERS;
   // (volatile: every use is a ds_read -- otherwise the compiler keeps what it has read in registers, which is what
   // moving the arrays to LDS is meant to avoid)
   volatile __attribute__((address_space(3))) double* lds;   // this lane's column of the wavefront's [2 NR][64] block
-  ANM_HD volatile __attribute__((address_space(3))) double& is(int r) { return lds[r * 64]; }
-  ANM_HD double is(int r) const { return lds[r * 64]; }
-  ANM_HD volatile __attribute__((address_space(3))) double& cross(int r) { return lds[(NR + r) * 64]; }
-  ANM_HD double cross(int r) const { return lds[(NR + r) * 64]; }
 #else
-  double is_[NR], cross_[NR];
-  ANM_HD double& is(int r) { return is_[r]; }
-  ANM_HD double is(int r) const { return is_[r]; }
-  ANM_HD double& cross(int r) { return cross_[r]; }
-  ANM_HD double cross(int r) const { return cross_[r]; }
+  static constexpr bool IN_LDS = false, IS_IN_LDS = false;
 #endif
+  double is_[IS_IN_LDS ? 1 : NR], cross_[IN_LDS ? 1 : NR];
+  ANM_HD double is(int r) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (IS_IN_LDS) return lds[r * 64];
+#endif
+    return is_[IS_IN_LDS ? 0 : r];
+  }
+  ANM_HD double cross(int r) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (IN_LDS) return lds[(NR + r) * 64];
+#endif
+    return cross_[IN_LDS ? 0 : r];
+  }
+  ANM_HD void set_is(int r, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (IS_IN_LDS) { lds[r * 64] = v; return; }
+#endif
+    is_[IS_IN_LDS ? 0 : r] = v;
+  }
+  ANM_HD void set_cross(int r, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (IN_LDS) { lds[(NR + r) * 64] = v; return; }
+#endif
+    cross_[IN_LDS ? 0 : r] = v;
+  }
   // constants of the stage
   double wd[pos(NG)], th0[pos(NB1)], f0[pos(NBR)], wgt, ct, objc;
   // per iteration
@@ -622,7 +647,7 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
     }
     ANM_UFOR (int r = 0; r < NR; ++r) {
       ln.z[r] = r >= S::R_FL1 ? ln.ct * (1.0 / 3.0) : 1.0;  // dual feasible for the epigraph variables
-      ln.cross(r) = 0.0;
+      ln.set_cross(r, 0.0);
     }
   }
   // (no interior start: a storage unit that cannot both charge and discharge, an angle limit the loads alone
@@ -693,7 +718,7 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
     if (tr) { tr[0] = n_mu; tr[1] = 0.0; tr[2] = n_rd; tr[3] = n_obj; }
     if (x.all_done(done)) break;
     // ---- factor (once per iteration) ----
-    ANM_UFOR (int r = 0; r < NR; ++r) ln.is(r) = recip(ln.s[r]);
+    ANM_UFOR (int r = 0; r < NR; ++r) ln.set_is(r, recip(ln.s[r]));
     ln.factor_stage(C);
     {  // value functions, last stage first:  P_i = Q_i + P'_{i+1}  (Q: the weights of the window rows).  Systolic:
        // in every step EVERY lane refactors with what its successor handed down last; stage k has its final input
@@ -792,7 +817,7 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
       sdz = fma(ln.s[r], dz, sdz);
       zds = fma(ln.z[r], ds, zds);
       dsdz = fma(ds, dz, dsdz);
-      ln.cross(r) = ds * dz;
+      ln.set_cross(r, ds * dz);
     });
     ms = x.max(on ? ms : 0.0);
     mz = x.max(on ? mz : 0.0);
