@@ -1000,8 +1000,21 @@ typedef mpc::NoTheta<Topo> TopoNoTheta;
 extern "C++" template <class TT>
 bool mpc_lds_attribute() {   // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, at creation)
   if (mpc::Sz<TT>::LDS_BYTES <= 64 * 1024) return true;
-  return hipFuncSetAttribute((const void*)mpc::k_mpc<TT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-         hipFuncSetAttribute((const void*)mpc::k_mpc<TT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  return hipFuncSetAttribute((const void*)mpc::k_mpc<TT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+         hipFuncSetAttribute((const void*)mpc::k_mpc<TT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+         hipFuncSetAttribute((const void*)mpc::k_mpc<TT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+}
+
+// one group of G lanes per environment: one thread (N = 1), a part of a DPP row (N <= 16), half or all of a wavefront
+extern "C++" template <class TT>
+void launch_mpc(unsigned grid, hipStream_t s, anm_mpc* m, const mpc::IO& io, const mpc::Opts& o, int64_t num_envs, int G) {
+  const size_t lds_bytes = mpc::Sz<TT>::LDS_BYTES;
+  if (G == 1)
+    hipLaunchKernelGGL((mpc::k_mpc<TT, 0>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+  else if (G <= 16)
+    hipLaunchKernelGGL((mpc::k_mpc<TT, 1>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+  else
+    hipLaunchKernelGGL((mpc::k_mpc<TT, 2>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
 }
 
 int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps, anm_mpc** out) {
@@ -1090,21 +1103,10 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
   const unsigned grid = unsigned((num_envs + per_wave - 1) / per_wave);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (full) {
-    if constexpr (S::FITS) {
-      const size_t lds_bytes = S::LDS_BYTES;
-      if (G == 1)
-        hipLaunchKernelGGL((mpc::k_mpc<Topo, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
-      else
-        hipLaunchKernelGGL((mpc::k_mpc<Topo, false>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
-    } else {
-      return fail("anm_mpc_solve_f64: with its angle rows this network has too many rows per stage for the MPC kernel");
-    }
+    if constexpr (S::FITS) launch_mpc<Topo>(grid, s, m, io, o, num_envs, G);
+    else return fail("anm_mpc_solve_f64: with its angle rows this network has too many rows per stage for the MPC kernel");
   } else {
-    const size_t lds_bytes = mpc::Sz<TopoNoTheta>::LDS_BYTES;
-    if (G == 1)
-      hipLaunchKernelGGL((mpc::k_mpc<TopoNoTheta, true>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
-    else
-      hipLaunchKernelGGL((mpc::k_mpc<TopoNoTheta, false>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
+    launch_mpc<TopoNoTheta>(grid, s, m, io, o, num_envs, G);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_mpc");

@@ -869,54 +869,87 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
 // gfx950: the lanes of a group exchange through wavefront shuffles.  SINGLE: one stage, one thread per
 // environment, no exchange at all.
 // ------------------------------------------------------------------------------------------------------------
-template <bool SINGLE>
+// one DPP move of a double inside its row of 16 lanes; lanes a shift brings in from outside the row read 0
+template <int CTRL>
+__device__ __forceinline__ double row_move(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// (masked form: rows outside `ROWS` read 0)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double row_move_masked(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// the value of the lane 16 / 32 lanes away (lane ^ 16, lane ^ 32): gfx950's v_permlane16_swap / v_permlane32_swap of a
+// register with a copy of itself leave the odd rows' (upper half's) values in one result and the even rows' (lower
+// half's) in the other
+__device__ __forceinline__ double lane_xor16(double x, bool odd_row) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+  return __hiloint2double(odd_row ? hi[0] : hi[1], odd_row ? lo[0] : lo[1]);
+}
+__device__ __forceinline__ double lane_xor32(double x, bool upper) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+  return __hiloint2double(upper ? hi[0] : hi[1], upper ? lo[0] : lo[1]);
+}
+
+// MODE 0: one stage, one thread per environment, no exchange at all.
+// MODE 1: groups of 2, 4, 8 or 16 lanes (N <= 16): a group lies inside a DPP row.
+// MODE 2: groups of 32 or 64 lanes.
+// Every exchange is a handful of v_mov_b32_dpp / v_permlane*_swap (no LDS crossbar, no latency to wait for):
+// neighbours by row_shr:1 / row_shl:1 (across rows: wave_shr:1 / wave_shl:1); all-reduces by the quad permutations,
+// row_half_mirror and row_mirror, then lane ^ 16 and lane ^ 32 (each step pairs a lane with one of the other half
+// of its 2-, 4-, ... 64-lane block: both add the same two numbers, so every lane of the group ends with the same
+// bits); prefix sums by row_shr:1, 2, 4, 8, then row_bcast15 / row_bcast31.  A step beyond the group is carried
+// out and dropped: no loop whose trip count depends on G -- with such loops between them the row arrays of the lane
+// no longer fit its registers.
+template <int MODE>
 struct WaveGroup {
-  int G, st;
+  static constexpr bool SINGLE = MODE == 0, ROW = MODE == 1;
+  int G, st, lane;
   __device__ int stage() const { return st; }
   __device__ double up(double v) const {
     if (SINGLE) return 0.0;
-    const double r = __shfl_up(v, 1, G);
+    const double r = ROW ? row_move<0x111>(v) : row_move<0x138>(v);
     return st == 0 ? 0.0 : r;
   }
   __device__ double down(double v) const {
     if (SINGLE) return 0.0;
-    const double r = __shfl_down(v, 1, G);
+    const double r = ROW ? row_move<0x101>(v) : row_move<0x130>(v);
     return st == G - 1 ? 0.0 : r;
   }
-  // butterflies of a fixed six steps (a step beyond the group adds the neutral element): no loop whose trip count
-  // depends on G -- with such loops between them the row arrays of the lane no longer fit its registers
-  __device__ double sum(double v) const {
-    if (!SINGLE) {
-      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_xor(v, o, 64);
-        v += o < G ? t : 0.0;
+  template <class Op>
+  __device__ double all(double v, Op op) const {
+    if constexpr (!SINGLE) {
+      v = op(v, row_move<0xB1>(v));                                      // quad_perm [1, 0, 3, 2]
+      { const double t = op(v, row_move<0x4E>(v)); v = G > 2 ? t : v; }   // quad_perm [2, 3, 0, 1]
+      { const double t = op(v, row_move<0x141>(v)); v = G > 4 ? t : v; }  // row_half_mirror
+      { const double t = op(v, row_move<0x140>(v)); v = G > 8 ? t : v; }  // row_mirror
+      if constexpr (!ROW) {
+        v = op(v, lane_xor16(v, (lane & 16) != 0));
+        { const double t = op(v, lane_xor32(v, (lane & 32) != 0)); v = G > 32 ? t : v; }
       }
     }
     return v;
   }
-  __device__ double max(double v) const {
-    if (!SINGLE) {
-      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_xor(v, o, 64);
-        v = o < G ? fmax(v, t) : v;
-      }
-    }
-    return v;
-  }
-  __device__ double min(double v) const {
-    if (!SINGLE) {
-      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_xor(v, o, 64);
-        v = o < G ? fmin(v, t) : v;
-      }
-    }
-    return v;
-  }
+  __device__ double sum(double v) const { return all(v, [](double a, double b) { return a + b; }); }
+  __device__ double max(double v) const { return all(v, [](double a, double b) { return fmax(a, b); }); }
+  __device__ double min(double v) const { return all(v, [](double a, double b) { return fmin(a, b); }); }
   __device__ double scan(double v) const {
-    if (!SINGLE) {
-      _Pragma("unroll") for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_up(v, o, 64);
-        v += (o < G && st >= o) ? t : 0.0;
+    if constexpr (!SINGLE) {
+      const int r = st & 15;   // place in the row
+      { const double t = row_move<0x111>(v); v += r >= 1 ? t : 0.0; }
+      { const double t = row_move<0x112>(v); v += r >= 2 ? t : 0.0; }
+      { const double t = row_move<0x114>(v); v += r >= 4 ? t : 0.0; }
+      { const double t = row_move<0x118>(v); v += r >= 8 ? t : 0.0; }
+      if constexpr (!ROW) {
+        v += row_move_masked<0x142, 0xA>(v);                                        // rows 1, 3 += the total of rows 0, 2
+        { const double t = row_move_masked<0x143, 0xC>(v); v += G > 32 ? t : 0.0; }  // rows 2, 3 += the total of rows 0 + 1
       }
     }
     return v;
@@ -924,12 +957,12 @@ struct WaveGroup {
   __device__ bool all_done(bool d) const { return __all(d); }
 };
 
-template <class T, bool SINGLE>
+template <class T, int MODE>
 __global__ __launch_bounds__(64) void k_mpc(cptr_t C, IO io, Opts opt, int64_t n_envs, int N, int G) {
   if constexpr (Sz<T>::FITS) {
     const int lane = threadIdx.x;
     const int64_t env = int64_t(blockIdx.x) * (64 / G) + lane / G;
-    WaveGroup<SINGLE> x{G, lane % G};
+    WaveGroup<MODE> x{G, lane % G, lane};
     extern __shared__ double mpc_lds[];   // [2 NR][64]: 1/s and the predictor's ds*dz of every row of every lane
     solve<T>(C, io, opt, env, env < n_envs, N, x, mpc_lds + lane);
   }
