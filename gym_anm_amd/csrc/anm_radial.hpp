@@ -408,8 +408,11 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   double vm = 1.0, cs = 1.0, sn = 0.0;
   double vr = 1.0, vi = 0.0, ir = 0.0, ii = 0.0, vpr = 1.0, vpi = 0.0;
   int it = 0;
-  double diff = 0.0;
+  bool g_bad = false, g_nan = false;   // the group's ||F||inf > tol / F has a NaN, as of its last evaluation
   bool active = true;
+  const unsigned long long busm = __builtin_amdgcn_uicmp(isbus ? 1u : 0u, 0u, group::ICMP_NE);
+  const unsigned long long gmask = (G >= 64) ? ~0ull : (((1ull << G) - 1ull) << ((t & 63) - l));
+  const unsigned glo = unsigned(gmask), ghi = unsigned(gmask >> 32);
   const int pl = gb + (parent >= 0 ? parent : 0);
   // Same formulation as the thread-per-environment kernels (PFState in anm_device.hpp): everything
   // comes from W_ik = V_i conj(Y_ik V_k).  A lane owns W_bb, W_bp (its row, parent column) and W_pb
@@ -467,18 +470,16 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       sr += sh[A_UPR][c];
       si += sh[A_UPI][c];
     }
-    // ---- mismatch and its inf-norm over the group
+    // ---- mismatch; "||F||inf > tol" and "F has a NaN" over the group, on lane masks (as anm_group.hpp and anm_mesh.hpp:
+    // two compares and a few scalar instructions instead of ten ds_bpermute butterflies): all the reference's loop
+    // and flags need; a group that stopped keeps its verdict
     const double fr = sr - bus_p, fi = si - bus_q;
-    double a = isbus ? fmax(fabs(fr), fabs(fi)) : 0.0;
-    double nanf = (isbus && (fr != fr || fi != fi)) ? 1.0 : 0.0;
-    for (int m = 1; m < G; m <<= 1) {
-      a = fmax(a, __shfl_xor(a, m, G));
-      nanf = fmax(nanf, __shfl_xor(nanf, m, G));
-    }
-    const double nd = (nanf > 0.0) ? NAN : a;
-    if (it == 0) diff = nd;            // initial evaluation
-    else if (active) diff = nd;
-    active = (diff > so.tol) && (it < so.max_iter);
+    const unsigned long long badm = __builtin_amdgcn_fcmp(isbus ? fmax(fabs(fr), fabs(fi)) : 0.0, so.tol, group::FCMP_UGT);
+    const unsigned long long nanm = __builtin_amdgcn_fcmp(fr, fi, group::FCMP_UNO) & busm;
+    const bool nb = ((unsigned(badm) & glo) | (unsigned(badm >> 32) & ghi)) != 0u;
+    const bool nn = ((unsigned(nanm) & glo) | (unsigned(nanm >> 32) & ghi)) != 0u;
+    if (it == 0 || active) { g_bad = nb; g_nan = nn; }
+    active = g_bad && !g_nan && (it < so.max_iter);   // NaN > tol is false, like the reference
     ANM_GROUP_SYNC();
     if (!__any(active && env_ok && !skip)) break;
     // ---- Jacobian blocks (magnitude columns scaled by |V|): own diagonal, coupling with the parent
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     }
     it = active ? it + 1 : it;
   }
-  f_nan = (diff != diff);
-  f_bad = !(diff <= so.tol);
+  f_nan = g_nan;
+  f_bad = g_nan || g_bad;
   }
   // V of the final iterate; the parent's through LDS
   vr = vm * cs;
