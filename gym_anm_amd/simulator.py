@@ -189,7 +189,8 @@ class BatchedSimulator:
         self.impl = {0: "thread", 1: "radial", 2: "mesh"}[self.backend.lib.anm_model_get_impl(self._handle)]
         # per-environment heterogeneous networks (the reference builds one Simulator per network): `variants`
         # are networks with the topology of `network` and other numbers, env_variant[e] in [0, len(variants)]
-        # picks the network of environment e (0 = `network`), constant over aligned blocks of 64 environments
+        # picks the network of environment e (0 = `network`); constant over aligned blocks of 64 environments it runs
+        # on every kernel family, any other assignment on the lane-group families
         self.variant_models = [self.model]
         self.env_variant = None
         if variants:
