@@ -74,7 +74,12 @@ struct Sz {
                        R_TH_LO = R_TH_UP + NTH, R_FL1 = R_TH_LO + NTH, R_FL2 = R_FL1 + NBR, R_FL3 = R_FL2 + NBR,
                        NR = R_FL3 + NBR;
   // what the register-resident kernel is compiled for (slacks + multipliers + work arrays of NR rows per lane)
-  static constexpr bool FITS = NR <= 72 && NS <= 2 && NA <= 8;
+  // Up to 72 rows, 2 storage units and 8 inputs per stage the lane's working set fits its 512 registers (no scratch);
+  // beyond, up to what the LDS row arrays of a wavefront allow (2 NR x 64 doubles <= 160 KB), the same code is compiled
+  // with the row arrays spilling to scratch (a 30-bus feeder with 5 storage units: 123 rows, 7 KB per lane): slower
+  // per program, still one launch for all of them
+  static constexpr bool IN_REGISTERS = NR <= 72 && NS <= 2 && NA <= 8;
+  static constexpr bool FITS = NR <= 156 && NS <= 6 && NA <= 16;
   // the work arrays of NR rows: ds*dz always lives in LDS, 1/s above this many rows (in registers up to it: the ANM6
   // program without its angle rows, 25 rows, then runs at 470 / 498 registers, no scratch, and 6 % faster; with both
   // arrays in registers the compiler spills 476 B)

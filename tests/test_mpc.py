@@ -353,6 +353,11 @@ def check_angle_rows(make_sim):
             assert float(relaxed.objective[e]) < ref["objective"] - 1e-6   # the relaxed program's value: below the full one's
 
 
+def test_network_beyond_the_register_budget_host():
+    net = networks.synthetic_radial_network(30, 0)
+    check_random_programs(_host_sim(net), net, 3, 3, horizons=(1, 3, 6))
+
+
 def test_angle_rows_host():
     check_angle_rows(_host_sim)
 
@@ -424,6 +429,14 @@ def test_solver_vs_highs_random_programs_gpu():
 def test_two_storage_units_and_a_classical_generator_gpu():
     net = two_storage_network()
     check_random_programs(_gpu_sim(net), net, 16, 3, horizons=(1, 3, 8, 16))
+
+
+@pytest.mark.gpu
+def test_network_beyond_the_register_budget_gpu():
+    """30-bus feeder, 5 storage units: 123 rows and 42 variables per stage -- the same solver source with its row arrays
+    in scratch (Sz::IN_REGISTERS false)"""
+    net = networks.synthetic_radial_network(30, 0)
+    check_random_programs(_gpu_sim(net), net, 6, 3, horizons=(1, 3, 10))
 
 
 @pytest.mark.gpu
