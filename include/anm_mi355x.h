@@ -281,7 +281,10 @@ int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const d
  *                        and the slack injection) from the same network description as anm_model_create
  *   anm_mpc_solve_f64 <- MPCAgent._update_parameters + _solve               mpc.py:372-417
  *
- * planning_steps in [1, 64].  Forecasts and results are per-unit, like the reference's program. */
+ * planning_steps in [1, 64].  Forecasts and results are per-unit, like the reference's program.  The kernel is compiled
+ * for the topology of the library: up to 72 rows, 2 storage units and n_gen + 2 n_des <= 8 inputs per stage its working
+ * set lives in registers; up to 156 rows, 6 storage units and 16 inputs it runs with its row arrays in scratch (slower);
+ * beyond, anm_mpc_create refuses. */
 typedef struct anm_mpc anm_mpc; /* opaque: device tables of one (network, gamma, safety margin, horizon) */
 
 typedef struct anm_mpc_dims {
