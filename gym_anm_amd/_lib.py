@@ -218,6 +218,42 @@ def load_for_topology(topo, impl=None) -> Backend:
     return be
 
 
+MPC_ABI = ("anm_last_error", "anm_topology_signature", "anm_mpc_create", "anm_mpc_destroy", "anm_mpc_dims_of", "anm_mpc_get_tables",
+           "anm_mpc_solve_f64")
+
+
+class MpcBackend:
+    """The MPC-only library of a topology (``libmpc_<topology>.so``): the ``anm_mpc_*`` entry points alone."""
+
+    def __init__(self, cdll, path):
+        for name in MPC_ABI:
+            res, args = ABI.get(name, (C.c_char_p, []))
+            fn = getattr(cdll, name)
+            fn.restype, fn.argtypes = res, args
+        self.lib, self.path, self.device_type = cdll, path, "cuda"
+
+    check = Backend.check
+    signature = Backend.signature
+
+
+def load_mpc_for_topology(topo) -> MpcBackend:
+    """Build (first use: one hipcc run of csrc/anm_mpc_only.hip) and load the MPC kernel of ``topo``: for networks
+    whose step runs in generic mode on the lane-group kernels of a library compiled for another topology."""
+    name = "mpc:" + codegen.topology_name(topo)
+    if name in _CACHE:
+        return _CACHE[name]
+    path = codegen.build_library(topo, mpc_only=True)
+    try:
+        cdll = C.CDLL(path)
+    except OSError as ex:
+        raise E.HipExtensionError("cannot load the gfx950 library %s: %s" % (path, ex)) from ex
+    be = MpcBackend(cdll, path)
+    if be.signature() != codegen.topology_signature(topo):
+        raise E.HipExtensionError("library %s was built for another topology (%s)" % (path, be.signature()))
+    _CACHE[name] = be
+    return be
+
+
 def as_c(arr, dtype):
     a = np.ascontiguousarray(arr, dtype=dtype)
     ptr_t = c_double_p if dtype == np.float64 else c_int32_p

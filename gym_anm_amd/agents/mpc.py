@@ -157,6 +157,10 @@ class BatchedDCOPF:
         from .. import _lib
 
         self.backend, self.device = simulator.backend, simulator.device
+        if getattr(self.backend, "generic", False):
+            # the simulator steps on the table-driven lane-group kernels of a library compiled for another topology;
+            # the MPC kernel is specialised on the sizes of THIS one: its own small library (built on first use)
+            self.backend = _lib.load_mpc_for_topology(simulator.model.topology())
         self._device_ctx = simulator._device_ctx
         self._stream_ptr = lambda: _lib_stream(self.device)
         self.N = int(planning_steps)

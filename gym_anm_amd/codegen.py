@@ -436,8 +436,8 @@ def _tag() -> str:
     return "." + t if t else ""
 
 
-def lib_path(name: str) -> str:
-    return os.path.join(BUILD_DIR, "libanm_%s%s.so" % (name, _tag()))
+def lib_path(name: str, mpc_only=False) -> str:
+    return os.path.join(BUILD_DIR, "lib%s_%s%s.so" % ("mpc" if mpc_only else "anm", name, _tag()))
 
 
 def header_path(name: str) -> str:
@@ -468,7 +468,7 @@ def _build_stamp(header_text, flags):
     h = hashlib.sha256()
     h.update(header_text.encode())
     h.update("\0".join(flags).encode())
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hpp", ".hip", ".h"))]
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hpp", ".hip", ".h", ".inc"))]
     files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "anm_mi355x.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -494,8 +494,11 @@ def library_is_fresh(lib: str) -> bool:
     return stamp == _build_stamp(text, HIPCC_FLAGS + extra)
 
 
-def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):
+def build_library(topo, name=None, force=False, verbose=False, extra_flags=(), mpc_only=False):
     """Write the descriptor and compile ``libanm_<name>.so`` for gfx950 (no GPU needed to build).
+
+    ``mpc_only``: ``libmpc_<name>.so`` instead -- the MPC kernel and the ``anm_mpc_*`` entry points alone
+    (csrc/anm_mpc_only.hip), for networks whose step runs on the table-driven kernels of another library.
 
     Safe to call from several processes at once (one rank per GPU): the compile is serialised by a
     lock file and the library is put in place by an atomic rename."""
@@ -503,7 +506,7 @@ def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):
 
     name = name or topology_name(topo)
     os.makedirs(BUILD_DIR, exist_ok=True)
-    hdr, lib = header_path(name), lib_path(name)
+    hdr, lib = header_path(name), lib_path(name, mpc_only)
     text = emit_header(topo, name)
     extra_flags = list(extra_flags) + os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
     stamp = _build_stamp(text, HIPCC_FLAGS + extra_flags)
@@ -537,7 +540,7 @@ def build_library(topo, name=None, force=False, verbose=False, extra_flags=()):
             cmd = [hipcc] + HIPCC_FLAGS + extra_flags + [
                 '-DANM_TOPO_HEADER="%s"' % hdr,
                 "-I", os.path.join(os.path.dirname(PKG_DIR), "include"),
-                os.path.join(CSRC, "anm_capi.hip"),
+                os.path.join(CSRC, "anm_mpc_only.hip" if mpc_only else "anm_capi.hip"),
                 "-o", tmp,
             ]  # fmt: skip
             if verbose:
@@ -573,11 +576,21 @@ def stock_topologies():
     return {k: NetworkModel(v, 0.25, 100).topology() for k, v in nets.items()}
 
 
+def stock_mpc_only_topologies():
+    """MPC-only libraries built ahead of time: a meshed 20-bus network (the GPU tests' example of a network that steps
+    in generic mode and has its MPC kernel compiled for its own topology)."""
+    from . import networks
+    from .model import NetworkModel
+
+    return {"mpc:mesh20": NetworkModel(networks.synthetic_meshed_network(20, 3, 6), 0.25, 100).topology()}
+
+
 def build_stock(force=False, verbose=False):
     """Build the stock libraries (in parallel: each is one independent hipcc invocation)."""
     from concurrent.futures import ThreadPoolExecutor
 
-    topos = stock_topologies()
-    with ThreadPoolExecutor(max_workers=len(topos)) as pool:
+    topos, mpc_topos = stock_topologies(), stock_mpc_only_topologies()
+    with ThreadPoolExecutor(max_workers=len(topos) + len(mpc_topos)) as pool:
         futs = {nm: pool.submit(build_library, topo, None, force, verbose) for nm, topo in topos.items()}
+        futs.update({nm: pool.submit(build_library, topo, None, force, verbose, (), True) for nm, topo in mpc_topos.items()})
         return {nm: f.result() for nm, f in futs.items()}

@@ -23,6 +23,8 @@
 
 using namespace anm;
 
+#include "anm_mpc_capi_types.inc"
+
 namespace {
 
 constexpr int BLOCK = 64;
@@ -144,13 +146,6 @@ struct anm_model {
   std::vector<cplx> ybus;
 };
 
-struct anm_mpc {
-  int N = 0;
-  std::vector<double> tab;   // host copy of the table of the reduced program (mpc::Sz<Topo>)
-  double* d_tab = nullptr;
-  double theta_bound = 0.0;  // largest |angle| within the device limits
-  bool angle_rows = true;    // the automatic choice: carry the rows |theta| <= pi through the solve
-};
 
 namespace {
 
@@ -995,123 +990,7 @@ int anm_time_step_launches(anm_model* m, int64_t n, const double* action, double
   return 0;
 }
 
-typedef mpc::NoTheta<Topo> TopoNoTheta;
-
-extern "C++" template <class TT>
-bool mpc_lds_attribute() {   // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, at creation)
-  if (mpc::Sz<TT>::LDS_BYTES <= 64 * 1024) return true;
-  return hipFuncSetAttribute((const void*)mpc::k_mpc<TT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-         hipFuncSetAttribute((const void*)mpc::k_mpc<TT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-         hipFuncSetAttribute((const void*)mpc::k_mpc<TT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-}
-
-// one group of G lanes per environment: one thread (N = 1), a part of a DPP row (N <= 16), half or all of a wavefront
-extern "C++" template <class TT>
-void launch_mpc(unsigned grid, hipStream_t s, anm_mpc* m, const mpc::IO& io, const mpc::Opts& o, int64_t num_envs, int G) {
-  const size_t lds_bytes = mpc::Sz<TT>::LDS_BYTES;
-  if (G == 1)
-    hipLaunchKernelGGL((mpc::k_mpc<TT, 0>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
-  else if (G <= 16)
-    hipLaunchKernelGGL((mpc::k_mpc<TT, 1>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
-  else
-    hipLaunchKernelGGL((mpc::k_mpc<TT, 2>), dim3(grid), dim3(64), lds_bytes, s, (cptr_t)m->d_tab, io, o, num_envs, m->N, G);
-}
-
-int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_margin, int32_t planning_steps, anm_mpc** out) {
-  if (!desc || !out) return fail("anm_mpc_create: null argument");
-  constexpr bool FITS_FULL = mpc::Sz<Topo>::FITS, FITS_RELAXED = mpc::Sz<TopoNoTheta>::FITS;
-  if constexpr (!FITS_RELAXED) {
-    return fail("anm_mpc_create: this network has too many rows per stage for the register-resident MPC kernel");
-  } else {
-    std::string err;
-    if (!check_topology<Topo>(*desc, err)) { g_err = err; return -3; }
-    anm_mpc* m = new (std::nothrow) anm_mpc();
-    if (!m) return fail("out of host memory");
-    if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err, &m->theta_bound)) {
-      delete m;
-      g_err = err;
-      return -3;
-    }
-    m->N = planning_steps;
-    // the angle rows ride along only where an angle could come near pi while the devices stay inside their limits
-    m->angle_rows = m->theta_bound >= 0.98 * 3.14159265358979323846;
-    if (m->angle_rows && !FITS_FULL) {
-      delete m;
-      return fail("anm_mpc_create: this network needs its angle rows (an angle can reach pi within the device limits) and has too "
-                  "many rows per stage with them for the register-resident MPC kernel");
-    }
-    bool ok = mpc_lds_attribute<TopoNoTheta>();
-    if constexpr (FITS_FULL) ok = ok && mpc_lds_attribute<Topo>();
-    if (!ok) {
-      delete m;
-      return fail("anm_mpc_create: LDS size attribute");
-    }
-    hipError_t e = hipMalloc(&m->d_tab, m->tab.size() * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpy(m->d_tab, m->tab.data(), m->tab.size() * sizeof(double), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-      anm_mpc_destroy(m);
-      return fail_hip(e, "anm_mpc_create: device tables");
-    }
-    *out = m;
-    return 0;
-  }
-}
-
-void anm_mpc_destroy(anm_mpc* m) {
-  if (!m) return;
-  if (m->d_tab) hipFree(m->d_tab);
-  delete m;
-}
-
-int anm_mpc_dims_of(const anm_mpc* m, anm_mpc_dims* o) {
-  if (!m || !o) return fail("anm_mpc_dims_of: null argument");
-  typedef mpc::Sz<Topo> S;
-  o->planning_steps = m->N; o->n_load = S::NL; o->n_gen = S::NG; o->n_des = S::NS; o->n_branch = S::NBR;
-  o->n_ctrl = S::NC; o->n_stage_vars = S::NV; o->table_doubles = S::T_TOTAL;
-  o->n_stage_rows = m->angle_rows ? S::NR : mpc::Sz<TopoNoTheta>::NR;
-  o->angle_rows = m->angle_rows ? 1 : 0;
-  o->angle_bound = m->theta_bound;
-  return 0;
-}
-
-int anm_mpc_get_tables(const anm_mpc* m, double* out) {
-  if (!m || !out) return fail("anm_mpc_get_tables: null argument");
-  std::memcpy(out, m->tab.data(), m->tab.size() * sizeof(double));
-  return 0;
-}
-
-int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
-                      const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
-                      const anm_mpc_opts* opts, void* stream) {
-  typedef mpc::Sz<Topo> S;
-  if (!m || (S::NC > 0 && !u0) || !objective || !iters) return fail("anm_mpc_solve_f64: null argument");
-  if ((S::NL > 0 && !p_load_forecast) || (S::NG > 0 && !p_gen_forecast) || (S::NS > 0 && !soc))
-    return fail("anm_mpc_solve_f64: a forecast / state-of-charge array is missing");
-  if (num_envs <= 0) return 0;
-  mpc::Opts o{1e-11, 40};
-  if (opts) {
-    if (opts->tol > 0.0) o.tol = opts->tol;
-    if (opts->max_iter > 0) o.max_iter = opts->max_iter;
-  }
-  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, opts ? opts->trace : nullptr};
-  bool full = m->angle_rows;
-  if (opts && opts->angle_rows == 1) full = true;
-  if (opts && opts->angle_rows == 2) full = false;
-  int G = 1;
-  while (G < m->N) G *= 2;
-  const int per_wave = 64 / G;
-  const unsigned grid = unsigned((num_envs + per_wave - 1) / per_wave);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (full) {
-    if constexpr (S::FITS) launch_mpc<Topo>(grid, s, m, io, o, num_envs, G);
-    else return fail("anm_mpc_solve_f64: with its angle rows this network has too many rows per stage for the MPC kernel");
-  } else {
-    launch_mpc<TopoNoTheta>(grid, s, m, io, o, num_envs, G);
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail_hip(e, "launch k_mpc");
-  return 0;
-}
+#include "anm_mpc_capi.inc"
 
 int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t state_dim, int32_t K,
                        const double* state, const uint8_t* terminated, int32_t n_obs, const int32_t* index,

@@ -431,6 +431,34 @@ def test_two_storage_units_and_a_classical_generator_gpu():
     check_random_programs(_gpu_sim(net), net, 16, 3, horizons=(1, 3, 8, 16))
 
 
+def test_mpc_only_library_builds_and_exports_the_mpc_entry_points():
+    """networks above 12 buses step on the table-driven kernels of some other library; their MPC kernel comes from a
+    small library of its own (csrc/anm_mpc_only.hip), cross-compiled here, loaded, symbols and signature checked"""
+    import ctypes as C
+
+    from gym_anm_amd import _lib, codegen
+
+    topo = NetworkModel(networks.synthetic_meshed_network(14, 5, 3), 0.25, 100).topology()
+    path = codegen.build_library(topo, mpc_only=True)
+    assert os.path.basename(path).startswith("libmpc_")
+    cdll = C.CDLL(path)
+    for name in _lib.MPC_ABI:
+        assert hasattr(cdll, name), name
+    cdll.anm_topology_signature.restype = C.c_char_p
+    assert cdll.anm_topology_signature().decode() == codegen.topology_signature(topo)
+    assert not hasattr(cdll, "anm_step_f64")
+
+
+@pytest.mark.gpu
+def test_mpc_of_a_network_that_steps_in_generic_mode_gpu():
+    """a meshed 20-bus network: the simulator runs on the general lane-group kernel of whatever library is built
+    (generic mode), the MPC agent on the MPC-only library of the network's own topology"""
+    net = networks.synthetic_meshed_network(20, 3, 6)
+    sim = _gpu_sim(net)
+    assert sim.backend.generic and sim.impl == "mesh"
+    check_random_programs(sim, net, 6, 3, horizons=(1, 4, 10))
+
+
 @pytest.mark.gpu
 def test_network_beyond_the_register_budget_gpu():
     """30-bus feeder, 5 storage units: 123 rows and 42 variables per stage -- the same solver source with its row arrays
