@@ -915,7 +915,7 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
         e2 = hipGetLastError();
         if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_stragglers");
       }
-      const unsigned g3 = unsigned((io.ws_cap + 255) / 256);
+      const unsigned g3 = unsigned((int64_t(io.ws_cap) * SCATTER_LANES + 255) / 256);
       hipLaunchKernelGGL(k_step_scatter, dim3(g3), dim3(256), 0, s, io);
       e2 = hipGetLastError();
       if (e2 != hipSuccess) return fail_hip(e2, "launch k_step_scatter");
