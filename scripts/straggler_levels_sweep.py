@@ -10,7 +10,7 @@ import torch
 from gym_anm_amd.envs import ANM6EasyVec
 
 DEV = "cuda:0"
-for E in (524288, 1048576):
+for E in (131072, 524288, 1048576):
     for after in (4, 5, 6):
         for mid in (None, 9, 12):
             env = ANM6EasyVec(num_envs=E, device=DEV, seed=1, autoreset=True, tol=1e-6, max_iter=100, straggler_after=after,

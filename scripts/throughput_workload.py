@@ -1,7 +1,7 @@
 """Workload for profiling the throughput regime (SURVEY 8d config 5's per-GPU load and beyond): ANM6Easy, random agent,
 the two-launch step (k_step_rows + k_step_stragglers + k_step_scatter), E environments on one GPU.
 
-    python scripts/throughput_workload.py 524288 [steps]
+    python scripts/throughput_workload.py 524288 [steps [straggler_after [straggler_mid]]]
 """
 import os
 import sys
@@ -15,7 +15,12 @@ from gym_anm_amd.envs import ANM6EasyVec
 DEV = "cuda:0"
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-env = ANM6EasyVec(num_envs=E, device=DEV, seed=1, autoreset=True, tol=1e-6, max_iter=100)
+kw = {}
+if len(sys.argv) > 3:
+    kw["straggler_after"] = int(sys.argv[3])
+if len(sys.argv) > 4:
+    kw["straggler_mid"] = None if sys.argv[4] == "none" else int(sys.argv[4])
+env = ANM6EasyVec(num_envs=E, device=DEV, seed=1, autoreset=True, tol=1e-6, max_iter=100, **kw)
 env.check_actions = False
 env.reset(seed=1)
 g = torch.Generator(device=DEV).manual_seed(0)
