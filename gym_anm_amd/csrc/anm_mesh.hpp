@@ -758,6 +758,12 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   const int* stype = tab + (d.off_stype - d.off_lists);
   int4 nxt = prog[l];
   int nxt_ty = stype[0];
+  int un[8];
+  auto unpack = [](const int4& q, int (&o)[8]) {
+    o[0] = q.x & 0xffff; o[1] = int(unsigned(q.x) >> 16); o[2] = q.y & 0xffff; o[3] = int(unsigned(q.y) >> 16);
+    o[4] = q.z & 0xffff; o[5] = int(unsigned(q.z) >> 16); o[6] = q.w & 0xffff; o[7] = int(unsigned(q.w) >> 16);
+  };
+  unpack(nxt, un);
   for (;;) {
     vr = vm * cs;
     vi = vm * sn;
@@ -824,14 +830,13 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     ANM_MESH_SYNC();
     // ---- elimination and back substitution: the step program
     for (int sidx = 0; sidx < d.n_steps; ++sidx) {
-      const int4 cur = nxt;
+      // the operands of this step were unpacked while the previous step's stores drained (below); the descriptor of
+      // the next one is fetched now
       const int ty = __builtin_amdgcn_readfirstlane(nxt_ty);
       const int sn = (sidx + 1 == d.n_steps) ? 0 : sidx + 1;
+      const int kind = un[0], o1 = un[1], o2 = un[2], o3 = un[3], o4 = un[4], o5 = un[5], o6 = un[6], o7 = un[7];
       nxt = prog[sn * G + l];
       nxt_ty = stype[sn];
-      const int kind = cur.x & 0xffff;
-      const int o1 = int(unsigned(cur.x) >> 16), o2 = cur.y & 0xffff, o3 = int(unsigned(cur.y) >> 16);
-      const int o4 = cur.z & 0xffff, o5 = int(unsigned(cur.z) >> 16), o6 = cur.w & 0xffff, o7 = int(unsigned(cur.w) >> 16);
       if ((ty & 0xff) == ST_PROD) {
         if (kind != OP_NONE) {
           const Blk<JT> Di = blk_inv(ld4(o1));
@@ -914,6 +919,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
           st4(o1, Blk<JT>{a0, Rk.b, a1, Rk.d});
         }
       }
+      unpack(nxt, un);   // (before the fence: in the shadow of this step's stores)
       ANM_MESH_SYNC();
     }
     // ---- update (group-uniform `active`); d1 is the relative magnitude step
