@@ -288,6 +288,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   const int K = io.e.K;
   const int S = d.SDIM + K;
 
+  ANM_PHASE(0);
   // ---------------- inputs per device lane -------------------------------------------------
   bool skip = false;        // env in the absorbing terminal state (step mode, no autoreset)
   bool resetting = false;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     }
   }
 
+  ANM_PHASE(1);
   // ---------------- device maps (lane = device) ---------------------------------------------
   double dev_p = 0.0, dev_q = 0.0, p_pot = 0.0;
   {
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     }
   ANM_GROUP_SYNC();
 
+  ANM_PHASE(2);
   // ---------------- Newton-Raphson (lane = bus) ----------------------------------------------
   const double ybb_r = RD(DF_YBB_RE), ybb_i = RD(DF_YBB_IM), ybp_r = RD(DF_YBP_RE), ybp_i = RD(DF_YBP_IM);
   const double ypb_r = RD(DF_YPB_RE), ypb_i = RD(DF_YPB_IM);
@@ -570,6 +573,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   }
   const bool converged = !f_nan && !f_bad;
 
+  ANM_PHASE(3);
   // ---------------- slack injection, branch flows, reward --------------------------------------
   // I_0 = Y_00 + sum over the buses attached to the slack of Y_0b V_b  (fixed butterfly order)
   double s0r = (isbus && parent < 0) ? (ypb_r * vr - ypb_i * vi) : 0.0;
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
 
   if (!env_ok) return;
 
+  ANM_PHASE(4);
   // ---------------- outputs ------------------------------------------------------------------
   double* full = (mode == 0) ? io.t.full : io.e.full;
   auto write_full = [&]() {
@@ -655,6 +660,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       if (io.t.nr_iters) io.t.nr_iters[e] = it;
     }
     write_full();
+    ANM_PHASE(5);
     return;
   }
 
