@@ -15,15 +15,19 @@
 // three epigraph rows per branch) or the state only (SoC window :288-291).  It is solved by a primal-dual
 // interior-point method (Mehrotra predictor-corrector).  A Newton step is then a linear-quadratic control
 // problem: each lane factors its own stage (a dense (n_gen + 2 n_des)^2 Cholesky, the epigraph variables
-// eliminated in closed form), and the stages are coupled only through the n_des states of charge -- a Riccati
-// sweep over the lanes of a group in the cancellation-free form  P' = P (I + M P)^-1,  M = B R^-1 B'.
+// eliminated in closed form), and the stages are coupled only through the n_des states of charge -- a sweep over
+// the lanes of a group that is the BLOCK CHOLESKY factorisation of the step's matrix in stage order (the classical
+// Riccati recursion: Lam = T + B' P B = L L', W = L^-1 B' P, P' = P - W' W; backward stable, unlike the
+// information form P (I + M P)^-1 with M = B T^-1 B', which was tried first and is not).
 //
 // Lane layout: a group of G = 2^k >= N lanes is one environment, lane = stage; 64 / G environments per
-// wavefront.  N = 1: one thread per environment.  Everything a lane owns (its rows' slacks and multipliers,
-// its factor) lives in registers; the network tables are wave-uniform scalar loads.
+// wavefront.  N = 1: one thread per environment.  What a lane owns (its rows' slacks and multipliers, its factor)
+// lives in registers, two work arrays of its rows in LDS; the network tables are wave-uniform scalar loads; the
+// lanes of a group exchange by DPP moves and v_permlane swaps (WaveGroup below).  The angle rows are left out where
+// the device limits keep every angle away from pi (NoTheta below).
 //
 // Plain C++17 with the ANM_HD decoration: tests/hostsim compiles the very same solver with g++ (one host
-// thread per lane, the shuffles replaced by a barrier-protected exchange array) as a TEST DOUBLE.
+// thread per lane, the exchanges replaced by a barrier-protected exchange array) as a TEST DOUBLE.
 #pragma once
 
 #include <cmath>
