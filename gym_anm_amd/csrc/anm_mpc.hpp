@@ -258,10 +258,13 @@ inline bool build_tables(const anm_network_desc& d, double gamma, double safety_
     }
     *theta_bound = worst;
   }
-  tab[S::T_LAMB] = d.lamb;
+  tab[S::T_LAMB] = std::fmax(d.lamb, 1e-30);   // (lamb = 0: the overloads cost nothing; the epigraph rows keep an interior)
   double w = 1.0;
   for (int i = 0; i < 64; ++i) {
-    tab[S::T_WGT + i] = w;  // gamma^i (mpc.py:212)
+    // gamma^i (mpc.py:212); a weight of exactly 0 (gamma = 0, or an underflow) would leave the later stages without
+    // any cost, and the epigraph multipliers without an interior: such stages get a weight that changes nothing in
+    // the first 25 digits of the value
+    tab[S::T_WGT + i] = std::fmax(w, 1e-30);
     w *= gamma;
   }
   return true;

@@ -154,8 +154,8 @@ def check_tables(sim, gamma=0.97, margin=0.93, N=5):
     cmp("socmax", red.soc_max)
     cmp("bc", red.dt * red.eff)
     cmp("bd", red.dt / red.eff)
-    cmp("lamb", [red.lamb])
-    cmp("wgt", gamma ** np.arange(64))
+    cmp("lamb", [max(red.lamb, 1e-30)])
+    cmp("wgt", np.maximum(gamma ** np.arange(64), 1e-30))
 
 
 def full_solution(red, pr, pl, pg, sol):
@@ -358,6 +358,29 @@ def test_network_beyond_the_register_budget_host():
     check_random_programs(_host_sim(net), net, 3, 3, horizons=(1, 3, 6))
 
 
+def check_discount_extremes(make_sim):
+    """gamma = 0 (the reference accepts [0, 1]: later stages then carry no cost at all) and discounts that underflow
+    over the horizon: the value of the program is still the reference's"""
+    net = networks.anm6_network()
+    sim, n = make_sim(net), O.parse_network(net, 0.25, 100)
+    m, rng = sim.model, np.random.default_rng(4)
+    for gamma, N in ((0.0, 1), (0.0, 4), (0.0, 10), (1e-20, 5), (0.01, 12)):
+        E = 4
+        s_ = BatchedDCOPF(sim, gamma, 0.9, N)
+        pl = -rng.uniform(0, 1, (E, len(m.load_idx), N)) * (-m.dev_p_min[m.load_idx])[None, :, None]
+        pg = rng.uniform(0, 1, (E, len(m.gen_idx), N)) * m.dev_p_max[m.gen_idx][None, :, None]
+        soc = rng.uniform(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx], (E, len(m.des_idx)))
+        s_.solve(pl, pg, soc)
+        assert int(s_.iters.max()) < s_.max_iter and float(s_.info[:, 1].max()) == 0.0, (gamma, N)
+        for e in range(E):
+            ref = MO.solve_dcopf(n, pl[e], pg[e], soc[e], gamma, 0.9, N)
+            assert abs(float(s_.objective[e]) - ref["objective"]) <= 2e-7 * (1 + abs(ref["objective"])), (gamma, N, e)
+
+
+def test_discount_extremes_host():
+    check_discount_extremes(_host_sim)
+
+
 def test_angle_rows_host():
     check_angle_rows(_host_sim)
 
@@ -465,6 +488,11 @@ def test_network_beyond_the_register_budget_gpu():
     in scratch (Sz::IN_REGISTERS false)"""
     net = networks.synthetic_radial_network(30, 0)
     check_random_programs(_gpu_sim(net), net, 6, 3, horizons=(1, 3, 10))
+
+
+@pytest.mark.gpu
+def test_discount_extremes_gpu():
+    check_discount_extremes(_gpu_sim)
 
 
 @pytest.mark.gpu
