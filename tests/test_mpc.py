@@ -483,6 +483,60 @@ def test_mpc_of_a_network_that_steps_in_generic_mode_gpu():
 
 
 @pytest.mark.gpu
+def test_closed_loop_on_a_network_that_steps_in_generic_mode_gpu():
+    """a task on the meshed 20-bus network (host hooks): the environment steps on the general lane-group kernel, the
+    reference's constant-forecast agent plans with the MPC kernel of the network's own small library"""
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    net = networks.synthetic_meshed_network(20, 3, 6)
+
+    class Task(BatchedANMEnv):
+        def __init__(self, num_envs):
+            super().__init__(net, "state", 1, 0.25, 0.995, 100, aux_bounds=np.array([[0, 23]]), costs_clipping=(1, 100), seed=0,
+                             num_envs=num_envs, device="cuda:0")
+            m = self.simulator.model
+            self._pl = torch.as_tensor(0.5 * m.dev_p_min[m.load_idx] * m.baseMVA, device=self.device)   # half load, MW
+            self._pg = torch.as_tensor(0.6 * m.dev_p_max[m.gen_idx] * m.baseMVA, device=self.device)
+
+        def init_state(self):
+            m = self.simulator.model
+            s0 = torch.zeros((self.num_envs, self.state_N), dtype=torch.float64, device=self.device)
+            s0[:, list(m.load_idx)] = self._pl
+            D, nd = m.N_device, m.N_des
+            s0[:, 2 * D : 2 * D + nd] = torch.as_tensor(0.5 * (m.dev_soc_min[m.des_idx] + m.dev_soc_max[m.des_idx]) * m.baseMVA, device=self.device)
+            s0[:, 2 * D + nd : 2 * D + nd + m.N_non_slack_gen] = self._pg
+            return s0
+
+        def next_vars(self, s_t):
+            E = s_t.shape[0]
+            wob = 1.0 + 0.2 * torch.sin(s_t[:, -1:] * 0.7)
+            return torch.cat((self._pl.expand(E, -1) * wob, self._pg.expand(E, -1) * (2.0 - wob), (s_t[:, -1:] + 1) % 24), 1)
+
+    env = Task(64)
+    assert env.simulator.backend.generic and env.simulator.impl == "mesh"
+    env.reset(seed=0)
+    agent = MPCAgentConstant(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=4)
+    assert os.path.basename(agent.solver.backend.path).startswith("libmpc_")
+    lo, hi = torch.as_tensor(env.action_space.low, device=env.device), torch.as_tensor(env.action_space.high, device=env.device)
+    tot = torch.zeros(64, dtype=torch.float64, device=env.device)
+    for _ in range(8):
+        a = agent.act(env)
+        assert a.shape == (64, env.action_space.shape[0]) and bool(agent.last_converged.all())
+        assert bool(((a >= lo - 1e-9) & (a <= hi + 1e-9)).all())
+        _, r, term, _, _ = env.step(a)
+        tot += r
+    assert not bool(env.terminated.any()) and bool(torch.isfinite(tot).all())
+    # planning beats doing nothing (zero set-points curtail every generator and leave the storage idle)
+    env2 = Task(64)
+    env2.reset(seed=0)
+    tot0 = torch.zeros(64, dtype=torch.float64, device=env.device)
+    for _ in range(8):
+        _, r, _, _, _ = env2.step(torch.zeros_like(a))
+        tot0 += r
+    assert float(tot.mean()) >= float(tot0.mean()) - 1e-9
+
+
+@pytest.mark.gpu
 def test_network_beyond_the_register_budget_gpu():
     """30-bus feeder, 5 storage units: 123 rows and 42 variables per stage -- the same solver source with its row arrays
     in scratch (Sz::IN_REGISTERS false)"""
