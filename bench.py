@@ -292,7 +292,7 @@ def main():
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps  # HIP events over the timed region, per launch
+    step_events_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps  # HIP events over the timed region: kernel + launch gap
     # statistics of the workload (outside the timed region)
     for i in range(8):
         env.step(pool[i % n_pool])
@@ -325,6 +325,10 @@ def main():
             n_launch, C.byref(ms),
         )  # fmt: skip
     sim.backend.check(rc, "anm_time_step_launches")
+    # the kernel's own duration: launches issued back to back from C, HIP events on the launch stream around them
+    # (nothing between two launches; agrees with the rocprofv3 kernel-trace average, profiles/).  The events over the
+    # timed region above additionally hold the gap the Python caller leaves between two launches.
+    kernel_s = ms.value * 1e-3
 
     # secondary figure: same workload with a 20-iteration cap.  Diverging solves (the only ones that
     # ever exceed ~8 iterations) are then cut off early; on every sample tested the terminated flags
@@ -424,8 +428,10 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "k_step_rows<double, false>" if args.precision == "f64" else "k_step_rows<float, false>",
-                "kernel_ms": kernel_s * 1e3, "launches_timed": args.steps,
-                "kernel_ms_back_to_back": ms.value, "launches_back_to_back": n_launch,
+                "kernel_ms": kernel_s * 1e3, "launches_timed": n_launch,
+                "kernel_ms_source": "HIP events on the launch stream around %d launches issued back to back from C "
+                                    "(anm_time_step_launches), live in this run" % n_launch,
+                "step_ms_hip_events": step_events_s * 1e3, "steps_timed": args.steps,
                 "algorithmic_bytes_per_env_step": bytes_per, "valu_fp64_issue": valu,
                 "note": "fp64-ALU/latency-bound (Newton-Raphson in registers), not HBM-bound: see DESIGN.md",
             },

@@ -149,8 +149,12 @@ class BatchedDCOPF:
     environments per wavefront, the network tables of the reduced program (``dcopf.py``) as scalar loads.
 
     ``solve(P_load_forecast [E, n_load, N], P_gen_forecast [E, n_gen, N], soc [E, n_des])`` -> the first-stage
-    ``[P_gen.., P_des..]`` (p.u.); ``objective``, ``iters``, ``info`` (final complementarity, row residual, dual residual) and, on
-    request, the whole primal solution stay available as tensors."""
+    ``[P_gen.., P_des..]`` (p.u.); ``objective``, ``iters``, ``info`` and, on request, the whole primal solution stay
+    available as tensors.  ``info[:, 0]`` is the final complementarity ``mu``, ``info[:, 1]`` a STATUS (0 ok, 1 a stage has
+    no interior start, 2 an angle row left out of the solve is violated -- ``include/anm_mi355x.h``), ``info[:, 2]`` the
+    largest dual residual.  ``converged`` folds them into the verdict every caller should apply."""
+
+    TOL_DEFAULT, MAX_ITER_DEFAULT = 1e-11, 40   # the library's defaults (anm_mpc_capi.inc), always passed explicitly
 
     def __init__(self, simulator, gamma, safety_margin, planning_steps, tol=None, max_iter=None, keep_solution=False,
                  keep_trace=False, angle_rows=None):
@@ -176,9 +180,14 @@ class BatchedDCOPF:
         # angle_rows: None = the library's choice (dims.angle_rows: the rows |theta| <= pi ride through the solve only
         # where an angle can come near pi within the device limits); True / False force them in / out (left out, the
         # solution's angles are checked: info[:, 1] == 2 where one exceeds pi)
-        self.opts = _lib.MpcOpts(tol=0.0 if tol is None else float(tol), max_iter=0 if max_iter is None else int(max_iter),
-                                 angle_rows=0 if angle_rows is None else (1 if angle_rows else 2))
-        self.max_iter = 40 if max_iter is None else int(max_iter)
+        # tolerance and iteration cap are always sent explicitly (0 would mean "the library's default": the trace buffer
+        # below is sized by max_iter, and a default that changed under it would be an out-of-bounds write)
+        self.tol = self.TOL_DEFAULT if tol is None else float(tol)
+        self.max_iter = self.MAX_ITER_DEFAULT if max_iter is None else int(max_iter)
+        if not (self.tol > 0.0 and self.max_iter > 0):
+            raise ValueError("tol and max_iter must be positive")
+        self.opts = _lib.MpcOpts(tol=self.tol, max_iter=self.max_iter, angle_rows=0 if angle_rows is None else (1 if angle_rows else 2))
+        self.dual_tol = 1e-6 * (1.0 + float(simulator.lamb))   # against costs of 1 ... lamb per p.u.
         self.keep_solution, self.keep_trace = keep_solution, keep_trace
         self._E = None
 
@@ -217,6 +226,14 @@ class BatchedDCOPF:
                 C.byref(self.opts), self._stream_ptr())
         self.backend.check(rc, "anm_mpc_solve_f64")
         return self.u0
+
+    @property
+    def converged(self):
+        """``[E]`` bool: the last solve reached the complementarity tolerance ``mu <= tol (1 + |objective|)`` (the kernel's
+        own stop test, read from ``info[:, 0]``: a solve that meets it in its last allowed iteration counts), status 0,
+        and a dual residual that is small against the costs (the kernel's stop test does not look at it)."""
+        mu_ok = self.info[:, 0] <= self.tol * (1.0 + self.objective.abs())
+        return mu_ok & (self.info[:, 1] == 0) & (self.info[:, 2] <= self.dual_tol)
 
     def __del__(self):
         try:
@@ -278,8 +295,8 @@ class MPCAgent:
         ng = self.solver.dims.n_gen
         P_gen, P_des = u0[:, :ng], u0[:, ng:]
         a = torch.cat((P_gen, torch.zeros_like(P_gen), P_des, torch.zeros_like(P_des)), dim=1)
-        # reached the tolerance, with a dual residual that is small against the costs (info: mu, row residual, dual residual)
-        self.last_converged = (self.solver.iters < self.solver.max_iter) & (self.solver.info[:, 2] <= 1e-6 * (1.0 + self.lamb))
+        # reached the tolerance with status 0 and a dual residual that is small against the costs (BatchedDCOPF.converged)
+        self.last_converged = self.solver.converged
         if not bool(self.last_converged.all()):
             import warnings
 

@@ -113,6 +113,7 @@ __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__
 
 struct anm_model {
   int impl = ANM_IMPL_THREAD;   // which kernel family serves this model
+  int impl_unbound = -1;        // the family to go back to when a per-environment class binding is lifted (-1: none pending)
   bool tpe_ok = false;          // the network has the topology this library was compiled for
   bool radial_ok = false;       // the network is a tree that fits one wavefront
   radial::Plan plan;            // per-lane tables of the lane-group kernel
@@ -556,6 +557,8 @@ int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_des
   m->x_hd = std::move(xh);
   m->x_md = std::move(xm);
   m->d_env_class = nullptr;
+  m->class_per_env = false;
+  if (m->impl_unbound >= 0) { m->impl = m->impl_unbound; m->impl_unbound = -1; }
   m->env_set = false;   // the task constants (anm_model_set_env) must be set again: they live in every class
   return upload_const(m);
 }
@@ -583,9 +586,14 @@ int anm_model_set_class_obs_bounds(anm_model* m, int32_t cls, const double* low,
 
 int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t num_envs) {
   if (!m) return fail("anm_model_bind_env_classes: null model");
+  auto restore_impl = [&]() {   // a binding that forced a lane-group family is gone: back to the family it displaced
+    if (m->impl_unbound >= 0) m->impl = m->impl_unbound;
+    m->impl_unbound = -1;
+  };
   if (!env_class) {
     m->d_env_class = nullptr;
     m->class_per_env = false;
+    restore_impl();
     return 0;
   }
   if (num_envs <= 0) return fail("anm_model_bind_env_classes: num_envs must be positive");
@@ -604,9 +612,19 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
   // thread-per-environment kernels cannot (64 environments share a wavefront's scalar constants).
   if (!blocks && !(m->radial_ok || m->mesh_ok))
     return fail("anm_model_bind_env_classes: a class must cover whole aligned blocks of 64 environments (this network has no lane-group kernel)");
+  // (the same guard as anm_model_set_impl: the lane-group kernels do not gather a list-form observation -- moving a
+  // model with one to them would silently turn its observation into clip(state))
+  if (!blocks && m->impl == ANM_IMPL_THREAD && m->n_obs > 0)
+    return fail("anm_model_bind_env_classes: classes that change inside blocks of 64 environments need a lane-group kernel, "
+                "and a list-form observation (anm_model_set_obs) is gathered by the thread-per-environment step kernel only: "
+                "clear it first (anm_model_set_obs with n_obs = 0) or bind the classes in aligned blocks of 64");
   m->class_per_env = !blocks;
   m->d_env_class = env_class;
-  if (!blocks && m->impl == ANM_IMPL_THREAD) m->impl = m->radial_ok ? ANM_IMPL_RADIAL : ANM_IMPL_MESH;
+  if (blocks) restore_impl();
+  else if (m->impl == ANM_IMPL_THREAD) {
+    m->impl_unbound = ANM_IMPL_THREAD;
+    m->impl = m->radial_ok ? ANM_IMPL_RADIAL : ANM_IMPL_MESH;
+  }
   return 0;
 }
 
@@ -699,6 +717,7 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
     return fail("anm_model_set_impl: a list-form observation is gathered inside the thread-per-environment step kernel "
                 "(anm_model_set_obs); clear it before switching to a lane-group kernel");
   m->impl = impl;
+  m->impl_unbound = -1;   // an explicit choice is not undone by a later unbind
   return 0;
 }
 

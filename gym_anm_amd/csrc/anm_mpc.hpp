@@ -113,7 +113,8 @@ struct IO {
   double* u0;            // [E][NC]    first-stage [P_gen.., P_des..], p.u.
   double* objective;     // [E]
   int32_t* iters;        // [E]
-  double* info;          // [E][3]     final mu, 1 if the stage has no interior start (else 0), largest dual residual   (may be null)
+  double* info;          // [E][3]     final mu; STATUS: 0 ok, 1 a stage has no interior start, 2 an angle row left out of
+                         //            the solve is violated by the solution; largest dual residual   (may be null)
   double* solution;      // [E][N][NV] P_g, p_c, d, t per stage         (may be null)
   double* trace;         // [E][max_iter + 1][12] per iteration: mu, 0, dual residual, objective, then (of the
                          //   step taken from there) primal and dual step length, centring, mu of the predictor, and the row

@@ -140,7 +140,10 @@ class BatchedANMEnv(GymEnv):
         self._term_bool = self._term_u8.view(torch.bool)  # zero-copy: the kernel only writes 0 / 1
         self.timestep = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
-        self._conv_bool = None
+        # convergence of the last power flow (see `pfe_converged`): a tensor from the start; after a step it is
+        # `~terminated`, formed when somebody asks (step() itself launches nothing but the step kernel)
+        self._conv_bool = torch.ones(E_, dtype=torch.bool, device=self.device)
+        self._conv_stale = False
         self._reset_count = torch.zeros(E_, dtype=torch.int32, device=self.device)
         self._truncated = torch.zeros(E_, dtype=torch.bool, device=self.device)
         # key of the device-side sampler (reset(options={"sampler": "device"}), autoreset).  Unseeded
@@ -411,7 +414,10 @@ class BatchedANMEnv(GymEnv):
     def pfe_converged(self):
         """Convergence of the last power flow of every environment (simulator.pfe_converged in the
         reference): that of the reset right after a reset; after a step an environment has converged iff
-        it is not terminated (anm_env.py:421)."""
+        it is not terminated (anm_env.py:421).  Formed on access: `step()` only marks it stale."""
+        if self._conv_stale:
+            self._conv_bool = ~self._term_bool
+            self._conv_stale = False
         return self._conv_bool
 
     # ---- reset (anm_env.py:235-311) --------------------------------------------------------------------------
@@ -436,10 +442,11 @@ class BatchedANMEnv(GymEnv):
         # convergence per environment: the environments this reset touched report the reset's power flow, the others
         # keep what their last step left (not terminated <=> converged, anm_env.py:421)
         conv = self._conv_u8.bool()
-        if mask_u8 is None or self._conv_bool is None:
+        if mask_u8 is None:
             self._conv_bool = conv
         else:
-            self._conv_bool = torch.where(mask_u8.bool(), conv, self._conv_bool)
+            self._conv_bool = torch.where(mask_u8.bool(), conv, self.pfe_converged)
+        self._conv_stale = False
         if self._need_full_reset or self._need_full:
             sim.state = StateView(sim, sim.full)
             sim.pfe_converged = self._conv_bool
@@ -581,10 +588,10 @@ class BatchedANMEnv(GymEnv):
             exo_ptr, aux_ptr = exo.data_ptr(), (aux.data_ptr() if self.K > 0 else None)
         self._step_call(action.data_ptr(), exo_ptr, aux_ptr)
         self._after_step = True
-        self._conv_bool = ~self._term_bool
+        self._conv_stale = True  # pfe_converged = ~terminated, formed on access (no launch, no allocation here)
         if self._need_full:
             sim.state = StateView(sim, sim.full)
-            sim.pfe_converged = self._conv_bool
+            sim.pfe_converged = self.pfe_converged
         if self._obs_is_state:
             obs = self._state_obs
         elif self._obs_fused:

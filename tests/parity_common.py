@@ -136,10 +136,13 @@ def uniform_actions(env, gen):
     return lo + (hi - lo) * torch.rand((env.num_envs, lo.numel()), generator=gen, dtype=torch.float64, device=dev)
 
 
-def headline_replay(kw, E_, T, n_random, n_collapsed, **env_kw):
+def headline_replay(kw, E_, T, n_random, n_collapsed, twin_kw=None, check_env=None, **env_kw):
     """ANM6EasyVec(tol=1e-6, autoreset) for T steps; a seeded sample plus environments that collapsed early
     are replayed by OracleEnv(tol=1e-6), autoreset draws included: observation <= 1e-9, reward rtol 1e-9,
-    terminated and Newton iteration counts exact."""
+    terminated and Newton iteration counts exact.
+    twin_kw: a second batch of the same size built with these keywords instead of env_kw (another step mode: e.g. the
+    one-launch in-wave hand-over next to the automatic policy) is stepped beside the first with the same actions;
+    every output of every step must be bit-identical.  check_env(env): assertions on the policy the batch chose."""
     import anm_oracle as O
     from gym_anm_amd import rng
     from gym_anm_amd.envs import ANM6EasyVec
@@ -149,6 +152,14 @@ def headline_replay(kw, E_, T, n_random, n_collapsed, **env_kw):
     dev = env.device
     env.check_actions = False
     env.reset(seed=1234)
+    if check_env is not None:
+        check_env(env)
+    twin = None
+    if twin_kw is not None:
+        twin = ANM6EasyVec(num_envs=E_, seed=1234, tol=1e-6, autoreset=True, **kw(net), **twin_kw)
+        twin.check_actions = False
+        twin.reset(seed=1234)
+        assert torch.equal(twin.state, env.state) and torch.equal(twin.simulator.soc, env.simulator.soc)
     state0, soc0 = env.state.clone(), env.simulator.soc.clone()
     gen = torch.Generator(device=dev).manual_seed(99)
     rec = {k: [] for k in ("a", "obs", "r", "term", "it", "rc", "el", "pen")}
@@ -156,6 +167,13 @@ def headline_replay(kw, E_, T, n_random, n_collapsed, **env_kw):
         a = uniform_actions(env, gen)
         rec["rc"].append(env._reset_count.clone())
         obs, r, term, _, _ = env.step(a)
+        if twin is not None:
+            o2, r2, t2, _, _ = twin.step(a)
+            for name, x, y in (("obs", obs, o2), ("reward", r, r2), ("terminated", term, t2), ("state", env.state, twin.state),
+                               ("nr_iters", env.simulator.nr_iters, twin.simulator.nr_iters), ("e_loss", env.e_loss, twin.e_loss),
+                               ("penalty", env.penalty, twin.penalty), ("soc", env.simulator.soc, twin.simulator.soc),
+                               ("timestep", env.timestep, twin.timestep), ("reset_count", env._reset_count, twin._reset_count)):  # fmt: skip
+                assert torch.equal(x, y), "step %d: %s differs between the two step modes" % (t, name)
         for k, v in zip(("a", "obs", "r", "term", "it", "el", "pen"),
                         (a, obs, r, term, env.simulator.nr_iters, env.e_loss, env.penalty)):  # fmt: skip
             rec[k].append(v.clone())

@@ -40,6 +40,45 @@ def test_headline_config_oracle_replay(handoff):
     assert n >= 256 and n_term >= 32 and n_reset >= 32
 
 
+@pytest.mark.parametrize("E_", [524288, 1048576])
+def test_config5_single_gpu_point_oracle_replay(E_):
+    """BASELINE.json config 5's load when its 524 288 environments sit on ONE GPU (and twice that): the step the
+    AUTOMATIC straggler policy chooses at this size (`straggler_after="auto"`: the solves still running after 6
+    iterations of the whole batch continue packed on lane groups; from 1 M environments on in two levels), 10
+    autoresetting steps: 128 sampled environments plus 64 that collapsed early replayed by OracleEnv(tol=1e-6) --
+    observation <= 1e-9, reward rtol 1e-9, terminated and Newton iteration counts exact, autoreset draws included --
+    and every output of every step bit-identical to the one-launch step with the in-wave hand-over (the path
+    test_headline_config_oracle_replay pins at 65 536).  Reference loop: gym_anm/envs/anm_env.py:333-453."""
+    def policy(env):
+        assert env._ws is not None and env._ws.iter_cap == 6, "the automatic policy must pick the packed continuation here"
+        assert (env._ws.mid_cap > 0) == (E_ >= 1000000)
+
+    n, n_term, n_reset = pc.headline_replay(KW, E_, 10, 128, 64, twin_kw=dict(straggler_after=None), check_env=policy)
+    assert n >= 160 and n_term >= 32 and n_reset >= 32
+
+
+def test_step_is_one_launch_without_allocation():
+    """`step()` on the fast path launches the step kernel and nothing else: no tensor is allocated (the caching
+    allocator's counters do not move) and `pfe_converged` is formed only when somebody reads it."""
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    env = ANM6EasyVec(num_envs=65536, device=DEV, seed=3, tol=1e-6, autoreset=True)
+    env.check_actions = False
+    env.reset(seed=3)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    acts = [_uniform_actions(env, gen) for _ in range(4)]
+    env.step(acts[0])
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_stats(DEV)
+    for a in acts:
+        obs, r, term, trunc, info = env.step(a)
+    torch.cuda.synchronize()
+    after = torch.cuda.memory_stats(DEV)
+    for key in ("allocation.all.allocated", "segment.all.allocated", "allocated_bytes.all.allocated"):
+        assert after[key] == before[key], key
+    assert torch.equal(env.pfe_converged, ~term)  # formed now, from the flags of the last step
+
+
 @pytest.mark.parametrize("name,impl", [("anm6", "thread"), ("anm6", "radial"), ("anm6", "mesh"), ("3bus", "thread"), ("3bus", "mesh")])
 def test_reset_golden_simulator_and_env(name, impl):
     env = pc.reset_golden(name, KW, impl)
