@@ -111,6 +111,8 @@ ABI = {
     "anm_mpc_dims_of": (C.c_int, [C.c_void_p, C.POINTER(MpcDims)]),
     "anm_mpc_get_tables": (C.c_int, [C.c_void_p, c_double_p]),
     "anm_mpc_solve_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 8 + [C.POINTER(MpcOpts), _P]),
+    "anm_mpc_act_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, C.c_int32] + [_P] * 8
+                        + [C.POINTER(MpcOpts), _P]),
     "anm_gather_obs_f64": (C.c_int, [C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P,
                                      _P]),
     "anm_time_step_launches": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 9 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,
@@ -219,7 +221,8 @@ def load_for_topology(topo, impl=None) -> Backend:
 
 
 MPC_ABI = ("anm_last_error", "anm_topology_signature", "anm_mpc_create", "anm_mpc_destroy", "anm_mpc_dims_of", "anm_mpc_get_tables",
-           "anm_mpc_solve_f64")
+           "anm_mpc_solve_f64", "anm_mpc_act_f64")
+MPC_FORECAST_CONSTANT, MPC_FORECAST_PERFECT = 1, 2
 
 
 class MpcBackend:

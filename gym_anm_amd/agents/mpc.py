@@ -227,6 +227,34 @@ class BatchedDCOPF:
         self.backend.check(rc, "anm_mpc_solve_f64")
         return self.u0
 
+    def act(self, forecast, env, act_low, act_high):
+        """``MPCAgent.act`` as ONE launch (``anm_mpc_act_f64``): the forecasts are gathered inside the kernel -- ``forecast``
+        1: constant, from the state rows of ``env``; 2: perfect, from its periodic tables -- and the first stage's
+        set-points come back as the clipped MW action rows ``[E, 2 n_gen + 2 n_des]`` (a persistent buffer)."""
+        d = self.dims
+        E = int(env.num_envs)
+        self._buffers(E)
+        if getattr(self, "_action", None) is None or self._action.shape[0] != E:
+            self._action = torch.zeros((E, 2 * d.n_gen + 2 * d.n_des), dtype=torch.float64, device=self.device)
+        series_ptr, period = None, 0
+        if forecast == 2:
+            if getattr(self, "_series_src", None) is not env._series:
+                self._series_src = env._series
+                self._series_dev = torch.as_tensor(env._series, dtype=torch.float64, device=self.device).contiguous()
+            series_ptr, period = self._series_dev.data_ptr(), int(self._series_dev.shape[1])
+        same = env._state_same
+        aux = None   # the time index is read from the last column of the state row (what `forecast()` does)
+        soc = env.simulator.soc
+        with self._device_ctx():
+            rc = self.backend.lib.anm_mpc_act_f64(
+                self._handle, E, int(forecast), env._state_buf.data_ptr(), None if same is None else env._state_obs.data_ptr(),
+                None if same is None else same.data_ptr(), int(env._state_buf.shape[1]), None if aux is None else aux.data_ptr(),
+                series_ptr, period, soc.data_ptr(), act_low.data_ptr(), act_high.data_ptr(), self._action.data_ptr(),
+                self.u0.data_ptr(), self.objective.data_ptr(), self.iters.data_ptr(), self.info.data_ptr(), C.byref(self.opts),
+                self._stream_ptr())
+        self.backend.check(rc, "anm_mpc_act_f64")
+        return self._action
+
     @property
     def converged(self):
         """``[E]`` bool: the last solve reached the complementarity tolerance ``mu <= tol (1 + |objective|)`` (the kernel's
@@ -269,7 +297,10 @@ class MPCAgent:
         self.des_ids = [m.dev_ids[k] for k in m.des_idx]
         self.device = simulator.device
         self.solver = BatchedDCOPF(simulator, gamma, safety_margin, planning_steps, tol=tol, max_iter=max_iter)
-        self.last_converged = None
+        self._acted, self._conv = False, None
+        # `tensor / python scalar` is a multiplication by the reciprocal on the GPU; the reference divides (`/ self.baseMVA`):
+        # the forecasts are divided by this 0-dim tensor (a true division), like the fused kernel does
+        self._base_t = torch.tensor(float(self.baseMVA), dtype=torch.float64, device=self.device)
         self._lo = torch.as_tensor(np.asarray(action_space.low, float), device=self.device)
         self._hi = torch.as_tensor(np.asarray(action_space.high, float), device=self.device)
 
@@ -284,24 +315,55 @@ class MPCAgent:
         """-> first-stage [P_gen.., P_des..] in p.u., [E, n_gen + n_des]"""
         return self.solver.solve(P_load_forecast, P_gen_forecast, soc)
 
+    FUSED_FORECAST = 0   # the stock agents: which forecast anm_mpc_act_f64 gathers inside the kernel (0: none, use forecast())
+
+    def _fused(self, env):
+        """The whole of act() can run as one launch: a stock forecast (not overridden by a subclass), the stock solve and
+        state of charge, a batched environment of this package that has what the kernel reads."""
+        cls = type(self)
+        stock = {1: MPCAgentConstant, 2: MPCAgentPerfect}.get(self.FUSED_FORECAST)
+        return (stock is not None and cls.forecast is stock.forecast and cls.solve is MPCAgent.solve and cls._soc is MPCAgent._soc
+                and hasattr(self.solver.backend.lib, "anm_mpc_act_f64") and hasattr(env, "_state_buf")
+                and (self.FUSED_FORECAST == 1 or getattr(env, "_series", None) is not None)
+                and env._state_buf.shape[1] >= 2 * env.simulator.model.N_device + env.simulator.model.N_des
+                + env.simulator.model.N_non_slack_gen + (1 if self.FUSED_FORECAST == 2 else 0))
+
+    warn_unconverged = True   # False: act() neither synchronises nor launches anything but the solve (last_converged stays lazy)
+
+    @property
+    def last_converged(self):
+        """per-environment mask of the solves of the last ``act`` that reached the tolerance (``BatchedDCOPF.converged``);
+        None before the first ``act``"""
+        if self._conv is None and self._acted:
+            self._conv = self.solver.converged
+        return self._conv
+
+    def _check_converged(self, n):
+        self._acted, self._conv = True, None
+        if self.warn_unconverged and not bool(self.last_converged.all()):
+            import warnings
+
+            warnings.warn("OPF problem did not reach the tolerance in %d of %d environments (see last_converged)"
+                          % (int((~self.last_converged).sum()), n))
+
     def act(self, env):
         """``env``: a batched environment -> ``[num_envs, action_dim]`` tensor; or one of the NumPy-facing
         single-environment classes (``ANMEnv``, ``ANM6``, ``ANM6Easy``) -> 1-D NumPy action, as in the reference's
-        ``examples/mpc_*.py``."""
+        ``examples/mpc_*.py``.  With a stock forecast the whole call is ONE kernel launch (forecast gather, solve, scaling
+        to MW, clipping: ``anm_mpc_act_f64``) and the tensor returned is a buffer the next call overwrites."""
         if hasattr(env, "vec"):
             return self.act(env.vec)[0].cpu().numpy()
+        if self._fused(env):
+            a = self.solver.act(self.FUSED_FORECAST, env, self._lo, self._hi)
+            self._check_converged(a.shape[0])
+            return a
         pl, pg = self.forecast(env)
         u0 = self.solve(pl, pg, self._soc(env)) * self.baseMVA
         ng = self.solver.dims.n_gen
         P_gen, P_des = u0[:, :ng], u0[:, ng:]
         a = torch.cat((P_gen, torch.zeros_like(P_gen), P_des, torch.zeros_like(P_des)), dim=1)
         # reached the tolerance with status 0 and a dual residual that is small against the costs (BatchedDCOPF.converged)
-        self.last_converged = self.solver.converged
-        if not bool(self.last_converged.all()):
-            import warnings
-
-            warnings.warn("OPF problem did not reach the tolerance in %d of %d environments (see last_converged)"
-                          % (int((~self.last_converged).sum()), a.shape[0]))
+        self._check_converged(a.shape[0])
         return torch.minimum(torch.maximum(a, self._lo), self._hi)  # mpc.py:341-344
 
 
@@ -309,12 +371,14 @@ class MPCAgentConstant(MPCAgent):
     """Constant forecasts: the current loads and generation potentials persist over the horizon
     (``mpc_constant.py:24-35``).  They are read from the state vector: dev_p of the loads and gen_p_max, MW."""
 
+    FUSED_FORECAST = 1
+
     def forecast(self, env):
         m = env.simulator.model
         s = env.state
         D, nd = m.N_device, m.N_des
-        pl = s[:, list(m.load_idx)] / self.baseMVA
-        pg = s[:, 2 * D + nd : 2 * D + nd + m.N_non_slack_gen] / self.baseMVA
+        pl = s[:, list(m.load_idx)] / self._base_t
+        pg = s[:, 2 * D + nd : 2 * D + nd + m.N_non_slack_gen] / self._base_t
         N = self.planning_steps
         return pl.unsqueeze(2).expand(-1, -1, N), pg.unsqueeze(2).expand(-1, -1, N)
 
@@ -323,6 +387,8 @@ class MPCAgentPerfect(MPCAgent):
     """Perfect forecasts for series-mode tasks (ANM6Easy): the next N columns of the task's periodic tables
     (``mpc_perfect.py:24-40``)."""
 
+    FUSED_FORECAST = 2
+
     def forecast(self, env):
         tab = torch.as_tensor(env._series, dtype=torch.float64, device=self.device)  # [n_load + n_gen, period]
         period = tab.shape[1]
@@ -330,4 +396,4 @@ class MPCAgentPerfect(MPCAgent):
         idx = (t0.unsqueeze(1) + torch.arange(self.planning_steps, device=self.device).unsqueeze(0)) % period  # [E, N]
         cols = tab[:, idx]  # [n, E, N]
         nl = env.simulator.N_load
-        return cols[:nl].permute(1, 0, 2) / self.baseMVA, cols[nl:].permute(1, 0, 2) / self.baseMVA
+        return cols[:nl].permute(1, 0, 2) / self._base_t, cols[nl:].permute(1, 0, 2) / self._base_t

@@ -645,11 +645,18 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
     pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, cap);
     if (!two_phase || pass == 1) break;
     int* cnt = reinterpret_cast<int*>(io.ws);  // cnt[0]: records of this step (zeroed by the scatter launch)
-    if (valid && st.active) {
-      const int slot = atomicAdd(cnt, 1);
-      if (slot < io.ws_cap) {
-        save_record<T>(io.ws + Rec<T>::HEADER + int64_t(slot) * Rec<T>::SIZE, e, ctx, w, st);
-        pending = true;
+    {
+      // one reservation per wavefront (the lanes' ranks order its slots), not one atomic per straggler
+      const unsigned long long am = __ballot(valid && st.active);
+      if (am != 0ull) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(cnt, __popcll(am));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int slot = base + __popcll(am & ((1ull << lane) - 1ull));
+        if (valid && st.active && slot < io.ws_cap) {
+          save_record<T>(io.ws + Rec<T>::HEADER + int64_t(slot) * Rec<T>::SIZE, e, ctx, w, st);
+          pending = true;
+        }
       }
     }
     if (pending) {  // handed over: this lane's own solve ends here (its outputs are not stored)

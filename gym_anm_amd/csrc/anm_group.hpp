@@ -24,6 +24,9 @@
 #include "anm_device.hpp"
 
 #if defined(__HIPCC__)
+#ifndef ANM_LDSX_FETCH
+#define ANM_LDSX_FETCH 3   // child slots a parent lane fetches from LDS before folding them (LDS hand-overs)
+#endif
 namespace anm {
 namespace group {
 
@@ -322,24 +325,24 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         if (height == h) {
           static_for<0, NC>([&](auto Cc) {
             if constexpr (LDSX) {
-              // three child slots are fetched together, then folded (a padding lane's slots hold zeros): staging all
-              // NC slots costs up to 60 registers (and the third wavefront per SIMD), one slot at a time one LDS
-              // latency per child
-              if constexpr (Cc % 3 == 0) {
-                constexpr int CB = (Cc + 1 < NC) ? Cc + 1 : Cc, CC = (Cc + 2 < NC) ? Cc + 2 : Cc;
-                const int c0 = cl[Cc], c1 = cl[CB], c2 = cl[CC];
-                double q0[6], q1[6], q2[6];
-                static_for<0, 6>([&](auto A) {
-                  constexpr int arr = (A < 4) ? XA_SC + A : XA_LR + (A - 4);
-                  q0[A] = xl[arr * 64 + c0]; q1[A] = xl[arr * 64 + c1]; q2[A] = xl[arr * 64 + c2];
+              // ANM_LDSX_FETCH (3) child slots are fetched together, then folded (a padding lane's slots hold zeros):
+              // staging all NC slots costs up to 60 registers (and the third wavefront per SIMD), one slot at a time one
+              // LDS latency per child
+              constexpr int F = ANM_LDSX_FETCH;
+              if constexpr (Cc % F == 0) {
+                constexpr int NF = (NC - Cc) < F ? (NC - Cc) : F;   // slots of this round
+                double qv[NF][6];
+                static_for<0, NF>([&](auto Q) {
+                  const int cq = cl[Cc + Q];
+                  static_for<0, 6>([&](auto A) {
+                    constexpr int arr = (A < 4) ? XA_SC + A : XA_LR + (A - 4);
+                    qv[Q][A] = xl[arr * 64 + cq];
+                  });
                 });
-                Dg.a -= JT(q0[0]); Dg.b -= JT(q0[1]); Dg.c -= JT(q0[2]); Dg.d -= JT(q0[3]); r0 -= JT(q0[4]); r1 -= JT(q0[5]);
-                if constexpr (CB != Cc) {
-                  Dg.a -= JT(q1[0]); Dg.b -= JT(q1[1]); Dg.c -= JT(q1[2]); Dg.d -= JT(q1[3]); r0 -= JT(q1[4]); r1 -= JT(q1[5]);
-                }
-                if constexpr (CC != Cc) {
-                  Dg.a -= JT(q2[0]); Dg.b -= JT(q2[1]); Dg.c -= JT(q2[2]); Dg.d -= JT(q2[3]); r0 -= JT(q2[4]); r1 -= JT(q2[5]);
-                }
+                static_for<0, NF>([&](auto Q) {
+                  Dg.a -= JT(qv[Q][0]); Dg.b -= JT(qv[Q][1]); Dg.c -= JT(qv[Q][2]); Dg.d -= JT(qv[Q][3]);
+                  r0 -= JT(qv[Q][4]); r1 -= JT(qv[Q][5]);
+                });
               }
             } else if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
               Dg.a -= ga[Cc]; Dg.b -= gbb[Cc]; Dg.c -= gc[Cc]; Dg.d -= gd[Cc];

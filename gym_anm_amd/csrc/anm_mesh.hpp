@@ -688,16 +688,23 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       const double p = fmin(fmax(in_p / base, sd[0]), sd[1]);
       dev_p = p;
       dev_q = p * sd[2];
-    } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
-      p_pot = fmin(fmax(in_pot / base, sd[SD_PMIN]), sd[SD_PMAX]);
-      project_pq<2>(sd, in_p / base, in_q / base, sd[SD_PMIN], fmin(sd[SD_PMAX], p_pot), dev_p, dev_q);
-    } else if (typ == DEV_STORAGE) {
+    } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE || typ == DEV_STORAGE) {
+      // one projection for both kinds (anm_radial.hpp: a generator's lines 3 and 4 are switched off in its table)
+      const bool des = typ == DEV_STORAGE;
       const double eff = sd[SD_EFF];
-      const double s_lo = (soc - sd[SD_SOC_MAX]) / (dt * eff);
-      const double s_hi = eff * (soc - sd[SD_SOC_MIN]) / dt;
-      project_pq<4>(sd, in_p / base, in_q / base, fmax(sd[SD_PMIN], s_lo), fmin(sd[SD_PMAX], s_hi), dev_p, dev_q);
-      const double ns = (dev_p <= 0.0) ? (soc - dt * eff * dev_p) : (soc - dt * dev_p / eff);
-      soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
+      double pl = sd[SD_PMIN], pu = sd[SD_PMAX];
+      if (des) {
+        pl = fmax(pl, (soc - sd[SD_SOC_MAX]) / (dt * eff));
+        pu = fmin(pu, eff * (soc - sd[SD_SOC_MIN]) / dt);
+      } else {
+        p_pot = fmin(fmax(in_pot / base, sd[SD_PMIN]), sd[SD_PMAX]);
+        pu = fmin(pu, p_pot);
+      }
+      project_pq<4>(sd, in_p / base, in_q / base, pl, pu, dev_p, dev_q);
+      if (des) {
+        const double ns = (dev_p <= 0.0) ? (soc - dt * eff * dev_p) : (soc - dt * dev_p / eff);
+        soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
+      }
     }
   }
   double* Ldev = S + d.l_dev;

@@ -105,6 +105,44 @@ struct Opts {
   int max_iter;
 };
 
+// MPCAgent.act() inside the kernel (mpc.py:321-346, 348-372, 383-388): the forecasts are gathered by the lanes (constant:
+// from the state row, mpc_constant.py:24-35; perfect: from the task's periodic tables, mpc_perfect.py:24-40) and the
+// first stage's set-points leave as the clipped MW action row -- no forecast tensors, no permute / scale / cat / clip launches.
+struct Act {
+  int mode;                   // 0: off (forecast arrays given); 1: constant forecast; 2: perfect forecast
+  const double* state;        // [E][state_dim] state rows, MW: dev_p of the loads, gen_p_max; the time index in the last column
+  const double* state_alt;    // rows to read where state_same[e] != 0 (the observation rows: anm_model_bind_state_same), or null
+  const uint8_t* state_same;  // [E] or null
+  int state_dim;
+  const int32_t* aux_index;   // [E] time index (perfect forecast), or null: the last column of the state row
+  const double* series;       // [NL + NG][period], MW (perfect forecast)
+  int period;
+  double base;                // MVA
+  double* action;             // [E][2 NG + 2 NS] out: [P_gen.., 0.., P_des.., 0..] MW, clipped to [act_lo, act_hi]
+  const double* act_lo;       // [2 NG + 2 NS] dev
+  const double* act_hi;
+};
+
+// column of the k-th load's dev_p in a state row = its device index (anm_env.py:139-147: dev_p of every device first)
+template <class T>
+constexpr int load_device(int k) {
+  for (int d = 0; d < T::ND; ++d)
+    if (T::DEV_TYPE[d] == DEV_LOAD && T::DEV_SLOT[d] == k) return d;
+  return 0;
+}
+template <class T>
+ANM_HD double act_forecast(const Act& a, int64_t env, int stage, bool gen, int k, int col_load) {
+  const double* row = ((a.state_same && a.state_same[env]) ? a.state_alt : a.state) + env * a.state_dim;
+  double v;
+  if (a.mode == 1) {
+    v = row[gen ? 2 * T::ND + T::NDES + k : col_load];
+  } else {
+    const int t0 = (a.aux_index ? int(a.aux_index[env]) : int(row[a.state_dim - 1])) + 1;
+    v = a.series[(gen ? T::NLOAD + k : k) * a.period + (t0 + stage) % a.period];
+  }
+  return v / a.base;
+}
+
 // per-environment I/O of one solve (device pointers; row-major)
 struct IO {
   const double* p_load;  // [E][N][NL]  forecasts, p.u.
@@ -119,6 +157,7 @@ struct IO {
   double* trace;         // [E][max_iter + 1][12] per iteration: mu, 0, dual residual, objective, then (of the
                          //   step taken from there) primal and dual step length, centring, mu of the predictor, and the row
                          //   that limits the primal step: stage, row, 0, 0   (may be null)
+  Act act;               // mode 0 unless the solve is an act() (then p_load / p_gen are not read)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -595,9 +634,10 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
   double soc0[pos(NS)];
   {
     double pl[pos(NL)];
-    ANM_UFOR (int l = 0; l < NL; ++l) pl[l] = on ? io.p_load[(env * N + i) * NL + l] : 0.0;
+    ANM_UFOR (int l = 0; l < NL; ++l)
+      pl[l] = !on ? 0.0 : (io.act.mode ? act_forecast<T>(io.act, env, i, false, l, load_device<T>(l)) : io.p_load[(env * N + i) * NL + l]);
     ANM_UFOR (int g = 0; g < NG; ++g) {
-      const double fc = on ? io.p_gen[(env * N + i) * NG + g] : 0.0;
+      const double fc = !on ? 0.0 : (io.act.mode ? act_forecast<T>(io.act, env, i, true, g, 0) : io.p_gen[(env * N + i) * NG + g]);
       ln.wd[g] = fmax(fmin(C[S::T_GPMAX + g], fc) - C[S::T_GPMIN + g], 0.0);
     }
     ANM_UFOR (int j = 0; j < NS; ++j) {  // (a state of charge outside its window -- not a state the simulator produces -- is moved onto it)
@@ -716,6 +756,12 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         double u[pos(NC)];
         ln.phys(C, u);
         ANM_UFOR (int c = 0; c < NC; ++c) io.u0[env * NC + c] = u[c];
+        if (io.act.mode && io.act.action) {   // [P_gen.., Q_gen.. = 0, P_des.., Q_des.. = 0] MW, clipped (mpc.py:341-344, 383-388)
+          double* a = io.act.action + env * (2 * NG + 2 * NS);
+          auto clip = [&](int k, double v) { a[k] = fmin(fmax(v, io.act.act_lo[k]), io.act.act_hi[k]); };
+          ANM_UFOR (int g = 0; g < NG; ++g) { clip(g, u[g] * io.act.base); clip(NG + g, 0.0); }
+          ANM_UFOR (int j = 0; j < NS; ++j) { clip(2 * NG + j, u[NG + j] * io.act.base); clip(2 * NG + NS + j, 0.0); }
+        }
       }
       if (on && io.solution) {
         double u[pos(NC)];

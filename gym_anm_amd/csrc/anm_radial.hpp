@@ -380,16 +380,26 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       const double p = fmin(fmax(in_p / base, sd[0]), sd[1]);
       dev_p = p;
       dev_q = p * sd[2];
-    } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
-      p_pot = fmin(fmax(in_pot / base, sd[SD_PMIN]), sd[SD_PMAX]);
-      project_pq<2>(sd, in_p / base, in_q / base, sd[SD_PMIN], fmin(sd[SD_PMAX], p_pot), dev_p, dev_q);
-    } else if (typ == DEV_STORAGE) {
-      const double eff = sd[SD_EFF];
-      const double s_lo = (soc - sd[SD_SOC_MAX]) / (dt * eff);
-      const double s_hi = eff * (soc - sd[SD_SOC_MIN]) / dt;
-      project_pq<4>(sd, in_p / base, in_q / base, fmax(sd[SD_PMIN], s_lo), fmin(sd[SD_PMAX], s_hi), dev_p, dev_q);
-      const double ns = (dev_p <= 0.0) ? (soc - dt * eff * dev_p) : (soc - dt * dev_p / eff);
-      soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
+    } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE || typ == DEV_STORAGE) {
+      // ONE projection for generators and storage units (the lanes of a wavefront hold both: two calls are two
+      // instruction streams, each with the other kind's lanes masked).  A generator's third and fourth slanted line
+      // are switched off in its table (sense 0, anm_pack.hpp: pack_device), which makes the four-line projection
+      // return exactly what the two-line one does.
+      const bool des = typ == DEV_STORAGE;
+      const double eff = sd[SD_EFF];   // (generators: 1)
+      double pl = sd[SD_PMIN], pu = sd[SD_PMAX];
+      if (des) {
+        pl = fmax(pl, (soc - sd[SD_SOC_MAX]) / (dt * eff));
+        pu = fmin(pu, eff * (soc - sd[SD_SOC_MIN]) / dt);
+      } else {
+        p_pot = fmin(fmax(in_pot / base, sd[SD_PMIN]), sd[SD_PMAX]);
+        pu = fmin(pu, p_pot);
+      }
+      project_pq<4>(sd, in_p / base, in_q / base, pl, pu, dev_p, dev_q);
+      if (des) {
+        const double ns = (dev_p <= 0.0) ? (soc - dt * eff * dev_p) : (soc - dt * dev_p / eff);
+        soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
+      }
     }
   }
   sh[A_S0][t] = dev_p;
@@ -652,6 +662,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) f[d.f_gen_pmax + slot] = p_pot;
   };
 
+  // (one call site for the dump: its hypot / atan2 code exists once, not once per mode)
+  bool dump = false;
+  do {
   if (mode == 0) {
     if (typ == DEV_STORAGE) io.t.soc[e * d.NDES + slot] = soc;
     if (l == 0) {
@@ -659,9 +672,8 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       io.t.converged[e] = converged ? 1 : 0;
       if (io.t.nr_iters) io.t.nr_iters[e] = it;
     }
-    write_full();
-    ANM_PHASE(5);
-    return;
+    dump = true;
+    break;
   }
 
   double* state = io.e.state + e * S;
@@ -676,7 +688,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       for (int k = l; k < S; k += G) obs[k] = 0.0;
       if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
     }
-    return;
+    break;
   }
   if (l == 0 && io.e.nr_iters) io.e.nr_iters[e] = it;
   if (resetting) {
@@ -710,8 +722,8 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
       }
     }
-    write_full();
-    return;
+    dump = true;
+    break;
   }
   // regular step
   if (typ == DEV_STORAGE) io.e.soc[e * d.NDES + slot] = soc;
@@ -741,7 +753,10 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     }
     if (io.e.timestep) io.e.timestep[e] += 1;
   }
-  write_full();
+  dump = true;
+  } while (false);
+  if (dump) write_full();
+  ANM_PHASE(5);
 }
 #endif  // __HIPCC__
 

@@ -329,6 +329,23 @@ int anm_mpc_get_tables(const anm_mpc* m, double* out /* [table_doubles] host */)
 int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
                       const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
                       const anm_mpc_opts* opts, void* stream);
+/* MPCAgent.act() as ONE launch (mpc.py:321-346): the forecasts are gathered inside the kernel and the first stage's
+ * set-points leave as the action row.
+ *   forecast  ANM_MPC_FORECAST_CONSTANT (mpc_constant.py:24-35): the loads' dev_p and gen_p_max of the state row persist
+ *             over the horizon; ANM_MPC_FORECAST_PERFECT (mpc_perfect.py:24-40): columns t + 1 ... t + N (mod period) of
+ *             the task's tables `series` [n_load + n_gen, period] (MW, dev), t = aux_index[e] (or, aux_index NULL, the
+ *             last column of the state row)
+ *   state     [num_envs, state_dim] state rows (MW; anm_env.py:139-147); where state_same[e] != 0 the row of
+ *             state_alt is read instead (the observation rows of a model with anm_model_bind_state_same); soc as above
+ *   action    out [num_envs, 2 n_gen + 2 n_des]: [P_gen.., Q_gen.. = 0, P_des.., Q_des.. = 0] in MW / MVAr
+ *             (mpc.py:383-388), clipped to [act_low, act_high] (dev arrays of that width; mpc.py:341-344)
+ * u0 / objective / iters / info as anm_mpc_solve_f64.  All dev. */
+#define ANM_MPC_FORECAST_CONSTANT 1
+#define ANM_MPC_FORECAST_PERFECT 2
+int anm_mpc_act_f64(anm_mpc* m, int64_t num_envs, int32_t forecast, const double* state, const double* state_alt,
+                    const uint8_t* state_same, int32_t state_dim, const int32_t* aux_index, const double* series,
+                    int32_t period, const double* soc, const double* act_low, const double* act_high, double* action,
+                    double* u0, double* objective, int32_t* iters, double* info, const anm_mpc_opts* opts, void* stream);
 
 /* Offsets of each quantity inside one row of `full` (p.u. / rad), in the order of the reference's
  * STATE_VARIABLES (constants.py:31-48): bus_p, bus_q, bus_v_magn, bus_v_ang, bus_i_magn,

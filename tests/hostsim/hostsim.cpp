@@ -38,6 +38,7 @@ struct anm_mpc {
   int N = 0;
   std::vector<double> tab;
   double theta_bound = 0.0;
+  double base_mva = 1.0;
   bool angle_rows = true;
 };
 
@@ -218,6 +219,7 @@ int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_mar
     anm_mpc* m = new anm_mpc();
     if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err, &m->theta_bound)) { delete m; g_err = err; return -3; }
     m->N = planning_steps;
+    m->base_mva = desc->base_mva;
     m->angle_rows = m->theta_bound >= 0.98 * 3.14159265358979323846;   // (as anm_capi.hip)
     if (m->angle_rows && !mpc::Sz<Topo>::FITS) { delete m; return fail("anm_mpc_create: too many rows per stage with the angle rows"); }
     *out = m;
@@ -252,15 +254,13 @@ void host_mpc_solve(anm_mpc* m, const mpc::IO& io, const mpc::Opts& o, int64_t n
     for (auto& t : th) t.join();
   }
 }
-int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
-                      const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
-                      const anm_mpc_opts* opts, void*) {
+static int host_mpc_run(anm_mpc* m, int64_t num_envs, mpc::IO io, const anm_mpc_opts* opts) {
   mpc::Opts o{1e-11, 40};
   if (opts) {
     if (opts->tol > 0.0) o.tol = opts->tol;
     if (opts->max_iter > 0) o.max_iter = opts->max_iter;
+    io.trace = opts->trace;
   }
-  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, opts ? opts->trace : nullptr};
   bool full = m->angle_rows;
   if (opts && opts->angle_rows == 1) full = true;
   if (opts && opts->angle_rows == 2) full = false;
@@ -268,6 +268,22 @@ int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecas
   if (full) host_mpc_solve<Topo>(m, io, o, num_envs);
   else host_mpc_solve<TopoNoTheta>(m, io, o, num_envs);
   return 0;
+}
+int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
+                      const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
+                      const anm_mpc_opts* opts, void*) {
+  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, nullptr, mpc::Act{}};
+  return host_mpc_run(m, num_envs, io, opts);
+}
+int anm_mpc_act_f64(anm_mpc* m, int64_t num_envs, int32_t forecast, const double* state, const double* state_alt,
+                    const uint8_t* state_same, int32_t state_dim, const int32_t* aux_index, const double* series,
+                    int32_t period, const double* soc, const double* act_low, const double* act_high, double* action,
+                    double* u0, double* objective, int32_t* iters, double* info, const anm_mpc_opts* opts, void*) {
+  if (forecast != ANM_MPC_FORECAST_CONSTANT && forecast != ANM_MPC_FORECAST_PERFECT) return fail("anm_mpc_act_f64: unknown forecast");
+  if (forecast == ANM_MPC_FORECAST_PERFECT && (!series || period <= 0)) return fail("anm_mpc_act_f64: a perfect forecast needs the task's periodic tables");
+  mpc::Act a{forecast, state, state_alt, state_same, state_dim, aux_index, series, period, m->base_mva, action, act_low, act_high};
+  mpc::IO io{nullptr, nullptr, soc, u0, objective, iters, info, nullptr, nullptr, a};
+  return host_mpc_run(m, num_envs, io, opts);
 }
 int anm_model_bind_state_same(anm_model*, uint8_t* p) { return p ? fail("the host test double writes every state row") : 0; }
 int anm_model_obs_fusable(const anm_model*) { return 0; }  // the test double has no fused gather

@@ -275,7 +275,40 @@ def check_closed_loop(env, agent_cls, N, steps, n_env):
     assert not bool(env.terminated.any()) and float(tot.mean()) / steps > -5.0  # random agent: about -175 per step
 
 
+def check_fused_act(env, n_env, steps=5, horizons=(1, 3)):
+    """MPCAgent.act() as ONE launch (anm_mpc_act_f64: forecasts gathered inside the kernel, the clipped MW action row
+    written by it; mpc.py:321-346, mpc_constant.py:24-35, mpc_perfect.py:24-40) against the same agent going through
+    forecast() -> anm_mpc_solve_f64 -> scaling / clipping in torch: identical bits, step after step in closed loop."""
+    for cls in (MPCAgentConstant, MPCAgentPerfect):
+        class Unfused(cls):
+            def _fused(self, env):
+                return False
+
+        for N in horizons:
+            fused = cls(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=N)
+            plain = Unfused(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=N)
+            assert fused._fused(env) and not plain._fused(env)
+            for _ in range(steps):
+                a = fused.act(env)
+                b = plain.act(env)
+                assert a.shape == b.shape == (n_env, env.action_space.shape[0])
+                assert torch.equal(a, b), (cls.__name__, N, float((a - b).abs().max()))
+                for name in ("u0", "objective", "iters", "info"):
+                    assert torch.equal(getattr(fused.solver, name), getattr(plain.solver, name)), name
+                assert bool(fused.last_converged.all())
+                env.step(a.clone())
+
+
 # ---- CPU tier: the solver source compiled for the host --------------------------------------------------------
+def test_fused_act_equals_the_unfused_path_on_the_host_double():
+    from hostsim_backend import hostsim_backend
+
+    be = hostsim_backend(NetworkModel(networks.anm6_network(), 0.25, 100).topology())
+    env = ANM6EasyVec(num_envs=6, device="cpu", seed=5, _backend=be)
+    env.reset(seed=5)
+    check_fused_act(env, 6, steps=3)
+
+
 def test_dc_reduction_tables_host():
     check_tables(_host_sim(networks.anm6_network()))
     check_tables(_host_sim(two_storage_network()), N=3)
@@ -594,6 +627,16 @@ def test_full_batch_is_consistent_with_small_batches():
         obj = s.objective.cpu().numpy()
         assert np.abs(obj - ref).max() <= 1e-7 * (1 + np.abs(ref).max())
         assert int(s.iters.max()) < s.max_iter
+
+
+@pytest.mark.gpu
+def test_fused_act_equals_the_unfused_path_gpu():
+    """(4 096 autoresetting environments on the fast path of the step: the kernel reads the state through the
+    state_same flags and the compact time index, like `env.state` assembles it)"""
+    env = ANM6EasyVec(num_envs=4096, device="cuda:0", seed=5, autoreset=True)
+    env.reset(seed=5)
+    assert env._state_same is not None and env._aux_index is not None
+    check_fused_act(env, 4096)
 
 
 @pytest.mark.gpu
