@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): bash scripts/r03_profile.sh <stage> [what...]
+# usage (on the GPU box, via gpurun): bash scripts/r04_profile.sh <stage> [what...]
 # kernel traces + PMC passes (one counter group per pass, kernel-trace only); summaries land in
-# gpurun_out/r03_<stage>_*.txt ready to be copied to profiles/.  what: head mpc thr c30 wg (default: head mpc thr c30)
+# gpurun_out/r04_<stage>_*.txt ready to be copied to profiles/.  what: head mpc thr c30 wg (default: head mpc thr c30)
 stage=$1; shift
 what="${@:-head mpc thr c30}"
 R=$GRAFT_REPO_ROOT
-out=/tmp/prof_r03_$stage   # raw rocprofv3 output stays on the box: only the summaries travel
+out=/tmp/prof_r04_$stage   # raw rocprofv3 output stays on the box: only the summaries travel
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 pmc() {  # pmc <dir> <cmd...> : four passes
@@ -19,7 +19,7 @@ pmc() {  # pmc <dir> <cmd...> : four passes
 trace() {  # trace <name> <note> <cmd...>
   nm=$1; note=$2; shift; shift
   rocprofv3 --kernel-trace --stats -d $out/trace_$nm -- "$@" > $out/trace_$nm.log 2>&1
-  ( python $R/scripts/prof_summary.py $out/trace_$nm "$note"; echo "# output of the command:"; grep -v amdgpu.ids $out/trace_$nm.log | tail -12 ) > $R/gpurun_out/r03_${stage}_${nm}_kernel_trace.txt
+  ( python $R/scripts/prof_summary.py $out/trace_$nm "$note"; echo "# output of the command:"; grep -v amdgpu.ids $out/trace_$nm.log | tail -12 ) > $R/gpurun_out/r04_${stage}_${nm}_kernel_trace.txt
 }
 for w in $what; do
 case $w in
@@ -27,14 +27,14 @@ head)
   HEAD="python $R/bench.py --no-cpu-baseline --headline-only --steps 200 --warmup 20"
   trace bench_headline "command: bench.py --no-cpu-baseline --headline-only --steps 200 --warmup 20" $HEAD
   pmc $out/pmc_head $HEAD
-  ANM_PMC_KERNEL=k_step_rows python $R/scripts/pmc_summary.py $out/pmc_head "headline: ANM6Easy 65536 envs, tol 1e-6, cap 100, autoreset, in-wave lane-group hand-over" > $R/gpurun_out/r03_${stage}_pmc_headline.txt
+  ANM_PMC_KERNEL=k_step_rows python $R/scripts/pmc_summary.py $out/pmc_head "headline: ANM6Easy 65536 envs, tol 1e-6, cap 100, autoreset, in-wave lane-group hand-over" > $R/gpurun_out/r04_${stage}_pmc_headline.txt
   ;;
 mpc)
   for N in 1 10; do
     CMD="python $R/scripts/mpc_workload.py $N 20"
     trace mpc_N$N "command: scripts/mpc_workload.py $N 20 (65536 ANM6Easy programs per launch of k_mpc, $N stage(s))" $CMD
     pmc $out/pmc_mpc$N $CMD
-    ANM_PMC_KERNEL=k_mpc python $R/scripts/pmc_summary.py $out/pmc_mpc$N "k_mpc: 65536 programs, N = $N" > $R/gpurun_out/r03_${stage}_pmc_mpc_N$N.txt
+    ANM_PMC_KERNEL=k_mpc python $R/scripts/pmc_summary.py $out/pmc_mpc$N "k_mpc: 65536 programs, N = $N" > $R/gpurun_out/r04_${stage}_pmc_mpc_N$N.txt
   done
   ;;
 thr)
@@ -44,7 +44,7 @@ thr)
     pmc $out/pmc_thr$E $CMD
     for k in k_step_rows k_step_stragglers k_step_scatter; do
       ANM_PMC_KERNEL=$k python $R/scripts/pmc_summary.py $out/pmc_thr$E "throughput regime: ANM6Easy $E envs on one GPU, two-launch step; kernel $k"
-    done > $R/gpurun_out/r03_${stage}_pmc_throughput_$E.txt
+    done > $R/gpurun_out/r04_${stage}_pmc_throughput_$E.txt
   done
   ;;
 wg)
@@ -52,14 +52,14 @@ wg)
     CMD="python $R/scripts/large_network_workload.py $NB 4096 12"
     trace mesh$NB "command: scripts/large_network_workload.py $NB 4096 12 (general lane-group family; 200 buses: one workgroup of 256 lanes per environment)" $CMD
     pmc $out/pmc_mesh$NB $CMD
-    ANM_PMC_KERNEL=k_mesh python $R/scripts/pmc_summary.py $out/pmc_mesh$NB "k_mesh: synthetic meshed network of $NB buses, 4096 transitions per launch, cap 100" > $R/gpurun_out/r03_${stage}_pmc_mesh$NB.txt
+    ANM_PMC_KERNEL=k_mesh python $R/scripts/pmc_summary.py $out/pmc_mesh$NB "k_mesh: synthetic meshed network of $NB buses, 4096 transitions per launch, cap 100" > $R/gpurun_out/r04_${stage}_pmc_mesh$NB.txt
   done
   ;;
 c30)
   C30="python $R/scripts/bench_case30_quick.py"
   pmc $out/pmc_c30 $C30
-  ANM_PMC_KERNEL=k_radial python $R/scripts/pmc_summary.py $out/pmc_c30 "config 4: case30 radial, 16384 envs, Simulator.transition with the electrical-state dump, caps 100 and 20 mixed" > $R/gpurun_out/r03_${stage}_pmc_case30.txt
+  ANM_PMC_KERNEL=k_radial python $R/scripts/pmc_summary.py $out/pmc_c30 "config 4: case30 radial, 16384 envs, Simulator.transition with the electrical-state dump, caps 100 and 20 mixed" > $R/gpurun_out/r04_${stage}_pmc_case30.txt
   ;;
 esac
 done
-ls $R/gpurun_out/r03_${stage}_* | head -30
+ls $R/gpurun_out/r04_${stage}_* | head -30
