@@ -51,6 +51,11 @@ class StepWs(C.Structure):
     _fields_ = [("buf", C.c_void_p), ("n_doubles", C.c_int64), ("iter_cap", C.c_int32), ("mid_cap", C.c_int32)]
 
 
+class BatchView(C.Structure):
+    _fields_ = [("env_index", C.c_void_p)] + [(k, C.c_int32) for k in ["w_load", "w_gen", "w_set", "w_des", "w_action", "w_state",
+                                                                      "w_exo", "w_aux", "w_full"]]  # fmt: skip
+
+
 class MpcDims(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ["planning_steps", "n_load", "n_gen", "n_des", "n_branch", "n_ctrl",
                                          "n_stage_vars", "n_stage_rows", "table_doubles", "angle_rows"]] + \
@@ -104,6 +109,7 @@ ABI = {
     "anm_model_set_class_obs_bounds": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p]),
     "anm_model_bind_env_classes": (C.c_int, [C.c_void_p, _P, C.c_int64]),
     "anm_model_bind_state_same": (C.c_int, [C.c_void_p, _P]),
+    "anm_model_bind_view": (C.c_int, [C.c_void_p, C.POINTER(BatchView)]),
     "anm_model_obs_fusable": (C.c_int, [C.c_void_p]),
     "anm_model_set_obs": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p]),
     "anm_mpc_create": (C.c_int, [C.POINTER(NetworkDesc), C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),

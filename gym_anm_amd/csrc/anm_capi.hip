@@ -114,6 +114,8 @@ __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__
 struct anm_model {
   int impl = ANM_IMPL_THREAD;   // which kernel family serves this model
   int impl_unbound = -1;        // the family to go back to when a per-environment class binding is lifted (-1: none pending)
+  radial::View view{};          // anm_model_bind_view: the launches serve a sub-batch of a larger, padded batch
+  int impl_unviewed = -1;       // the family to go back to when the view is lifted
   bool tpe_ok = false;          // the network has the topology this library was compiled for
   bool radial_ok = false;       // the network is a tree that fits one wavefront
   radial::Plan plan;            // per-lane tables of the lane-group kernel
@@ -196,7 +198,9 @@ void launch_mesh_as(anm_model* m, int precision, unsigned grid, unsigned threads
     hipLaunchKernelGGL((mesh::k_mesh<double, false, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
 }
 
-int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
+int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io_in, SolverOpts so) {
+  radial::IO io = io_in;
+  io.v = m->view;
   const mesh::Dims& d = m->mplan.d;
   const int waves = mesh::waves_per_block(d);
   const int per_block = mesh::envs_per_block(d);
@@ -634,6 +638,36 @@ int anm_model_bind_state_same(anm_model* m, uint8_t* state_same) {
   return 0;
 }
 
+int anm_model_bind_view(anm_model* m, const anm_batch_view* v) {
+  if (!m) return fail("anm_model_bind_view: null model");
+  if (!v) {
+    m->view = radial::View{};
+    if (m->impl_unviewed >= 0) m->impl = m->impl_unviewed;
+    m->impl_unviewed = -1;
+    return 0;
+  }
+  if (!m->mesh_ok) return fail("anm_model_bind_view: a view is served by the general lane-group kernel, which cannot take this network");
+  if (m->d_env_class) return fail("anm_model_bind_view: not together with parameter classes (anm_model_bind_env_classes)");
+  if (m->n_obs > 0) return fail("anm_model_bind_view: a list-form observation is gathered by the thread-per-environment step kernel only");
+  const mesh::Dims& d = m->mplan.d;
+  const int K = m->K;
+  struct { int given, own; const char* what; } w[] = {
+      {v->w_load, d.NLOAD, "w_load"}, {v->w_gen, d.NGEN, "w_gen"}, {v->w_set, d.NSET, "w_set"}, {v->w_des, d.NDES, "w_des"},
+      {v->w_action, 2 * (d.NGEN + d.NDES), "w_action"}, {v->w_state, d.SDIM + K, "w_state"}, {v->w_exo, d.NLOAD + d.NGEN, "w_exo"},
+      {v->w_aux, K, "w_aux"}, {v->w_full, d.FS, "w_full"}};
+  for (auto& x : w)
+    if (x.given != 0 && x.given < x.own) {
+      g_err = std::string("anm_model_bind_view: ") + x.what + " is narrower than this network's own rows";
+      return -1;
+    }
+  m->view = radial::View{v->env_index, v->w_load, v->w_gen, v->w_set, v->w_des, v->w_action, v->w_state, v->w_exo, v->w_aux, v->w_full};
+  if (m->impl != ANM_IMPL_MESH) {
+    m->impl_unviewed = m->impl;
+    m->impl = ANM_IMPL_MESH;
+  }
+  return 0;
+}
+
 int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
 
 static unsigned magic_div(int d) { return d > 0 ? unsigned((0x100000000ull + uint64_t(d) - 1) / uint64_t(d)) : 0u; }
@@ -713,6 +747,8 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
   if (impl == ANM_IMPL_THREAD && m->class_per_env)
     return fail("anm_model_set_impl: the bound parameter classes change inside blocks of 64 environments: only a "
                 "lane-group kernel can serve them");
+  if (impl != ANM_IMPL_MESH && (m->view.index || m->view.w_state > 0))
+    return fail("anm_model_set_impl: a batch view is bound (anm_model_bind_view): only the general lane-group kernel serves it");
   if (impl != ANM_IMPL_THREAD && m->n_obs > 0)
     return fail("anm_model_set_impl: a list-form observation is gathered inside the thread-per-environment step kernel "
                 "(anm_model_set_obs); clear it before switching to a lane-group kernel");

@@ -537,9 +537,19 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   const int per_block = WG ? 1 : int(blockDim.x) / G;
   const int grp = WG ? 0 : t / G;
   const int wave = t >> 6, n_waves = int(blockDim.x) >> 6;
-  const int64_t e = int64_t(blockIdx.x) * per_block + grp;
-  const bool env_ok = e < n_env;
-  const int64_t ee = env_ok ? e : 0;
+  // slot of this launch -> environment: itself, or (a view is bound: the launch serves a SUB-batch of a larger batch whose
+  // rows are padded to common widths, anm_model_bind_view) the index the view names; the row strides of the batch arrays
+  // are the network's own widths unless the view gives others
+  const int64_t slot_e = int64_t(blockIdx.x) * per_block + grp;
+  const bool env_ok = slot_e < n_env;
+  const int64_t ee = io.v.index ? int64_t(io.v.index[env_ok ? slot_e : 0]) : (env_ok ? slot_e : 0);
+  const int64_t e = ee;   // (lanes of a slot beyond the batch compute on another environment and never store)
+  const int W_LOAD = io.v.w_load > 0 ? io.v.w_load : d.NLOAD, W_GEN = io.v.w_gen > 0 ? io.v.w_gen : d.NGEN;
+  const int W_SET = io.v.w_set > 0 ? io.v.w_set : d.NSET, W_DES = io.v.w_des > 0 ? io.v.w_des : d.NDES;
+  const int W_ACT = io.v.w_action > 0 ? io.v.w_action : 2 * (d.NGEN + d.NDES);
+  const int W_ST = io.v.w_state > 0 ? io.v.w_state : d.SDIM + io.e.K;
+  const int W_EXO = io.v.w_exo > 0 ? io.v.w_exo : d.NLOAD + d.NGEN, W_AUX = io.v.w_aux > 0 ? io.v.w_aux : io.e.K;
+  const int W_FS = io.v.w_full > 0 ? io.v.w_full : d.FS;
   const int64_t first_env = int64_t(blockIdx.x) * per_block + (WG ? 0 : (t >> 6) * per_wave);
   const double* __restrict__ rd =
       PG ? rd0 + int64_t(cls.env_class[ee]) * cls.stride
@@ -609,15 +619,15 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   int aux = 0;
   double in_p = 0.0, in_q = 0.0, in_pot = 0.0, soc = 0.0, s0_q = 0.0, soc_req = 0.0;
   if (mode == 0) {
-    if (typ == DEV_LOAD) in_p = io.t.p_load[ee * d.NLOAD + slot];
+    if (typ == DEV_LOAD) in_p = io.t.p_load[ee * W_LOAD + slot];
     else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
-      in_pot = io.t.p_pot[ee * d.NGEN + slot];
-      in_p = io.t.p_set[ee * d.NSET + sset];
-      in_q = io.t.q_set[ee * d.NSET + sset];
+      in_pot = io.t.p_pot[ee * W_GEN + slot];
+      in_p = io.t.p_set[ee * W_SET + sset];
+      in_q = io.t.q_set[ee * W_SET + sset];
     } else if (typ == DEV_STORAGE) {
-      in_p = io.t.p_set[ee * d.NSET + sset];
-      in_q = io.t.q_set[ee * d.NSET + sset];
-      soc = io.t.soc[ee * d.NDES + slot];
+      in_p = io.t.p_set[ee * W_SET + sset];
+      in_q = io.t.q_set[ee * W_SET + sset];
+      soc = io.t.soc[ee * W_DES + slot];
     }
   } else {
     const bool was_term = (mode == 2) && io.e.terminated[ee] != 0;
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     double s0_p = 0.0, s0_pm = 0.0;
     sampled = resetting && !(mode == 1 && io.e.init_state);
     if (mode == 1 && io.e.init_state) {
-      const double* s0 = io.e.init_state + ee * SD_;
+      const double* s0 = io.e.init_state + ee * W_ST;
       if (typ != DEV_NONE) { s0_p = s0[l]; s0_q = s0[d.ND + l]; }
       if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) s0_pm = s0[2 * d.ND + d.NDES + slot];
       if (typ == DEV_STORAGE) soc_req = s0[2 * d.ND + slot];
@@ -661,21 +671,21 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
         soc = (s0_p <= 0.0) ? sd[SD_SOC_MIN] : sd[SD_SOC_MAX];  // simulator.py:273-278
       }
     } else if (!skip) {
-      const double* a = io.e.action + ee * (2 * (d.NGEN + d.NDES));
+      const double* a = io.e.action + ee * W_ACT;
       if (series) {
-        const double av = io.e.state[ee * SD_ + d.SDIM];
+        const double av = io.e.state[ee * W_ST + d.SDIM];
         aux = int(fmod(av + 1.0, double(io.e.period)));
         if (typ == DEV_LOAD) in_p = io.e.series[slot * io.e.period + aux];
         else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.series[(d.NLOAD + slot) * io.e.period + aux];
       } else {
-        if (typ == DEV_LOAD) in_p = io.e.exo[ee * (d.NLOAD + d.NGEN) + slot];
-        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.exo[ee * (d.NLOAD + d.NGEN) + d.NLOAD + slot];
+        if (typ == DEV_LOAD) in_p = io.e.exo[ee * W_EXO + slot];
+        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.exo[ee * W_EXO + d.NLOAD + slot];
       }
       if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) { in_p = a[slot]; in_q = a[d.NGEN + slot]; }
       else if (typ == DEV_STORAGE) {
         in_p = a[2 * d.NGEN + slot];
         in_q = a[2 * d.NGEN + d.NDES + slot];
-        soc = io.e.soc[ee * d.NDES + slot];
+        soc = io.e.soc[ee * W_DES + slot];
       }
     }
   }
@@ -1035,7 +1045,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   double* full = (mode == 0) ? io.t.full : io.e.full;
   auto write_full = [&]() {
     if (!full) return;
-    double* f = full + e * d.FS;
+    double* f = full + e * W_FS;
     if (isbus) {
       f[d.f_bus_p + bus] = bus_p; f[d.f_bus_q + bus] = bus_q;
       f[d.f_bus_vm + bus] = hypot(vr, vi); f[d.f_bus_va + bus] = atan2(vi, vr);
@@ -1060,7 +1070,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   };
 
   if (mode == 0) {
-    if (typ == DEV_STORAGE) io.t.soc[e * d.NDES + slot] = soc;
+    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
     if (l == 0) {
       io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
       io.t.converged[e] = converged ? 1 : 0;
@@ -1070,8 +1080,8 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     return;
   }
 
-  double* state = io.e.state + e * SD_;
-  double* obs = io.e.obs + e * SD_;
+  double* state = io.e.state + e * W_ST;
+  double* obs = io.e.obs + e * W_ST;
   cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
   auto put = [&](int k, double v) {
     state[k] = v;
@@ -1088,7 +1098,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   if (resetting) {
     if (typ == DEV_STORAGE) {
       soc = soc_req / base;  // simulator.py:284-288
-      io.e.soc[e * d.NDES + slot] = soc;
+      io.e.soc[e * W_DES + slot] = soc;
     }
     if (mode == 2 && !converged) {
       for (int k = l; k < SD_; k += G) { state[k] = 0.0; obs[k] = 0.0; }
@@ -1101,7 +1111,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       if (sampled) {
         if (l == 0) { put(d.SDIM, double(aux)); io.e.reset_count[e] += 1; }
       } else {
-        const double* s0 = io.e.init_state + e * SD_;
+        const double* s0 = io.e.init_state + e * W_ST;
         for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
       }
       if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
@@ -1117,7 +1127,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     write_full();
     return;
   }
-  if (typ == DEV_STORAGE) io.e.soc[e * d.NDES + slot] = soc;
+  if (typ == DEV_STORAGE) io.e.soc[e * W_DES + slot] = soc;
   const bool term = !converged;
   if (!term) {
     if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
@@ -1126,7 +1136,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     if (io.e.exo == nullptr) {
       if (l == 0) put(d.SDIM, double(aux));
     } else {
-      for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * K + k]);
+      for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * W_AUX + k]);
     }
   } else {
     for (int k = l; k < SD_; k += G) { state[k] = 0.0; obs[k] = 0.0; }

@@ -222,10 +222,19 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
 
+// A launch may serve a SUB-batch of a larger batch (anm_model_bind_view; the general lane-group family): slot s of the
+// launch is environment index[s] of the batch arrays, whose rows are padded to common widths -- how one batch holds
+// environments over networks of DIFFERENT topologies, one launch per topology
+struct View {
+  const int32_t* index;   // null: slot = environment
+  int w_load, w_gen, w_set, w_des, w_action, w_state, w_exo, w_aux, w_full;   // row strides (0: the network's own widths)
+};
+
 struct IO {
   int mode;  // 0 transition, 1 reset, 2 step
   TransitionIO t;
   EnvIO e;
+  View v;
 };
 
 // A workgroup is exactly one wavefront and a wavefront's LDS operations complete in program

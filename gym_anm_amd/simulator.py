@@ -377,3 +377,82 @@ class BatchedSimulator:
             "dev_type": {did: int(m.dev_type[k]) for k, did in enumerate(m.dev_ids)}, "des_soc": sb["des_soc"],
             "branch_s": branch_s,
         }  # fmt: skip
+
+
+class MixedBatchedSimulator:
+    """Environments over networks of DIFFERENT topologies in one batch (the reference builds one ``Simulator`` per
+    environment from whatever dict it is given: ``simulator.py:70-111``, ``examples/custom_anm6.py:20``).
+
+    ``networks``: the distinct network dicts; ``env_network[e]``: which of them environment ``e`` lives on, in any order.
+    Every per-environment array has ONE row per environment, padded to the widest network (``P_load [E, max n_load]``,
+    ``full [E, max full_dim]`` ...); inside its row an environment uses the layout of its own network, from column 0
+    (``layout(k)`` gives it: ``full_offsets``, ``full_counts``, the device order).  ``transition`` is one launch of the
+    general lane-group kernel per topology, each told through a view (``anm_model_bind_view``) which rows are its own --
+    nothing is gathered, copied or scattered around the launches.
+    """
+
+    def __init__(self, networks, env_network, delta_t, lamb, device="cuda", tol=1e-5, max_iter=100, precision="f64"):
+        env_network = np.asarray(env_network, dtype=np.int64)
+        if env_network.ndim != 1 or env_network.size == 0 or env_network.min() < 0 or env_network.max() >= len(networks):
+            raise ValueError("env_network must be a 1-D array of indices into `networks`")
+        self.num_envs = int(env_network.size)
+        self.delta_t, self.lamb = delta_t, lamb
+        self.env_network = env_network
+        self.subs, self.env_index = [], []
+        for k, net in enumerate(networks):
+            idx = np.nonzero(env_network == k)[0]
+            sub = BatchedSimulator(net, delta_t, lamb, num_envs=max(1, idx.size), device=device, tol=tol, max_iter=max_iter,
+                                   precision=precision, impl="mesh")
+            self.subs.append(sub)
+            self.env_index.append(torch.as_tensor(idx, dtype=torch.int32, device=sub.device))
+        self.device = self.subs[0].device
+        W = lambda f: max(f(s) for s in self.subs)  # noqa: E731
+        self.widths = dict(load=W(lambda s: s.N_load), gen=W(lambda s: s.N_non_slack_gen), setp=W(lambda s: len(s.model.setp_idx)),
+                           des=W(lambda s: s.N_des), full=W(lambda s: s.full_dim))
+        E_, f64 = self.num_envs, dict(dtype=torch.float64, device=self.device)
+        w = self.widths
+        self.soc = torch.zeros((E_, max(1, w["des"])), **f64)
+        self.full = torch.zeros((E_, w["full"]), **f64)
+        self.reward, self.e_loss, self.penalty = (torch.zeros(E_, **f64) for _ in range(3))
+        self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
+        self.nr_iters = torch.zeros(E_, dtype=torch.int32, device=self.device)
+        self.pfe_converged = None
+        self._views = []
+        for sub, idx in zip(self.subs, self.env_index):
+            v = _lib.BatchView(idx.data_ptr(), max(1, w["load"]), max(1, w["gen"]), max(1, w["setp"]), self.soc.shape[1], 0, 0, 0, 0,
+                               w["full"])
+            self._views.append(v)
+            with sub._device_ctx():
+                sub.backend.check(sub.backend.lib.anm_model_bind_view(sub._handle, C.byref(v)), "anm_model_bind_view")
+
+    def layout(self, k):
+        """the ``BatchedSimulator`` of network ``k``: its ``model``, ``full_offsets`` / ``full_counts`` (columns of a ``full``
+        row of an environment on that network), ``unit_scale`` ..."""
+        return self.subs[k]
+
+    def _pad(self, x, width, name):
+        t = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+        if t.dim() != 2 or t.shape[0] != self.num_envs or t.shape[1] > max(1, width):
+            raise ValueError("%s must have shape (%d, <= %d), got %s" % (name, self.num_envs, max(1, width), tuple(t.shape)))
+        if t.shape[1] < max(1, width):
+            t = torch.nn.functional.pad(t, (0, max(1, width) - t.shape[1]))
+        return t.contiguous()
+
+    def transition(self, P_load, P_potential, P_set_points, Q_set_points):
+        """Batched ``Simulator.transition`` (simulator.py:464-537) over the mixed batch: ``[E, width]`` tensors, row ``e``
+        holding the values of environment ``e``'s own network from column 0 (devices by ascending id), the rest ignored.
+        Returns ``(full, reward, e_loss, penalty, pfe_converged)``."""
+        w = self.widths
+        pl, pp = self._pad(P_load, w["load"], "P_load"), self._pad(P_potential, w["gen"], "P_potential")
+        ps, qs = self._pad(P_set_points, w["setp"], "P_set_points"), self._pad(Q_set_points, w["setp"], "Q_set_points")
+        for sub, idx in zip(self.subs, self.env_index):
+            if idx.numel() == 0:
+                continue
+            with sub._device_ctx():
+                rc = sub.backend.lib.anm_transition_f64(
+                    sub._handle, int(idx.numel()), pl.data_ptr(), pp.data_ptr(), ps.data_ptr(), qs.data_ptr(), self.soc.data_ptr(),
+                    self.full.data_ptr(), self.reward.data_ptr(), self.e_loss.data_ptr(), self.penalty.data_ptr(),
+                    self._conv_u8.data_ptr(), self.nr_iters.data_ptr(), C.byref(sub.opts), _stream_ptr(self.device))
+            sub.backend.check(rc, "anm_transition_f64")
+        self.pfe_converged = self._conv_u8.bool()
+        return self.full, self.reward, self.e_loss, self.penalty, self.pfe_converged

@@ -151,6 +151,23 @@ int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_des
 int anm_model_set_class_obs_bounds(anm_model* m, int32_t cls, const double* low, const double* high);
 int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t num_envs);
 
+/* Environments over networks of DIFFERENT topologies in one batch (the reference builds one Simulator per environment from
+ * any dict: simulator.py:70-111, examples/custom_anm6.py:20).  The batch arrays then have rows padded to common widths
+ * (the largest of the networks in each array) and every topology has its own model; a VIEW tells a model which
+ * environments of the batch are its own and how wide the rows are.  While a view is bound, anm_transition_f64 /
+ * anm_reset_f64 / anm_step_f64 take num_envs = the number of environments of the view: launch slot s works on
+ * environment env_index[s] -- row env_index[s] of every per-environment array, the RNG key env_offset + env_index[s] --
+ * with the row strides given here; inside a row the network's own layout starts at column 0 (state: dev_p, dev_q,
+ * des_soc, gen_p_max, aux at column state_base_dim).  Served by the general lane-group family (the model switches to it;
+ * a network it cannot take is refused); not together with parameter classes or a list-form observation.  NULL unbinds.
+ * One launch per topology; launches of different models on different streams may overlap (they touch disjoint rows). */
+typedef struct anm_batch_view {
+  const int32_t* env_index; /* DEVICE int32 [n]: the environments of this view (caller-owned, alive while bound); NULL: 0..n-1 */
+  int32_t w_load, w_gen, w_set, w_des;   /* row strides of p_load / p_pot / p_set, q_set / soc (0: the network's own width) */
+  int32_t w_action, w_state, w_exo, w_aux, w_full; /* ... of action / state, obs, init_state / exo / aux_next / full */
+} anm_batch_view;
+int anm_model_bind_view(anm_model* m, const anm_batch_view* view);
+
 /* The observation of the "state" form is clip(state, Box): the same numbers as the state row except when a
  * bound bites.  With a flag array bound here (DEVICE uint8 [num_envs], caller-owned, alive while bound; NULL
  * unbinds) anm_step_f64 does not write the duplicate: state_same[e] = 1 means "the state row of e equals its

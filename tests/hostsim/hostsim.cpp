@@ -285,6 +285,7 @@ int anm_mpc_act_f64(anm_mpc* m, int64_t num_envs, int32_t forecast, const double
   mpc::IO io{nullptr, nullptr, soc, u0, objective, iters, info, nullptr, nullptr, a};
   return host_mpc_run(m, num_envs, io, opts);
 }
+int anm_model_bind_view(anm_model*, const anm_batch_view* v) { return v ? fail("the host test double has no lane-group kernels") : 0; }
 int anm_model_bind_state_same(anm_model*, uint8_t* p) { return p ? fail("the host test double writes every state row") : 0; }
 int anm_model_obs_fusable(const anm_model*) { return 0; }  // the test double has no fused gather
 int anm_model_set_obs(anm_model*, int32_t n_obs, const int32_t*, const double*, const double*, const double*) {

@@ -396,6 +396,76 @@ def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeles
     return sim
 
 
+def test_different_topologies_in_one_batch_against_their_own_oracles():
+    """The reference builds one Simulator per environment from any dict (simulator.py:70-111, examples/custom_anm6.py:20).
+    Here: ANM6, the 3-bus loop and a random meshed 20-bus network, dealt at random to the 4 096 environments of ONE batch
+    (MixedBatchedSimulator: rows padded to the widest network, one launch of the general lane-group kernel per topology
+    through anm_model_bind_view, nothing copied around them).  Every 8th environment -- and every one of the hopeless
+    cases -- against the oracle of ITS OWN network: flags and Newton iteration counts exact, electrical state <= 1e-9; the
+    padding of every row untouched."""
+    import anm_oracle as O
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import MixedBatchedSimulator
+
+    nets = [networks.anm6_network(), networks.three_bus_loop_network(gen_max=1.5), networks.synthetic_meshed_network(20, 3, 6)]
+    E_ = 4096
+    rng = np.random.default_rng(5)
+    env_net = rng.integers(0, len(nets), E_)
+    sim = MixedBatchedSimulator(nets, env_net, 0.25, 100, device=DEV, tol=1e-8)
+    assert len({s.model.topology()[0] for s in sim.subs}) == 3 and all(s.impl == "mesh" for s in sim.subs)
+    w = sim.widths
+    pl, pp = np.zeros((E_, w["load"])), np.zeros((E_, w["gen"]))
+    ps, qs, soc = np.zeros((E_, w["setp"])), np.zeros((E_, w["setp"])), np.zeros((E_, w["des"]))
+    hopeless = rng.random(E_) < 0.01
+    for k, sub in enumerate(sim.subs):
+        m, b = sub.model, sub.model.baseMVA
+        idx = np.nonzero(env_net == k)[0]
+
+        def U(lo, hi, scale=1.0):
+            lo, hi = np.asarray(lo, float) * scale, np.asarray(hi, float) * scale
+            return lo + (hi - lo) * rng.uniform(size=(idx.size, lo.size))
+
+        pl[idx, : m.N_load] = U(m.dev_p_min[m.load_idx], 0 * m.dev_p_min[m.load_idx], 0.6 * b)
+        pp[idx, : m.N_non_slack_gen] = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx], b)
+        ps[idx, : len(m.setp_idx)] = U(m.dev_p_min[m.setp_idx], m.dev_p_max[m.setp_idx], 1.2 * b)
+        qs[idx, : len(m.setp_idx)] = U(m.dev_q_min[m.setp_idx], m.dev_q_max[m.setp_idx], 1.2 * b)
+        soc[idx, : m.N_des] = U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx])
+    pl[hopeless] *= 40.0   # both sides must give up the same way
+    sim.soc[:, : w["des"]].copy_(torch.as_tensor(soc))
+    sim.full.fill_(-777.0)
+    full, r, el, pen, conv = sim.transition(pl, pp, ps, qs)
+    full, conv, iters = full.cpu().numpy(), conv.cpu().numpy(), sim.nr_iters.cpu().numpy()
+    soc_after, reward = sim.soc.cpu().numpy(), r.cpu().numpy()
+    parsed = [O.parse_network(n, 0.25, 100) for n in nets]
+    n_checked, n_conv, n_fail = np.zeros(3, int), 0, 0
+    for e in range(E_):
+        k = int(env_net[e])
+        sub, m = sim.layout(k), sim.layout(k).model
+        assert (full[e, sub.full_dim:] == -777.0).all(), "environment %d wrote beyond the row of its network" % e
+        if e % 8 and not hopeless[e]:
+            continue
+        ref = O.transition(parsed[k], pl[e, : m.N_load], pp[e, : m.N_non_slack_gen], ps[e, : len(m.setp_idx)], qs[e, : len(m.setp_idx)],
+                           soc[e, : m.N_des], tol=1e-8, sparse=False)
+        n_checked[k] += 1
+        assert bool(conv[e]) == bool(ref["converged"]), e
+        npt.assert_allclose(soc_after[e, : m.N_des], ref["soc_after"], rtol=0, atol=1e-12)
+        if not ref["converged"]:
+            n_fail += 1
+            continue
+        n_conv += 1
+        sl = pc.full_slices(sub)
+        assert int(iters[e]) == ref["n_iter"], e
+        npt.assert_allclose(full[e, sl["bus_v_magn"]], np.abs(ref["V"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["bus_v_ang"]], np.angle(ref["V"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["bus_i_magn"]], np.abs(ref["I"]), rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["dev_p"]], ref["dev_p"], rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["dev_q"]], ref["dev_q"], rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["branch_p"]], ref["br_p_from"], rtol=0, atol=1e-9)
+        npt.assert_allclose(full[e, sl["branch_s"]], ref["br_s"], rtol=0, atol=1e-9)
+        npt.assert_allclose(reward[e], ref["reward"], rtol=1e-9, atol=1e-9)
+    assert (n_checked >= 100).all() and n_conv >= 400 and n_fail >= 5, (n_checked, n_conv, n_fail)
+
+
 @pytest.mark.parametrize("n_bus,seed,n_chords", [(30, 6, 4), (64, 10, 24), (200, 13, 30)])
 def test_mesh_fused_levels_schedule_equals_the_default(monkeypatch, n_bus, seed, n_chords):
     """ANM_MESH_FUSED_LEVELS (read when the model is created): product and subtraction of an elimination level in one
