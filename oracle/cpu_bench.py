@@ -57,6 +57,30 @@ def run(budget_s, seed=0):
     return n, time.perf_counter() - t0, time.process_time() - c0
 
 
+def run_reference(budget_s, seed=0):
+    """The UNMODIFIED reference (gym_anm.envs.ANM6Easy from /root/reference, imported through oracle/ref_harness.py: stubs
+    for gymnasium / websocket, the exact-projection stand-in for the one cvxpy QP) on the same workload: uniform random
+    actions in the action Box, reset on collapse.  Dev container only (the reference does not travel to the GPU box)."""
+    import ref_harness
+
+    if not ref_harness.reference_available():
+        raise SystemExit("the reference is not available here (/root/reference)")
+    ref_harness.load_reference()
+    from gym_anm.envs import ANM6Easy
+
+    env = ANM6Easy()
+    env.reset(seed=seed)
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(env.action_space.low, float), np.asarray(env.action_space.high, float)
+    n, t0, c0 = 0, time.perf_counter(), time.process_time()
+    while time.perf_counter() - t0 < budget_s:
+        _, _, term, _, _ = env.step(rng.uniform(lo, hi))
+        n += 1
+        if term:
+            env.reset()
+    return n, time.perf_counter() - t0, time.process_time() - c0
+
+
 def run_cpp(budget_s, seed=0, num_envs=2048):
     """Second CPU figure: the kernel templates themselves compiled for the host with g++ -O2
     (tests/hostsim, the test double of the CPU tier), single-threaded loop over `num_envs` environments
@@ -132,7 +156,16 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--impl", choices=["numpy", "cpp"], default="numpy")
+    ap.add_argument("--impl", choices=["numpy", "cpp", "reference"], default="numpy")
+    ap.add_argument("--reference", action="store_true",
+                    help="dev container: the unmodified reference and the oracle on the same workload, one after the other")
     a = ap.parse_args()
-    n, dt, cpu = (run if a.impl == "numpy" else run_cpp)(a.seconds, a.seed)
-    print(json.dumps({"steps": n, "seconds": dt, "cpu_seconds": cpu}))
+    if a.reference:
+        nr, tr, _ = run_reference(a.seconds, a.seed)
+        no, to, _ = run(a.seconds, a.seed)
+        print(json.dumps({"reference_env_steps_per_s": nr / tr, "oracle_env_steps_per_s": no / to, "ratio_oracle_over_reference": (no / to) / (nr / tr),
+                          "seconds_each": a.seconds, "cores": 1, "host": os.uname().nodename,
+                          "workload": "ANM6Easy, uniform random actions in the action Box, reset on collapse, tol 1e-5, one environment"}))
+    else:
+        n, dt, cpu = {"numpy": run, "cpp": run_cpp, "reference": run_reference}[a.impl](a.seconds, a.seed)
+        print(json.dumps({"steps": n, "seconds": dt, "cpu_seconds": cpu}))
