@@ -145,6 +145,7 @@ class Backend:
         self.device_type = device_type  # "cuda" for the product; the test double says "cpu"
         self.path = path
         self.generic = False  # True: library compiled for another topology, lane-group kernel only
+        self.size_class = None  # (MPC size-class libraries only: MpcBackend)
 
     def check(self, rc, what):
         if rc != 0:
@@ -240,25 +241,49 @@ class MpcBackend:
             fn = getattr(cdll, name)
             fn.restype, fn.argtypes = res, args
         self.lib, self.path, self.device_type = cdll, path, "cuda"
+        self.size_class = None   # name of the MPC size class this library was compiled for (codegen.MPC_CLASSES), if any
 
     check = Backend.check
     signature = Backend.signature
 
 
-def load_mpc_for_topology(topo) -> MpcBackend:
-    """Build (first use: one hipcc run of csrc/anm_mpc_only.hip) and load the MPC kernel of ``topo``: for networks
-    whose step runs in generic mode on the lane-group kernels of a library compiled for another topology."""
-    name = "mpc:" + codegen.topology_name(topo)
+def _topology_counts(topo):
+    n_bus, branches, devices = topo
+    types = [t for t, _ in devices]
+    return (types.count(codegen.LOAD), types.count(codegen.CLASSICAL) + types.count(codegen.RENEWABLE), types.count(codegen.STORAGE),
+            n_bus, len(branches))
+
+
+def load_mpc_for_topology(topo, size_class=None) -> MpcBackend:
+    """The MPC kernel for a network whose step runs in generic mode (on the lane-group kernels of a library compiled for
+    another topology).  ``k_mpc`` depends on the network through its SIZES only, so:
+
+    * a library already built for exactly this topology (``libmpc_<topology>.so``) is used when it is there;
+    * else the smallest precompiled SIZE CLASS that takes the network padded (``libmpc_class_<name>.so``,
+      ``codegen.MPC_CLASSES``: up to 24 loads, 4 generators, 2 storage units, 42 buses, 44 branches) -- no compile;
+    * else ``libmpc_<topology>.so`` is built (one hipcc run of csrc/anm_mpc_only.hip on first use).
+
+    ``size_class``: True forces a size class (tests), False forbids it."""
+    tname = codegen.topology_name(topo)
+    name = "mpc:" + tname
+    exact = codegen.lib_path(tname, mpc_only=True)
+    cls = None if size_class is False else codegen.mpc_class_for(_topology_counts(topo))
+    if size_class is True and cls is None:
+        raise E.UnsupportedNetworkError("no MPC size class takes this network")
+    use_class = cls is not None and (size_class is True or not os.path.exists(exact))
+    if use_class:
+        name = "mpcclass:" + cls
     if name in _CACHE:
         return _CACHE[name]
-    path = codegen.build_library(topo, mpc_only=True)
+    path = codegen.build_mpc_class(cls) if use_class else codegen.build_library(topo, mpc_only=True)
     try:
         cdll = C.CDLL(path)
     except OSError as ex:
         raise E.HipExtensionError("cannot load the gfx950 library %s: %s" % (path, ex)) from ex
     be = MpcBackend(cdll, path)
-    if be.signature() != codegen.topology_signature(topo):
+    if not use_class and be.signature() != codegen.topology_signature(topo):
         raise E.HipExtensionError("library %s was built for another topology (%s)" % (path, be.signature()))
+    be.size_class = cls if use_class else None
     _CACHE[name] = be
     return be
 

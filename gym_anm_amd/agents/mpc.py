@@ -157,14 +157,15 @@ class BatchedDCOPF:
     TOL_DEFAULT, MAX_ITER_DEFAULT = 1e-11, 40   # the library's defaults (anm_mpc_capi.inc), always passed explicitly
 
     def __init__(self, simulator, gamma, safety_margin, planning_steps, tol=None, max_iter=None, keep_solution=False,
-                 keep_trace=False, angle_rows=None):
+                 keep_trace=False, angle_rows=None, size_class=None):
         from .. import _lib
 
         self.backend, self.device = simulator.backend, simulator.device
-        if getattr(self.backend, "generic", False):
-            # the simulator steps on the table-driven lane-group kernels of a library compiled for another topology;
-            # the MPC kernel is specialised on the sizes of THIS one: its own small library (built on first use)
-            self.backend = _lib.load_mpc_for_topology(simulator.model.topology())
+        if getattr(self.backend, "generic", False) or size_class:
+            # the simulator steps on the table-driven lane-group kernels of a library compiled for another topology; the
+            # MPC kernel depends on the network's SIZES: a precompiled size class the network is padded into (no compile),
+            # or a small library of its own (size_class=True forces a class: tests)
+            self.backend = _lib.load_mpc_for_topology(simulator.model.topology(), size_class=size_class)
         self._device_ctx = simulator._device_ctx
         self._stream_ptr = lambda: _lib_stream(self.device)
         self.N = int(planning_steps)
@@ -286,7 +287,8 @@ class MPCAgent:
     ``last_converged`` is the per-environment mask of solves that reached the tolerance; like the reference, which
     prints ``OPF problem is <status>`` and goes on (``mpc.py:377-379``), ``act`` warns when it is not all true."""
 
-    def __init__(self, simulator, action_space, gamma, safety_margin=0.9, planning_steps=1, tol=None, max_iter=None):
+    def __init__(self, simulator, action_space, gamma, safety_margin=0.9, planning_steps=1, tol=None, max_iter=None,
+                 size_class=None):
         self.simulator = simulator
         self.action_space = action_space
         self.gamma, self.safety_margin, self.planning_steps = gamma, safety_margin, int(planning_steps)
@@ -296,7 +298,7 @@ class MPCAgent:
         self.non_slack_gen_ids = [m.dev_ids[k] for k in m.gen_idx]
         self.des_ids = [m.dev_ids[k] for k in m.des_idx]
         self.device = simulator.device
-        self.solver = BatchedDCOPF(simulator, gamma, safety_margin, planning_steps, tol=tol, max_iter=max_iter)
+        self.solver = BatchedDCOPF(simulator, gamma, safety_margin, planning_steps, tol=tol, max_iter=max_iter, size_class=size_class)
         self._acted, self._conv = False, None
         # `tensor / python scalar` is a multiplication by the reciprocal on the GPU; the reference divides (`/ self.baseMVA`):
         # the forecasts are divided by this 0-dim tensor (a true division), like the fused kernel does

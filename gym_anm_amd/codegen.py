@@ -576,6 +576,94 @@ def stock_topologies():
     return {k: NetworkModel(v, 0.25, 100).topology() for k, v in nets.items()}
 
 
+# MPC size classes: (n_load, n_gen, n_des, n_bus, n_branch) upper bounds of kernels compiled ONCE (libmpc_class_<name>.so)
+# that serve any smaller network padded into them (csrc/anm_mpc.hpp: is_padded) -- a network that steps on the
+# table-driven kernels (no library of its own) then gets its MPC agent without a compile.  The storage count must match.
+# "s*": at most 72 rows per stage, the working set of a lane in registers; "l*": up to 156 rows, row arrays in scratch.
+MPC_CLASSES = {
+    "s0": (8, 2, 0, 18, 22), "s1": (8, 2, 1, 18, 20), "s2": (8, 2, 2, 18, 18),
+    "l0": (24, 4, 0, 42, 44), "l1": (24, 4, 1, 42, 44), "l2": (24, 4, 2, 42, 44),
+}
+
+
+def mpc_class_for(model_or_counts):
+    """smallest size class that takes a network of (n_load, n_gen, n_des, n_bus, n_branch), or None"""
+    nl, ng, ns, nb, nbr = model_or_counts
+    for name in ("s%d" % ns, "l%d" % ns):
+        c = MPC_CLASSES.get(name)
+        if c and nl <= c[0] and ng <= c[1] and ns == c[2] and nb <= c[3] and nbr <= c[4]:
+            return name
+    return None
+
+
+def mpc_class_header(name) -> str:
+    nl, ng, ns, nb, nbr = MPC_CLASSES[name]
+    return "\n".join([
+        "// Generated by gym_anm_amd/codegen.py -- MPC size class '%s' (no topology: csrc/anm_mpc.hpp, is_padded)." % name,
+        "#pragma once",
+        "namespace {",
+        "struct Topo {",
+        '  static constexpr const char* NAME = "mpcclass_%s";' % name,
+        '  static constexpr const char* SIGNATURE = "MPCCLASS|L%d|G%d|S%d|B%d|R%d";' % (nl, ng, ns, nb, nbr),
+        "  static constexpr int NB = %d, NBR = %d, ND = %d;" % (nb, nbr, nl + ng + ns + 1),
+        "  static constexpr int NLOAD = %d, NGEN = %d, NDES = %d;" % (nl, ng, ns),
+        "  static constexpr bool MPC_PADDED = true;",
+        "};",
+        "}  // namespace",
+        "",
+    ])
+
+
+def build_mpc_class(name, force=False, verbose=False):
+    """Compile ``libmpc_class_<name>.so`` (csrc/anm_mpc_only.hip over the class header) for gfx950."""
+    import fcntl
+
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    hdr = os.path.join(BUILD_DIR, "mpcclass_%s.h" % name)
+    lib = os.path.join(BUILD_DIR, "libmpc_class_%s%s.so" % (name, _tag()))
+    text = mpc_class_header(name)
+    extra = os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
+    stamp = _build_stamp(text, HIPCC_FLAGS + extra)
+    stamp_path = lib + ".stamp"
+
+    def fresh():
+        try:
+            return os.path.exists(lib) and open(stamp_path).read().strip() == stamp
+        except OSError:
+            return False
+
+    if fresh() and not force:
+        return lib
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise E.HipExtensionError("no prebuilt MPC size-class library '%s' and hipcc was not found to build it" % name)
+    with open(lib + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if fresh() and not force:
+                return lib
+            with open(hdr + ".tmp", "w") as f:
+                f.write(text)
+            os.replace(hdr + ".tmp", hdr)
+            tmp = "%s.%d.tmp" % (lib, os.getpid())
+            cmd = [hipcc] + HIPCC_FLAGS + extra + ['-DANM_TOPO_HEADER="%s"' % hdr, "-I", os.path.join(os.path.dirname(PKG_DIR), "include"),
+                   os.path.join(CSRC, "anm_mpc_only.hip"), "-o", tmp]  # fmt: skip
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+                raise E.HipExtensionError("hipcc failed for MPC size class '%s':\n%s\n%s" % (name, res.stdout[-4000:], res.stderr[-8000:]))
+            os.replace(tmp, lib)
+            with open(stamp_path + ".tmp", "w") as f:
+                f.write(stamp + "\n")
+            os.replace(stamp_path + ".tmp", stamp_path)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return lib
+
+
 def stock_mpc_only_topologies():
     """MPC-only libraries built ahead of time: a meshed 20-bus network (the GPU tests' example of a network that steps
     in generic mode and has its MPC kernel compiled for its own topology)."""
@@ -590,7 +678,8 @@ def build_stock(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
 
     topos, mpc_topos = stock_topologies(), stock_mpc_only_topologies()
-    with ThreadPoolExecutor(max_workers=len(topos) + len(mpc_topos)) as pool:
+    with ThreadPoolExecutor(max_workers=min(8, len(topos) + len(mpc_topos) + len(MPC_CLASSES))) as pool:
         futs = {nm: pool.submit(build_library, topo, None, force, verbose) for nm, topo in topos.items()}
         futs.update({nm: pool.submit(build_library, topo, None, force, verbose, (), True) for nm, topo in mpc_topos.items()})
+        futs.update({"mpcclass:" + c: pool.submit(build_mpc_class, c, force, verbose) for c in MPC_CLASSES})
         return {nm: f.result() for nm, f in futs.items()}

@@ -634,6 +634,7 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
 
 int anm_model_bind_state_same(anm_model* m, uint8_t* state_same) {
   if (!m) return fail("anm_model_bind_state_same: null model");
+  if (state_same && (m->view.index || m->view.w_state > 0)) return fail("anm_model_bind_state_same: not while a batch view is bound");
   m->d_state_same = state_same;
   return 0;
 }
@@ -649,6 +650,7 @@ int anm_model_bind_view(anm_model* m, const anm_batch_view* v) {
   if (!m->mesh_ok) return fail("anm_model_bind_view: a view is served by the general lane-group kernel, which cannot take this network");
   if (m->d_env_class) return fail("anm_model_bind_view: not together with parameter classes (anm_model_bind_env_classes)");
   if (m->n_obs > 0) return fail("anm_model_bind_view: a list-form observation is gathered by the thread-per-environment step kernel only");
+  if (m->d_state_same) return fail("anm_model_bind_view: not together with anm_model_bind_state_same (the flags are indexed by launch slot)");
   const mesh::Dims& d = m->mplan.d;
   const int K = m->K;
   struct { int given, own; const char* what; } w[] = {

@@ -67,6 +67,17 @@ struct has_theta_rows : std::true_type {};
 template <class T>
 struct has_theta_rows<T, std::void_t<decltype(T::MPC_NO_THETA)>> : std::false_type {};
 
+// A SIZE CLASS instead of a topology (csrc/anm_mpc_only.hip with a class header, codegen.mpc_class_header): the solver
+// depends on the network through its sizes only -- the topology lives in the tables build_tables computes on the host --
+// so a kernel compiled for (n_load, n_gen, n_des, n_bus, n_branch) upper bounds serves any SMALLER network padded into
+// it: loads with zero coefficients and a zero forecast, generators with the empty range [0, 0] (the solver's "the
+// forecast closes the interval" case), branches with zero coefficients and a huge rating; the number of storage units
+// must match (a padded unit would have no interior).  The actual counts ride in IO::nl / IO::ng.
+template <class T, class = void>
+struct is_padded : std::false_type {};
+template <class T>
+struct is_padded<T, std::void_t<decltype(T::MPC_PADDED)>> : std::true_type {};
+
 template <class T>
 struct Sz {
   static constexpr int NG = T::NGEN, NS = T::NDES, NL = T::NLOAD, NB1 = T::NB - 1, NBR = T::NBR;
@@ -121,24 +132,32 @@ struct Act {
   double* action;             // [E][2 NG + 2 NS] out: [P_gen.., 0.., P_des.., 0..] MW, clipped to [act_lo, act_hi]
   const double* act_lo;       // [2 NG + 2 NS] dev
   const double* act_hi;
+  short load_col[32];         // size classes: column of each load's dev_p in a state row (a topology knows them at compile time)
+  int gen_col0;               // ... and the first column of gen_p_max
 };
 
 // column of the k-th load's dev_p in a state row = its device index (anm_env.py:139-147: dev_p of every device first)
 template <class T>
 constexpr int load_device(int k) {
-  for (int d = 0; d < T::ND; ++d)
-    if (T::DEV_TYPE[d] == DEV_LOAD && T::DEV_SLOT[d] == k) return d;
-  return 0;
+  if constexpr (is_padded<T>::value) {
+    return 0;
+  } else {
+    for (int d = 0; d < T::ND; ++d)
+      if (T::DEV_TYPE[d] == DEV_LOAD && T::DEV_SLOT[d] == k) return d;
+    return 0;
+  }
 }
+// nl: the network's own number of loads (the rows of `series` before the generators')
 template <class T>
-ANM_HD double act_forecast(const Act& a, int64_t env, int stage, bool gen, int k, int col_load) {
+ANM_HD double act_forecast(const Act& a, int64_t env, int stage, bool gen, int k, int col_load, int nl) {
   const double* row = ((a.state_same && a.state_same[env]) ? a.state_alt : a.state) + env * a.state_dim;
   double v;
   if (a.mode == 1) {
-    v = row[gen ? 2 * T::ND + T::NDES + k : col_load];
+    if constexpr (is_padded<T>::value) v = row[gen ? a.gen_col0 + k : int(a.load_col[k])];
+    else v = row[gen ? 2 * T::ND + T::NDES + k : col_load];
   } else {
     const int t0 = (a.aux_index ? int(a.aux_index[env]) : int(row[a.state_dim - 1])) + 1;
-    v = a.series[(gen ? T::NLOAD + k : k) * a.period + (t0 + stage) % a.period];
+    v = a.series[(gen ? nl + k : k) * a.period + (t0 + stage) % a.period];
   }
   return v / a.base;
 }
@@ -158,6 +177,7 @@ struct IO {
                          //   step taken from there) primal and dual step length, centring, mu of the predictor, and the row
                          //   that limits the primal step: stage, row, 0, 0   (may be null)
   Act act;               // mode 0 unless the solve is an act() (then p_load / p_gen are not read)
+  int nl, ng;            // size classes: the network's own numbers of loads / generators (rows of the arrays above: nl, ng, ng + NS wide)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -199,11 +219,25 @@ template <class T>
 inline bool build_tables(const anm_network_desc& d, double gamma, double safety_margin, int N, std::vector<double>& tab,
                          std::string& err, double* theta_bound = nullptr) {
   typedef Sz<T> S;
-  const int nb = T::NB, nd = T::ND;
+  // the network's own sizes: those of T for a topology, at most those of T for a size class (the rest of the tables
+  // stays zero: padded loads / generators / branches change nothing, see is_padded)
+  const int nb = d.n_bus, nd = d.n_dev, nbr = d.n_branch;
+  int n_load = 0, n_gen = 0, n_des = 0;
+  for (int k = 0; k < nd; ++k) {
+    const int ty = d.dev_type[k];
+    n_load += ty == DEV_LOAD;
+    n_gen += ty == DEV_CLASSICAL || ty == DEV_RENEWABLE;
+    n_des += ty == DEV_STORAGE;
+  }
+  if (nb - 1 > S::NB1 || nbr > S::NBR || n_load > S::NL || n_gen > S::NG || n_des != S::NS) {
+    err = "the network does not fit the sizes this MPC kernel was compiled for (its number of storage units must match)";
+    return false;
+  }
+  const int nb1 = nb - 1;
   if (N < 1 || N > 64) { err = "planning_steps must be in [1, 64] (one lane per stage)"; return false; }
   // B = Im(Y_bus) (mpc.py:113), Y as in simulator.py:189-197
   std::vector<double> B(size_t(nb) * nb, 0.0);
-  for (int b = 0; b < T::NBR; ++b) {
+  for (int b = 0; b < nbr; ++b) {
     const int f = d.br_from[b], t = d.br_to[b];
     const std::complex<double> ys(d.br_series[2 * b], d.br_series[2 * b + 1]), sh(d.br_shunt[2 * b], d.br_shunt[2 * b + 1]),
         tap(d.br_tap[2 * b], d.br_tap[2 * b + 1]);
@@ -221,7 +255,7 @@ inline bool build_tables(const anm_network_desc& d, double gamma, double safety_
   }
   const int pin = slack_dev, slack_bus = d.dev_bus[slack_dev];
   std::vector<double> Lap(size_t(nb) * nb, 0.0);
-  for (int b = 0; b < T::NBR; ++b) {  // mpc.py:232-245
+  for (int b = 0; b < nbr; ++b) {  // mpc.py:232-245
     const int f = d.br_from[b], t = d.br_to[b];
     Lap[size_t(f) * nb + f] += B[size_t(f) * nb + t];
     Lap[size_t(f) * nb + t] -= B[size_t(f) * nb + t];
@@ -253,27 +287,33 @@ inline bool build_tables(const anm_network_desc& d, double gamma, double safety_
     }
     for (int k = 0; k < nd; ++k)
       if (d.dev_type[k] == DEV_STORAGE) ctrl[S::NG + is++] = k;
+    for (int g = ig; g < S::NG; ++g) ctrl[g] = -1;   // (padding)
+    for (int l = il; l < S::NL; ++l) loads[l] = -1;
   }
   tab.assign(S::T_TOTAL, 0.0);
-  for (int r = 0; r < S::NB1; ++r) {
+  for (int r = 0; r < nb1; ++r) {
     const int b = keep[r];
-    for (int c = 0; c < S::NC; ++c) tab[S::T_THC + r * S::NC + c] = Th[size_t(b) * nd + ctrl[c]];
-    for (int l = 0; l < S::NL; ++l) tab[S::T_THL + r * S::NL + l] = Th[size_t(b) * nd + loads[l]];
+    for (int c = 0; c < S::NC; ++c)
+      if (ctrl[c] >= 0) tab[S::T_THC + r * S::NC + c] = Th[size_t(b) * nd + ctrl[c]];
+    for (int l = 0; l < n_load; ++l) tab[S::T_THL + r * S::NL + l] = Th[size_t(b) * nd + loads[l]];
   }
   for (int e = 0; e < S::NBR; ++e) {
+    if (e >= nbr) { tab[S::T_LIM + e] = 1e6; continue; }   // a padded branch: no flow, a rating nothing reaches
     const int f = d.br_from[e], t = d.br_to[e];
     const double bft = B[size_t(f) * nb + t];
-    for (int c = 0; c < S::NC; ++c) tab[S::T_PHC + e * S::NC + c] = bft * (Th[size_t(f) * nd + ctrl[c]] - Th[size_t(t) * nd + ctrl[c]]);
-    for (int l = 0; l < S::NL; ++l) tab[S::T_PHL + e * S::NL + l] = bft * (Th[size_t(f) * nd + loads[l]] - Th[size_t(t) * nd + loads[l]]);
+    for (int c = 0; c < S::NC; ++c)
+      if (ctrl[c] >= 0) tab[S::T_PHC + e * S::NC + c] = bft * (Th[size_t(f) * nd + ctrl[c]] - Th[size_t(t) * nd + ctrl[c]]);
+    for (int l = 0; l < n_load; ++l) tab[S::T_PHL + e * S::NL + l] = bft * (Th[size_t(f) * nd + loads[l]] - Th[size_t(t) * nd + loads[l]]);
     tab[S::T_LIM + e] = safety_margin * d.br_rate[e];
   }
   for (int c = 0; c < S::NC; ++c) {
+    if (ctrl[c] < 0) continue;
     double cost = sg[ctrl[c]];
     if (c < S::NG && d.dev_type[ctrl[c]] == DEV_CLASSICAL) cost += 1.0;  // mpc.py:304-306
     tab[S::T_COST + c] = cost;
   }
-  for (int l = 0; l < S::NL; ++l) tab[S::T_SGL + l] = sg[loads[l]];
-  for (int g = 0; g < S::NG; ++g) {
+  for (int l = 0; l < n_load; ++l) tab[S::T_SGL + l] = sg[loads[l]];
+  for (int g = 0; g < n_gen; ++g) {   // (a padded generator keeps the range [0, 0])
     tab[S::T_GPMIN + g] = d.dev_pmin[ctrl[g]];
     tab[S::T_GPMAX + g] = d.dev_pmax[ctrl[g]];
   }
@@ -289,11 +329,11 @@ inline bool build_tables(const anm_network_desc& d, double gamma, double safety_
   if (theta_bound) {
     // the largest |angle| any bus can reach while every device stays inside its limits (loads: [P_min, 0])
     double worst = 0.0;
-    for (int r = 0; r < S::NB1; ++r) {
+    for (int r = 0; r < nb1; ++r) {
       double a = 0.0;
       for (int c = 0; c < S::NC; ++c)
-        a += std::fabs(tab[S::T_THC + r * S::NC + c]) * std::fmax(std::fabs(d.dev_pmin[ctrl[c]]), std::fabs(d.dev_pmax[ctrl[c]]));
-      for (int l = 0; l < S::NL; ++l) a += std::fabs(tab[S::T_THL + r * S::NL + l]) * std::fabs(d.dev_pmin[loads[l]]);
+        if (ctrl[c] >= 0) a += std::fabs(tab[S::T_THC + r * S::NC + c]) * std::fmax(std::fabs(d.dev_pmin[ctrl[c]]), std::fabs(d.dev_pmax[ctrl[c]]));
+      for (int l = 0; l < n_load; ++l) a += std::fabs(tab[S::T_THL + r * S::NL + l]) * std::fabs(d.dev_pmin[loads[l]]);
       worst = std::fmax(worst, a);
     }
     *theta_bound = worst;
@@ -634,10 +674,13 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
   double soc0[pos(NS)];
   {
     double pl[pos(NL)];
+    constexpr bool PAD = is_padded<T>::value;
+    const int nl = PAD ? io.nl : NL, ng = PAD ? io.ng : NG;   // (a topology's kernel: compile-time constants)
     ANM_UFOR (int l = 0; l < NL; ++l)
-      pl[l] = !on ? 0.0 : (io.act.mode ? act_forecast<T>(io.act, env, i, false, l, load_device<T>(l)) : io.p_load[(env * N + i) * NL + l]);
+      pl[l] = (!on || l >= nl) ? 0.0 : (io.act.mode ? act_forecast<T>(io.act, env, i, false, l, load_device<T>(l), nl)
+                                                    : io.p_load[(env * N + i) * nl + l]);
     ANM_UFOR (int g = 0; g < NG; ++g) {
-      const double fc = !on ? 0.0 : (io.act.mode ? act_forecast<T>(io.act, env, i, true, g, 0) : io.p_gen[(env * N + i) * NG + g]);
+      const double fc = (!on || g >= ng) ? 0.0 : (io.act.mode ? act_forecast<T>(io.act, env, i, true, g, 0, nl) : io.p_gen[(env * N + i) * ng + g]);
       ln.wd[g] = fmax(fmin(C[S::T_GPMAX + g], fc) - C[S::T_GPMIN + g], 0.0);
     }
     ANM_UFOR (int j = 0; j < NS; ++j) {  // (a state of charge outside its window -- not a state the simulator produces -- is moved onto it)
@@ -755,12 +798,16 @@ ANM_HD void solve(cptr_t C, const IO& io, const Opts& opt, int64_t env, bool val
         if (io.info) { io.info[env * 3] = mu; io.info[env * 3 + 1] = !startable ? 1.0 : (relaxed_ok ? 0.0 : 2.0); io.info[env * 3 + 2] = rdmax; }
         double u[pos(NC)];
         ln.phys(C, u);
-        ANM_UFOR (int c = 0; c < NC; ++c) io.u0[env * NC + c] = u[c];
+        const int ng = is_padded<T>::value ? io.ng : NG;   // the rows of u0 / action are as wide as the NETWORK's own counts
+        ANM_UFOR (int g = 0; g < NG; ++g)
+          if (g < ng) io.u0[env * (ng + NS) + g] = u[g];
+        ANM_UFOR (int j = 0; j < NS; ++j) io.u0[env * (ng + NS) + ng + j] = u[NG + j];
         if (io.act.mode && io.act.action) {   // [P_gen.., Q_gen.. = 0, P_des.., Q_des.. = 0] MW, clipped (mpc.py:341-344, 383-388)
-          double* a = io.act.action + env * (2 * NG + 2 * NS);
+          double* a = io.act.action + env * (2 * ng + 2 * NS);
           auto clip = [&](int k, double v) { a[k] = fmin(fmax(v, io.act.act_lo[k]), io.act.act_hi[k]); };
-          ANM_UFOR (int g = 0; g < NG; ++g) { clip(g, u[g] * io.act.base); clip(NG + g, 0.0); }
-          ANM_UFOR (int j = 0; j < NS; ++j) { clip(2 * NG + j, u[NG + j] * io.act.base); clip(2 * NG + NS + j, 0.0); }
+          ANM_UFOR (int g = 0; g < NG; ++g)
+            if (g < ng) { clip(g, u[g] * io.act.base); clip(ng + g, 0.0); }
+          ANM_UFOR (int j = 0; j < NS; ++j) { clip(2 * ng + j, u[NG + j] * io.act.base); clip(2 * ng + NS + j, 0.0); }
         }
       }
       if (on && io.solution) {

@@ -39,6 +39,7 @@ struct anm_mpc {
   std::vector<double> tab;
   double theta_bound = 0.0;
   double base_mva = 1.0;
+  int nl = 0, ng = 0, ns = 0, nd = 0;
   bool angle_rows = true;
 };
 
@@ -220,6 +221,7 @@ int anm_mpc_create(const anm_network_desc* desc, double gamma, double safety_mar
     if (!mpc::build_tables<Topo>(*desc, gamma, safety_margin, planning_steps, m->tab, err, &m->theta_bound)) { delete m; g_err = err; return -3; }
     m->N = planning_steps;
     m->base_mva = desc->base_mva;
+    m->nl = Topo::NLOAD; m->ng = Topo::NGEN; m->ns = Topo::NDES; m->nd = Topo::ND;
     m->angle_rows = m->theta_bound >= 0.98 * 3.14159265358979323846;   // (as anm_capi.hip)
     if (m->angle_rows && !mpc::Sz<Topo>::FITS) { delete m; return fail("anm_mpc_create: too many rows per stage with the angle rows"); }
     *out = m;
@@ -272,7 +274,7 @@ static int host_mpc_run(anm_mpc* m, int64_t num_envs, mpc::IO io, const anm_mpc_
 int anm_mpc_solve_f64(anm_mpc* m, int64_t num_envs, const double* p_load_forecast, const double* p_gen_forecast,
                       const double* soc, double* u0, double* objective, int32_t* iters, double* info, double* solution,
                       const anm_mpc_opts* opts, void*) {
-  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, nullptr, mpc::Act{}};
+  mpc::IO io{p_load_forecast, p_gen_forecast, soc, u0, objective, iters, info, solution, nullptr, mpc::Act{}, Topo::NLOAD, Topo::NGEN};
   return host_mpc_run(m, num_envs, io, opts);
 }
 int anm_mpc_act_f64(anm_mpc* m, int64_t num_envs, int32_t forecast, const double* state, const double* state_alt,
@@ -281,8 +283,8 @@ int anm_mpc_act_f64(anm_mpc* m, int64_t num_envs, int32_t forecast, const double
                     double* u0, double* objective, int32_t* iters, double* info, const anm_mpc_opts* opts, void*) {
   if (forecast != ANM_MPC_FORECAST_CONSTANT && forecast != ANM_MPC_FORECAST_PERFECT) return fail("anm_mpc_act_f64: unknown forecast");
   if (forecast == ANM_MPC_FORECAST_PERFECT && (!series || period <= 0)) return fail("anm_mpc_act_f64: a perfect forecast needs the task's periodic tables");
-  mpc::Act a{forecast, state, state_alt, state_same, state_dim, aux_index, series, period, m->base_mva, action, act_low, act_high};
-  mpc::IO io{nullptr, nullptr, soc, u0, objective, iters, info, nullptr, nullptr, a};
+  mpc::Act a{forecast, state, state_alt, state_same, state_dim, aux_index, series, period, m->base_mva, action, act_low, act_high, {0}, 0};
+  mpc::IO io{nullptr, nullptr, soc, u0, objective, iters, info, nullptr, nullptr, a, Topo::NLOAD, Topo::NGEN};
   return host_mpc_run(m, num_envs, io, opts);
 }
 int anm_model_bind_view(anm_model*, const anm_batch_view* v) { return v ? fail("the host test double has no lane-group kernels") : 0; }

@@ -217,7 +217,7 @@ def check_golden(sim, every=1):
     assert n_unique > n_checked // 8, (n_unique, n_checked)  # (a good part of the recorded set-points is unique)
 
 
-def check_random_programs(sim, net, n_cases, seed, horizons=(1, 2, 5, 12, 33)):
+def check_random_programs(sim, net, n_cases, seed, horizons=(1, 2, 5, 12, 33), **solver_kw):
     """random forecasts, horizons, margins, discounts and states of charge (also exactly at the bounds) vs HiGHS"""
     n = O.parse_network(net, 0.25, 100)
     m = sim.model
@@ -225,7 +225,7 @@ def check_random_programs(sim, net, n_cases, seed, horizons=(1, 2, 5, 12, 33)):
     nl, ng, ns = len(m.load_idx), len(m.gen_idx), len(m.des_idx)
     for N in horizons:
         margin, gamma = float(rng.choice([0.8, 0.9, 1.0])), float(rng.choice([0.9, 0.995, 1.0]))
-        solver = BatchedDCOPF(sim, gamma, margin, N)
+        solver = BatchedDCOPF(sim, gamma, margin, N, **solver_kw)
         pl = -rng.uniform(0, 1, (n_cases, nl, N)) * (-m.dev_p_min[m.load_idx])[None, :, None]
         pg = rng.uniform(0, 1, (n_cases, ng, N)) * m.dev_p_max[m.gen_idx][None, :, None] * (rng.random((n_cases, ng, N)) > 0.25)
         lo_, hi_ = m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx]
@@ -513,6 +513,58 @@ def test_mpc_of_a_network_that_steps_in_generic_mode_gpu():
     sim = _gpu_sim(net)
     assert sim.backend.generic and sim.impl == "mesh"
     check_random_programs(sim, net, 6, 3, horizons=(1, 4, 10))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bus,seed,n_chords,cls", [(14, 0, 3, "s1"), (14, 2, 0, "s0"), (16, 6, 3, "s2"), (18, 4, 3, "l1"), (24, 7, 3, "l0"),
+                                                     (24, 2, 0, "l2")])
+def test_mpc_size_classes_without_a_compiler_gpu(monkeypatch, n_bus, seed, n_chords, cls):
+    """`k_mpc` depends on a network through its SIZES only (the topology lives in the tables the host computes): a network
+    that steps in generic mode gets its MPC agent from a precompiled size class it is padded into (extra loads with zero
+    coefficients, generators with an empty range, branches without flow) -- with hipcc hidden.  Random programs on
+    networks nobody compiled anything for, against HiGHS (`agents/mpc.py:163-319` handles any network through cvxpy)."""
+    from gym_anm_amd import _lib, codegen
+
+    monkeypatch.setattr(codegen, "hipcc_path", lambda: None)
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if n_chords else networks.synthetic_radial_network(n_bus, seed)
+    sim = _gpu_sim(net)
+    assert sim.backend.generic
+    solver = BatchedDCOPF(sim, 0.97, 0.93, 3)
+    assert solver.backend.size_class == cls and os.path.basename(solver.backend.path).startswith("libmpc_class_")
+    check_random_programs(sim, net, 5, seed, horizons=(1, 3, 8))
+
+
+@pytest.mark.gpu
+def test_mpc_size_class_equals_the_kernel_of_the_topology_gpu():
+    """ANM6 through the size class `s1` (8 loads, 2 generators, 1 storage unit, 18 buses, 20 branches: 15 padded
+    branches, 5 padded loads) next to the kernel compiled for ANM6: every recorded program of the reference's agents to
+    the tolerance of the golden set, and the fused act() in closed loop."""
+    sim = _gpu_sim(networks.anm6_network())
+    net = networks.anm6_network()
+    check_random_programs(sim, net, 12, 7, horizons=(1, 2, 5, 12), size_class=True)
+    for k, kind, N, margin, gamma, g in _golden_configs():
+        pl, pg, soc, ref = g["c%d_load" % k], g["c%d_gen" % k], g["c%d_soc" % k], g["c%d_objective" % k]
+        own, cls = BatchedDCOPF(sim, gamma, margin, N), BatchedDCOPF(sim, gamma, margin, N, size_class=True)
+        assert cls.backend.size_class == "s1" and own.backend.size_class is None
+        own.solve(pl, pg, soc)
+        cls.solve(pl, pg, soc)
+        obj = cls.objective.cpu().numpy()
+        assert int(cls.iters.max()) < cls.max_iter and bool(cls.converged.all())
+        assert (np.abs(obj - ref) / (1 + np.abs(ref))).max() <= 1e-7, (kind, N)
+        # (the set-points themselves: equal where the minimiser is unique -- check_golden decides that for the topology's
+        # own kernel --, anywhere on the optimal face else: the padded rows move the central path)
+        assert float(((own.objective - cls.objective).abs() / (1 + own.objective.abs())).max()) <= 2e-7
+    env = ANM6EasyVec(num_envs=512, device="cuda:0", seed=11)
+    env.reset(seed=11)
+    ag = MPCAgentPerfect(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=4, size_class=True)
+    assert ag._fused(env) and ag.solver.backend.size_class == "s1"
+    tot = torch.zeros(512, dtype=torch.float64, device=env.device)
+    for _ in range(8):
+        a = ag.act(env)
+        assert bool(ag.last_converged.all()) and env.action_space.contains(a[0].cpu().numpy())
+        _, r, _, _, _ = env.step(a.clone())
+        tot += r
+    assert not bool(env.terminated.any()) and float(tot.mean()) / 8 > -5.0
 
 
 @pytest.mark.gpu
