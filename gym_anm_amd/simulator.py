@@ -456,3 +456,41 @@ class MixedBatchedSimulator:
             sub.backend.check(rc, "anm_transition_f64")
         self.pfe_converged = self._conv_u8.bool()
         return self.full, self.reward, self.e_loss, self.penalty, self.pfe_converged
+
+    def reset(self, init_state):
+        """Batched ``Simulator.reset`` (simulator.py:225-293) over the mixed batch: ``init_state [E, max state width]``, row
+        ``e`` in the layout of environment ``e``'s own network (dev_p, dev_q, des_soc, gen_p_max ...).  One ``transition``
+        for the whole batch between the reference's two SoC assignments.  Returns ``pfe_converged [E]``."""
+        s0 = torch.as_tensor(init_state, dtype=torch.float64, device=self.device)
+        w = self.widths
+        pl = torch.zeros((self.num_envs, max(1, w["load"])), dtype=torch.float64, device=self.device)
+        pp = torch.zeros((self.num_envs, max(1, w["gen"])), dtype=torch.float64, device=self.device)
+        ps = torch.zeros((self.num_envs, max(1, w["setp"])), dtype=torch.float64, device=self.device)
+        qs = torch.zeros_like(ps)
+        soc_req = torch.zeros_like(self.soc)
+        for sub, idx in zip(self.subs, self.env_index):
+            if idx.numel() == 0:
+                continue
+            m = sub.model
+            D, nd, ng = m.N_device, m.N_des, m.N_non_slack_gen
+            rows = s0[idx.long()]
+            P_dev, Q_dev = rows[:, :D], rows[:, D : 2 * D]
+            ix = idx.long()
+            pl[ix, : m.N_load] = P_dev[:, list(m.load_idx)]
+            pp[ix, :ng] = rows[:, 2 * D + nd : 2 * D + nd + ng]
+            ps[ix, : len(m.setp_idx)] = P_dev[:, list(m.setp_idx)]
+            qs[ix, : len(m.setp_idx)] = Q_dev[:, list(m.setp_idx)]
+            if nd:
+                lo = torch.as_tensor(m.dev_soc_min[m.des_idx], dtype=torch.float64, device=self.device)
+                hi = torch.as_tensor(m.dev_soc_max[m.des_idx], dtype=torch.float64, device=self.device)
+                self.soc[ix, :nd] = torch.where(P_dev[:, list(m.des_idx)] <= 0, lo, hi)  # simulator.py:273-278
+                soc_req[ix, :nd] = rows[:, 2 * D : 2 * D + nd] / sub.baseMVA
+        out = self.transition(pl, pp, ps, qs)
+        for sub, idx in zip(self.subs, self.env_index):
+            nd = sub.model.N_des
+            if idx.numel() and nd:
+                ix = idx.long()
+                self.soc[ix, :nd] = soc_req[ix, :nd]  # simulator.py:284-288
+                off = sub.full_offsets["des_soc"]
+                self.full[ix, off : off + nd] = soc_req[ix, :nd]
+        return out[4]

@@ -465,6 +465,28 @@ def test_different_topologies_in_one_batch_against_their_own_oracles():
         npt.assert_allclose(reward[e], ref["reward"], rtol=1e-9, atol=1e-9)
     assert (n_checked >= 100).all() and n_conv >= 400 and n_fail >= 5, (n_checked, n_conv, n_fail)
 
+    # Simulator.reset over the mixed batch (simulator.py:225-293) == BatchedSimulator.reset of every network on its own rows
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    s0 = np.zeros((E_, max(2 * s.model.N_device + s.model.N_des + s.model.N_non_slack_gen for s in sim.subs)))
+    for k, sub in enumerate(sim.subs):
+        m, b = sub.model, sub.model.baseMVA
+        idx = np.nonzero(env_net == k)[0]
+        D, nd, ng = m.N_device, m.N_des, m.N_non_slack_gen
+        s0[idx, :D] = rng.uniform(-1, 1, (idx.size, D)) * np.maximum(np.abs(np.nan_to_num(m.dev_p_min, posinf=1, neginf=-1)), np.abs(np.nan_to_num(m.dev_p_max, posinf=1, neginf=-1))) * b * 0.5
+        s0[idx, D : 2 * D] = rng.uniform(-0.2, 0.2, (idx.size, D)) * b * 0.1
+        s0[idx, 2 * D : 2 * D + nd] = rng.uniform(0.1, 0.9, (idx.size, nd)) * (m.dev_soc_max[m.des_idx] * b)
+        s0[idx, 2 * D + nd : 2 * D + nd + ng] = rng.uniform(0, 1, (idx.size, ng)) * m.dev_p_max[m.gen_idx] * b
+    conv_mixed = sim.reset(s0).cpu().numpy()
+    for k, net in enumerate(nets):
+        idx = np.nonzero(env_net == k)[0][:64]
+        alone = BatchedSimulator(net, 0.25, 100, num_envs=idx.size, device=DEV, tol=1e-8, impl="mesh")
+        S_k = 2 * alone.model.N_device + alone.model.N_des + alone.model.N_non_slack_gen
+        conv_alone = alone.reset(s0[idx, :S_k]).cpu().numpy()
+        npt.assert_array_equal(conv_mixed[idx], conv_alone)
+        assert torch.equal(sim.full[torch.as_tensor(idx, device=DEV)][:, : alone.full_dim], alone.full)
+        assert torch.equal(sim.soc[torch.as_tensor(idx, device=DEV)][:, : alone.model.N_des], alone.soc)
+
 
 @pytest.mark.parametrize("n_bus,seed,n_chords", [(30, 6, 4), (64, 10, 24), (200, 13, 30)])
 def test_mesh_fused_levels_schedule_equals_the_default(monkeypatch, n_bus, seed, n_chords):
