@@ -195,7 +195,8 @@ def load_for_topology(topo, impl=None) -> Backend:
               (fits_group and (impl == "mesh" or (impl is None and topo[0] > 12)))
     if not os.path.exists(path) and generic:
         for cand in sorted(os.listdir(codegen.BUILD_DIR)) if os.path.isdir(codegen.BUILD_DIR) else []:
-            if cand.startswith("libanm_") and cand.endswith(".so") and cand.count(".") == 1:
+            # (kernel-tuning variants, ANM_BUILD_TAG: libanm_<topology>.<tag>.so, only among themselves)
+            if cand.startswith("libanm_") and cand.endswith(codegen._tag() + ".so") and cand.count(".") == 1 + codegen._tag().count("."):
                 gpath = os.path.join(codegen.BUILD_DIR, cand)
                 if not codegen.library_is_fresh(gpath):  # built from other sources / another ABI revision
                     continue

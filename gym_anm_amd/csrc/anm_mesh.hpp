@@ -15,8 +15,10 @@
 //   (order: rounds of pairwise non-adjacent pivots of near-minimal degree; see StepType / OpKind below): in a
 //   step every lane carries out at most one small operation named by its descriptor, operations go to
 //   whatever lanes are free, a fence separates the steps; per level one step of products
-//   M = A_ik D_k^-1 A_kj and one of sums A_ij -= sum M, then one back-substitution step per level (the last
-//   two buses as one dense step).  tests/hostsim/mesh_program_check.cpp executes the schedule on the host.
+//   M = A_ik D_k^-1 A_kj (which subtract the first contribution to a destination themselves) and, where a
+//   destination has several, one of sums; then the back substitution by columns, one step per link of its
+//   longest dependency chain (the last two buses as one dense step).  tests/hostsim/mesh_program_check.cpp
+//   executes the schedule on the host.
 // A workgroup is 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet; a lane
 // group lies within one wavefront, whose LDS operations complete in program order, so the hand-overs between
 // the steps need compiler fences only.  Nothing is compiled per topology: integer tables drive one generic
@@ -44,7 +46,7 @@ using radial::SF_RTERM; using radial::SF_PERIOD; using radial::SF_Y00_RE; using 
 using radial::SF_SLACK_VMIN; using radial::SF_SLACK_VMAX; using radial::SF_COUNT;
 
 enum IField : int { IF_LEVEL = 0, IF_DIAG, IF_INC_BEG, IF_INC_END, IF_BD_BEG, IF_BD_END, IF_INC0, IF_DEG,
-                    IF_DEV_TYPE, IF_DEV_SLOT, IF_DEV_SET,
+                    IF_DEV_TYPE, IF_DEV_SLOT, IF_DEV_SET, IF_XINV,   // IF_XINV: the bus's pivot block was never inverted (see ST_COL)
                     IF_BR_F, IF_BR_T, IF_BR_BLK_FT, IF_BR_BLK_TF, IF_BR_POS_F, IF_BR_POS_T,   // branch l ...
                     IF_BR_FIELDS = IF_BR_POS_T - IF_BR_F + 1,
                     IF_COUNT = IF_BR_F + 2 * IF_BR_FIELDS };                                  // ... and branch G + l
@@ -57,30 +59,33 @@ constexpr int BR_SLOTS = 2;
 // wherever one is free (no lane "owns" a row), so a level of the elimination costs a fixed, short sequence of
 // instructions whatever the sparsity pattern, instead of a per-lane loop over task lists.
 // The right-hand side rides along as one more block column: r_i is kept as the block (r0, 0; r1, 0).
-//   step ST_PROD  OP_PROD (i, k, j)    s1 = D_k, s2 = A_ik, s3 = A_kj (or r_k), s4 = where the product
-//                                      M = A_ik D_k^-1 A_kj goes; s5 != 0: also leave D_k^-1 at s5
-//   step ST_SUM   OP_SUM  (i, j)       s1 = A_ij (or r_i) -= the products at s2, s3, s4, s5 in this order (the step
-//                                      says how many of them any of its lanes needs; an unused one is the zero block)
-//   step ST_BACK  OP_BACK (pivot k)    s1 = r_k, s2 = D_k^-1, s3 = x_k, (s4, s5), (s6, s7) = (A_kj, x_j) of two later buses
-//                 OP_INVBACK           the same for a bus nothing was eliminated into: s2 = D_k itself
-//   step ST_ACC   OP_ACC  (pivot k)    s1 = r_k (-= A_kj x_j for (s2, s3), (s4, s5), (s6, s7)): buses with more than two
+//   step ST_PROD  OP_PROD (i, k, j)    s1 = D_k, s2 = A_ik, s3 = A_kj (or r_k), s6 = Z, s4 = where Z - A_ik D_k^-1 A_kj
+//                                      goes; s5 != 0: also leave D_k^-1 at s5.  Z = s4 = A_ij (r_i) for the FIRST
+//                                      contribution to a destination: the product operation subtracts it itself (a
+//                                      destination is no operand of its own level).  Z = the zero block for the
+//                                      others: the NEGATED product is parked for the sums
+//   step ST_SUM   OP_SUM  (i, j)       s1 = A_ij (or r_i) += the parked products at s2, s3, s4, s5 in this order (the step
+//                                      says how many of them any of its lanes needs; an unused one is the zero block).
+//                                      A level whose destinations all have one contribution has no such step
 //   step ST_TAIL  OP_TAIL2 (a, b)      the last two buses of the order when each is alone in its level: ONE lane
-//                                      eliminates a into b and solves both -- one step instead of the four
-//                                      (products, sums, two back substitutions) the last two levels would take.
-//                                      s1 = D_a, s2 = A_ab, s3 = A_ba, s4 = D_b, s5 = r_a, s6 = r_b (x_a, x_b: where
-//                                      the r's index says)
-//   step ST_FUSE  OP_FUSE1 (i, j; k)   s1 = A_ij (or r_i) -= A_ik D_k^-1 A_kj with s2 = D_k, s3 = A_ik, s4 = A_kj (or r_k):
-//                 OP_FUSE2 (.; k, k')  product and subtraction by ONE lane in ONE step (round 3, experimental: a level is one step instead
-//                                      of a products step + a sums step; nothing is parked in LDS in between); FUSE2: a
-//                                      second contribution (s5, s6, s7), subtracted after the first.  A destination
-//                                      with more than two contributions takes further steps (same order).  With fused
-//                                      levels the inverted pivots are not stored: the back substitution inverts D_k
-//                                      itself (OP_INVBACK), D_k being intact.
-// s0 = the operation (0: the lane idles in this step).  Nothing a step reads is written in the same step, and
-// D_k, A_ik, A_kj stay as they are (the factor L_ik = A_ik D_k^-1 is never stored: every product recomputes it,
-// lanes are plentiful), so the operations of a level may be dealt to the lanes in any number of rounds.
-enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_BACK, OP_INVBACK, OP_ACC, OP_TAIL2, OP_FUSE1, OP_FUSE2 };
-enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_BACK = 2, ST_ACC = 3, ST_TAIL = 4, ST_FUSE = 5 };
+//                                      eliminates a into b and prepares both -- one step instead of the three
+//                                      (products, sums, the column of b) the last two levels would take.
+//                                      s1 = D_a, s2 = A_ab, s3 = A_ba, s4 = D_b, s5 = r_a, s6 = r_b; it leaves
+//                                      r_b, D_b^-1, r_a - A_ab x_b, D_a^-1 (the inverses where the r's index says)
+//   step ST_COL   OP_COL  (i; k, k')   back substitution by columns: s1 = r_i -= A_ik x_k + A_ik' x_k' with
+//                                      (s2, s3, s4) = (A_ik, r_k, D_k^-1) and (s5, s6, s7) the same for k' (or three
+//                                      zero blocks), x_k = D_k^-1 r_k formed by the operation itself: r_k is final
+//                                      once every later bus has left it, nobody stores x.  | OP_COL_INV1 / _INV2: the
+//                                      bus k / k' had nothing eliminated into it, s4 / s7 is D_k itself.  When the
+//                                      program ends every bus lane forms its own x_i = D_i^-1 r_i (IF_XINV: from D_i)
+// s0 = the operation (0: the lane idles in this step).  Nothing a step reads is written in the same step by ANOTHER
+// lane, and D_k, A_ik, A_kj stay as they are (the factor L_ik = A_ik D_k^-1 is never stored: every product recomputes
+// it, lanes are plentiful), so the operations of a level may be dealt to the lanes in any number of rounds.
+// (Rounds 2-4: the back substitution went row-wise -- x_k stored, up to four steps per level; products and sums were
+// two steps on every level; "fused levels", every contribution subtracted by its product operation two at a time, were
+// tried in round 3 and lost what they won to the longer steps: profiles/r03_n_mesh_fused_levels.txt.)
+enum OpKind : int { OP_NONE = 0, OP_PROD, OP_SUM, OP_TAIL2, OP_COL = 8, OP_COL_INV1 = 1, OP_COL_INV2 = 2 };   // OP_COL | INV bits: 8 ... 11
+enum StepType : int { ST_PROD = 0, ST_SUM = 1, ST_TAIL = 2, ST_COL = 3 };
 enum DField : int { DF_YII_RE = 0, DF_YII_IM, DF_VMIN, DF_VMAX, DF_YFT_RE, DF_YFT_IM, DF_YTF_RE, DF_YTF_IM, DF_BRC,
                     DF_BR_FIELDS = DF_BRC + 9 - DF_YFT_RE, DF_COUNT = DF_YFT_RE + 2 * DF_BR_FIELDS };
 
@@ -246,21 +251,14 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   d.n_levels = 0;
   for (int i = 1; i < NB; ++i) d.n_levels = std::max(d.n_levels, level[i] + 1);
 
-  // ---- LDS layout of one environment (doubles).  Two pairs of areas are never alive together and share their
-  // place: the branch products W (written and summed before the step program starts) with the products of the
-  // elimination, and V (read by the branch lanes at the start of a trip) with the Newton step x (written by the
-  // back substitution, read by the update at the end of the trip)
-  // ANM_MESH_FUSED_LEVELS: product and subtraction of a level in one step (ST_FUSE).  Fewer steps (mesh30 12 -> 10,
-  // case30 11 -> 8, a 64-bus network 59 -> 46), no products parked in LDS, and no faster: a step's time is the
-  // dependent fp64 chain of its 2x2 block operations (inverse, two products), which the fused step strings together
-  // (profiles/r03_n_mesh_fused_levels.txt, r03_o_large_fused_levels.txt: within +-5 % everywhere).  Off by default.
-  const bool fuse = getenv("ANM_MESH_FUSED_LEVELS") != nullptr;
+  // ---- LDS layout of one environment (doubles).  The branch products W (written and summed before the step
+  // program starts) and the parked products of the elimination are never alive together and share their place
   d.l_v = 0;
-  d.l_x = d.l_v;                         // x[NB][2] / vr[NB], vi[NB]
+  d.l_x = d.l_v;                         // vr[NB], vi[NB]
   d.l_blk = d.l_v + 2 * NB;
   d.l_r = d.l_blk + 4 * d.NBLK;          // r[NB] as blocks (r0, 0; r1, 0)
-  d.l_dinv = d.l_r + 4 * NB;             // inverted pivots [NB][4] (split levels only)
-  d.l_zero = d.l_dinv + (fuse ? 0 : 4 * NB);   // 6 zeros nobody writes: what an unused operand slot of a descriptor reads
+  d.l_dinv = d.l_r + 4 * NB;             // inverted pivots [NB][4]
+  d.l_zero = d.l_dinv + 4 * NB;          // 6 zeros nobody writes: what an unused operand slot of a descriptor reads
   d.l_bw = d.l_zero + 6;                 // W entries [2 NBR][2] / I = Y V terms [4][NBR] ...
   d.l_m = d.l_bw;                        // ... / products [n_m][4]
 
@@ -324,7 +322,7 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   std::vector<std::vector<Desc>> steps;          // [step][lane]; a product slot m is written -(m + 1) until the layout is known
   const Desc none = {0, 0, 0, 0, 0, 0, 0, 0};
   auto new_step = [&](int ty) { stype.push_back(ty); steps.push_back(std::vector<Desc>()); return int(steps.size()) - 1; };
-  const int oB = d.l_blk, oR = d.l_r, oX = d.l_x, oDI = d.l_dinv, oZ = d.l_zero;
+  const int oB = d.l_blk, oR = d.l_r, oDI = d.l_dinv, oZ = d.l_zero;
   std::vector<std::vector<int>> piv(d.n_levels);
   for (int k : order) piv[level[k]].push_back(k);
   int n_m = 0;
@@ -350,61 +348,37 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
           contrib[dst_of[i][j]].push_back(Contribution{i, k, j});
         }
     if (dsts.empty()) continue;
-    if (fuse) {
-      // fused levels: a destination's contributions two at a time, in pivot order
-      size_t n_r = 0;
-      for (const auto& c : contrib) n_r = std::max(n_r, (c.size() + 1) / 2);
-      for (size_t r = 0; r < n_r; ++r) {
-        std::vector<Desc> ops;
-        for (size_t q = 0; q < dsts.size(); ++q) {
-          const auto& c = contrib[q];
-          if (c.size() <= 2 * r) continue;
-          const int dst = dsts[q].second == NB ? oR + 4 * dsts[q].first : oB + 4 * blk[dsts[q].first][dsts[q].second];
-          Desc op = {OP_FUSE1, dst, 0, 0, 0, 0, 0, 0};
-          for (size_t u = 2 * r; u < std::min(c.size(), 2 * r + 2); ++u) {
-            const Contribution& x = c[u];
-            const int o = 2 + 3 * int(u - 2 * r);
-            op[o] = oB + 4 * blk[x.k][x.k];
-            op[o + 1] = oB + 4 * blk[x.i][x.k];
-            op[o + 2] = x.j == NB ? oR + 4 * x.k : oB + 4 * blk[x.k][x.j];
-            if (u > 2 * r) op[0] = OP_FUSE2;
-          }
-          ops.push_back(op);
-        }
-        for (size_t q = 0; q < ops.size(); q += G) {
-          int run = 1;
-          for (size_t u = q; u < std::min(ops.size(), q + G); ++u) run = std::max(run, ops[u][0] == OP_FUSE2 ? 2 : 1);
-          const int st = new_step(ST_FUSE | (run << 8));
-          for (size_t u = q; u < std::min(ops.size(), q + G); ++u) steps[st].push_back(ops[u]);
-        }
-      }
-      continue;
-    }
-    // summation rounds: up to four products per destination and round (an unused operand is the zero block);
-    // the products of a level are all alive at once, the next level reuses their places
+    // The FIRST contribution of a destination is subtracted by the product operation itself (the destination is no
+    // operand of its level: neither of its indices is a pivot of the level); the others are parked, NEGATED, and added
+    // by summation rounds of up to four per destination (an unused operand is the zero block), in contribution order:
+    // ((Z - M0) + (-M1)) + (-M2) ... -- a level whose destinations all have one contribution (one pivot: the dense end
+    // of the order) is ONE step.  The parked products of a level are all alive at once, the next level reuses their places.
     size_t n_rounds = 0;
-    for (const auto& c : contrib) n_rounds = std::max(n_rounds, (c.size() + 3) / 4);
+    for (const auto& c : contrib) n_rounds = std::max(n_rounds, (c.size() - 1 + 3) / 4);
     std::vector<Desc> prods;
     std::vector<std::vector<Desc>> sums(n_rounds);
     std::vector<char> dinv_done(NB, 0);
     int m_lv = 0;
-    for (size_t r = 0; r < n_rounds; ++r)
-      for (size_t q = 0; q < dsts.size(); ++q) {
-        const auto& c = contrib[q];
-        if (c.size() <= 4 * r) continue;
-        const int dst = dsts[q].second == NB ? oR + 4 * dsts[q].first : oB + 4 * blk[dsts[q].first][dsts[q].second];
-        Desc sum = {OP_SUM, dst, oZ, oZ, oZ, oZ, int(std::min<size_t>(4, c.size() - 4 * r)), 0};
-        for (size_t u = 4 * r; u < std::min(c.size(), 4 * r + 4); ++u) {
-          const Contribution& x = c[u];
-          const int src = x.j == NB ? oR + 4 * x.k : oB + 4 * blk[x.k][x.j];
+    auto product = [&](const Contribution& x, int where, int z) {
+      const int src = x.j == NB ? oR + 4 * x.k : oB + 4 * blk[x.k][x.j];
+      prods.push_back(Desc{OP_PROD, oB + 4 * blk[x.k][x.k], oB + 4 * blk[x.i][x.k], src, where,
+                           dinv_done[x.k] ? 0 : oDI + 4 * x.k, z, 0});
+      dinv_done[x.k] = 1;
+    };
+    for (size_t q = 0; q < dsts.size(); ++q) {
+      const auto& c = contrib[q];
+      const int dst = dsts[q].second == NB ? oR + 4 * dsts[q].first : oB + 4 * blk[dsts[q].first][dsts[q].second];
+      product(c[0], dst, dst);
+      for (size_t r = 0; 1 + 4 * r < c.size(); ++r) {
+        Desc sum = {OP_SUM, dst, oZ, oZ, oZ, oZ, int(std::min<size_t>(4, c.size() - 1 - 4 * r)), 0};
+        for (size_t u = 1 + 4 * r; u < std::min(c.size(), 1 + 4 * r + 4); ++u) {
           const int m = m_lv++;
-          sum[2 + (u - 4 * r)] = -(m + 1);
-          prods.push_back(Desc{OP_PROD, oB + 4 * blk[x.k][x.k], oB + 4 * blk[x.i][x.k], src, -(m + 1),
-                               dinv_done[x.k] ? 0 : oDI + 4 * x.k, 0, 0});
-          dinv_done[x.k] = 1;
+          sum[2 + (u - 1 - 4 * r)] = -(m + 1);
+          product(c[u], -(m + 1), oZ);
         }
         sums[r].push_back(sum);
       }
+    }
     n_m = std::max(n_m, m_lv);
     for (size_t q = 0; q < prods.size(); q += G) {
       const int st = new_step(ST_PROD);
@@ -423,30 +397,53 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     steps[st].push_back(Desc{OP_TAIL2, oB + 4 * blk[tail_a][tail_a], oB + 4 * blk[tail_a][tail_b], oB + 4 * blk[tail_b][tail_a],
                              oB + 4 * blk[tail_b][tail_b], oR + 4 * tail_a, oR + 4 * tail_b, 0});
   }
-  for (int lv = d.n_levels - 1 - (tail_a >= 0 ? 2 : 0); lv >= 0; --lv) {
-    // x_k = D_k^-1 (r_k - sum over the later buses j of A_kj x_j): two terms ride with the final operation, the
-    // others are subtracted from r_k first, three per step, in the order of upper[k]
-    size_t max_acc = 0;
-    for (int k : piv[lv]) max_acc = std::max(max_acc, upper[k].size() > 2 ? (upper[k].size() - 2 + 2) / 3 : size_t(0));
-    std::vector<int> acc(max_acc);
-    for (size_t a = 0; a < max_acc; ++a) acc[a] = new_step(ST_ACC);
-    const int fin = new_step(ST_BACK);
-    if (int(piv[lv].size()) > G) { err = "internal: more pivots in a level than lanes"; return false; }
-    for (int k : piv[lv]) {
-      const std::vector<int>& up = upper[k];
-      const size_t n_acc = up.size() > 2 ? (up.size() - 2 + 2) / 3 : 0;
-      size_t u = 0;
-      for (size_t a = 0; a < n_acc; ++a) {
-        Desc dsc = {OP_ACC, oR + 4 * k, oZ, oZ + 4, oZ, oZ + 4, oZ, oZ + 4};
-        for (int c = 0; c < 3 && up.size() - u > 2; ++c, ++u) { dsc[2 + 2 * c] = oB + 4 * blk[k][up[u]]; dsc[3 + 2 * c] = oX + 2 * up[u]; }
-        steps[acc[max_acc - n_acc + a]].push_back(dsc);
-      }
-      Desc dsc = {OP_BACK, oR + 4 * k, oDI + 4 * k, oX + 2 * k, oZ, oZ + 4, oZ, oZ + 4};
-      if (up.empty() || fuse) { dsc[0] = OP_INVBACK; dsc[2] = oB + 4 * blk[k][k]; }
-      for (int c = 0; u < up.size(); ++c, ++u) { dsc[4 + 2 * c] = oB + 4 * blk[k][up[u]]; dsc[5 + 2 * c] = oX + 2 * up[u]; }
-      steps[fin].push_back(dsc);
-    }
+  // ---- back substitution, by COLUMNS: x_k = D_k^-1 r_k is known ("ready") once every later bus j of upper[k] has
+  // taken A_kj x_j out of r_k.  A step gives every row i with ready buses among its pending ones one operation
+  // r_i -= A_ik x_k + A_ik' x_k' (two of them, in the order of upper[i]); the operation forms x_k from (r_k, D_k^-1)
+  // itself -- nobody stores x, and a bus is ready the step after its last term went.  The steps follow the
+  // dependencies, not the levels: a dense end of the order costs one step per bus (the row-wise form took up to four),
+  // and whatever is ready goes together.  What is left when the program ends is x_i = D_i^-1 r_i for every bus: each
+  // bus lane forms its own (k_mesh, the update).  D^-1 was stored when the bus was eliminated (or by the tail
+  // step); a bus nothing was eliminated into still has D itself: the operation inverts it (OP_COL_INV1 / _INV2 bits).
+  std::vector<std::vector<int>> pend(NB);
+  std::vector<char> ready(NB, 0), self_inv(NB, 0);
+  for (int k = 1; k < NB; ++k) {
+    pend[k] = upper[k];
+    self_inv[k] = upper[k].empty() && k != tail_b;
   }
+  if (tail_a >= 0) pend[tail_a].clear();             // (the tail step takes A_ab x_b out of r_a)
+  for (int k = 1; k < NB; ++k) ready[k] = pend[k].empty();
+  for (;;) {
+    std::vector<Desc> ops;
+    std::vector<int> newly;
+    for (int i = 1; i < NB; ++i) {
+      if (pend[i].empty()) continue;
+      Desc op = {OP_COL, oR + 4 * i, oZ, oZ, oZ, oZ, oZ, oZ};
+      int n_take = 0;
+      for (size_t u = 0; u < pend[i].size() && n_take < 2;) {
+        const int k = pend[i][u];
+        if (!ready[k]) { ++u; continue; }
+        op[2 + 3 * n_take] = oB + 4 * blk[i][k];
+        op[3 + 3 * n_take] = oR + 4 * k;
+        op[4 + 3 * n_take] = self_inv[k] ? oB + 4 * blk[k][k] : oDI + 4 * k;
+        if (self_inv[k]) op[0] |= (n_take == 0 ? OP_COL_INV1 : OP_COL_INV2);
+        ++n_take;
+        pend[i].erase(pend[i].begin() + u);
+      }
+      if (n_take == 0) continue;
+      ops.push_back(op);
+      if (pend[i].empty()) newly.push_back(i);
+    }
+    if (ops.empty()) break;
+    for (size_t q = 0; q < ops.size(); q += G) {
+      const int st = new_step(ST_COL);
+      for (size_t u = q; u < std::min(ops.size(), q + G); ++u) steps[st].push_back(ops[u]);
+    }
+    for (int i : newly) ready[i] = 1;
+  }
+  for (int k = 1; k < NB; ++k)
+    if (!pend[k].empty()) { err = "internal: back substitution left terms behind"; return false; }
+  for (int l = 0; l + 1 < NB; ++l) I(IF_XINV, l) = self_inv[l + 1];
   d.n_m = n_m;
   d.l_dev = d.l_m + std::max(4 * n_m, 4 * d.NBR);
   // 16-byte aligned (blocks and vector pairs move as ds_read_b128 / ds_write_b128), and = 2 (mod 4) doubles: the
@@ -597,6 +594,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   int br_f[BR_SLOTS], br_t[BR_SLOTS], blk_ft[BR_SLOTS], blk_tf[BR_SLOTS], pos_f[BR_SLOTS], pos_t[BR_SLOTS];
   const int bus = l + 1;
   const int level = RI(IF_LEVEL), diag = RI(IF_DIAG);
+  const bool xinv = RI(IF_XINV) != 0;
   const int inc_beg = RI(IF_INC_BEG), inc_end = RI(IF_INC_END);
   const int inc0 = RI(IF_INC0), deg = RI(IF_DEG);
 #pragma unroll
@@ -733,7 +731,6 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   double* LBW = S + d.l_bw;     // wft_r, wft_i, wtf_r, wtf_i [NBR] each
   double* LBLK = S + d.l_blk;   // [NBLK][4]
   double* LR = S + d.l_r;       // r[NB] as blocks (r0, 0; r1, 0)
-  double* LX = S + d.l_x;       // x[NB][2]
   const int NB = d.NB, NBR = d.NBR;
   const double yii_r = RD(DF_YII_RE), yii_i = RD(DF_YII_IM);
   double yft_r[BR_SLOTS], yft_i[BR_SLOTS], ytf_r[BR_SLOTS], ytf_i[BR_SLOTS];
@@ -770,6 +767,9 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     st2(o, double(m.a), double(m.b));
     st2(o + 2, double(m.c), double(m.d));
   };
+  // a right-hand side r_i = the first column of its block (r0, 0; r1, 0)
+  auto ldr = [&](int o) { return double2{S[o], S[o + 2]}; };
+  auto str = [&](int o, double a, double b) { S[o] = a; S[o + 2] = b; };
   // the step program (see OpKind): descriptor and type of the next step are fetched while this one runs
   const int4* prog = reinterpret_cast<const int4*>(tab + (d.off_desc - d.off_lists));
   const int* stype = tab + (d.off_stype - d.off_lists);
@@ -781,6 +781,16 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     o[4] = q.z & 0xffff; o[5] = int(unsigned(q.z) >> 16); o[6] = q.w & 0xffff; o[7] = int(unsigned(q.w) >> 16);
   };
   unpack(nxt, un);
+#if defined(ANM_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  // tuning builds: cycles per part of the Newton trip, summed over the trips of a wavefront
+  // (scripts/mesh_trip_times.py): 0 publish V + branch products, 1 bus sums + stop test + diagonal, 2 product steps,
+  // 3 sum steps, 4 the tail step, 5 back substitution, 6 update, 7 number of trips
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph_t = __builtin_readcyclecounter();
+#define ANM_MESH_ACC(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define ANM_MESH_ACC(k) do { } while (0)
+#endif
   for (;;) {
     vr = vm * cs;
     vi = vm * sn;
@@ -803,6 +813,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       }
     for (int k = l; k < d.n_fill; k += G) put_blk(fills[k], 0.0, 0.0, 0.0, 0.0);
     ANM_MESH_SYNC();
+    ANM_MESH_ACC(0);
     // ---- bus lanes: S_i = W_ii + sum over the incident branches, mismatch, diagonal block
     const double m2 = vm * vm;
     const double wii_r = yii_r * m2, wii_i = -(yii_i * m2);
@@ -845,6 +856,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       LR[4 * bus] = double(JT(fr)); LR[4 * bus + 2] = double(JT(fi));
     }
     ANM_MESH_SYNC();
+    ANM_MESH_ACC(1);
     // ---- elimination and back substitution: the step program
     for (int sidx = 0; sidx < d.n_steps; ++sidx) {
       // the operands of this step were unpacked while the previous step's stores drained (below); the descriptor of
@@ -858,91 +870,81 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
         if (kind != OP_NONE) {
           const Blk<JT> Di = blk_inv(ld4(o1));
           const Blk<JT> Lik = blk_mul(ld4(o2), Di);
-          st4(o4, blk_mul(Lik, ld4(o3)));
+          Blk<JT> Z = ld4(o6);                        // the destination itself (first contribution) or the zero block
+          const Blk<JT> M = blk_mul(Lik, ld4(o3));
+          Z.a -= M.a; Z.b -= M.b; Z.c -= M.c; Z.d -= M.d;
+          st4(o4, Z);
           if (o5 != 0) st4(o5, Di);
         }
       } else if ((ty & 0xff) == ST_SUM) {
         if (kind != OP_NONE) {
           Blk<JT> Z = ld4(o1);
           const Blk<JT> M0 = ld4(o2);
-          Z.a -= M0.a; Z.b -= M0.b; Z.c -= M0.c; Z.d -= M0.d;
+          Z.a += M0.a; Z.b += M0.b; Z.c += M0.c; Z.d += M0.d;
           if ((ty >> 8) > 1) {
             const Blk<JT> M1 = ld4(o3);
-            Z.a -= M1.a; Z.b -= M1.b; Z.c -= M1.c; Z.d -= M1.d;
+            Z.a += M1.a; Z.b += M1.b; Z.c += M1.c; Z.d += M1.d;
           }
           if ((ty >> 8) > 2) {
             const Blk<JT> M2 = ld4(o4), M3 = ld4(o5);
-            Z.a -= M2.a; Z.b -= M2.b; Z.c -= M2.c; Z.d -= M2.d;
-            Z.a -= M3.a; Z.b -= M3.b; Z.c -= M3.c; Z.d -= M3.d;
-          }
-          st4(o1, Z);
-        }
-      } else if ((ty & 0xff) == ST_FUSE) {
-        if (kind != OP_NONE) {
-          Blk<JT> Z = ld4(o1);
-          {
-            const Blk<JT> M = blk_mul(blk_mul(ld4(o3), blk_inv(ld4(o2))), ld4(o4));
-            Z.a -= M.a; Z.b -= M.b; Z.c -= M.c; Z.d -= M.d;
-          }
-          if ((ty >> 8) > 1) {
-            if (kind == OP_FUSE2) {
-              const Blk<JT> M = blk_mul(blk_mul(ld4(o6), blk_inv(ld4(o5))), ld4(o7));
-              Z.a -= M.a; Z.b -= M.b; Z.c -= M.c; Z.d -= M.d;
-            }
+            Z.a += M2.a; Z.b += M2.b; Z.c += M2.c; Z.d += M2.d;
+            Z.a += M3.a; Z.b += M3.b; Z.c += M3.c; Z.d += M3.d;
           }
           st4(o1, Z);
         }
       } else if ((ty & 0xff) == ST_TAIL) {
         if (kind != OP_NONE) {
-          const Blk<JT> Dai = blk_inv(ld4(o1)), Aab = ld4(o2), Ra = ld4(o5), Rb = ld4(o6);
+          const Blk<JT> Dai = blk_inv(ld4(o1)), Aab = ld4(o2);
+          const double2 ra = ldr(o5), rb = ldr(o6);
           const Blk<JT> L = blk_mul(ld4(o3), Dai);
           Blk<JT> Db = ld4(o4);
           blk_submul(Db, L, Aab);
-          const JT rb0 = fm(-L.b, Ra.c, fm(-L.a, Ra.a, Rb.a)), rb1 = fm(-L.d, Ra.c, fm(-L.c, Ra.a, Rb.c));
+          const JT ra0 = JT(ra.x), ra1 = JT(ra.y);
+          const JT rb0 = fm(-L.b, ra1, fm(-L.a, ra0, JT(rb.x))), rb1 = fm(-L.d, ra1, fm(-L.c, ra0, JT(rb.y)));
           const Blk<JT> Dbi = blk_inv(Db);
           const JT xb0 = fm(Dbi.a, rb0, Dbi.b * rb1), xb1 = fm(Dbi.c, rb0, Dbi.d * rb1);
-          const JT a0 = fm(-Aab.b, xb1, fm(-Aab.a, xb0, Ra.a)), a1 = fm(-Aab.d, xb1, fm(-Aab.c, xb0, Ra.c));
-          st2(d.l_x + ((o6 - d.l_r) >> 1), double(xb0), double(xb1));
-          st2(d.l_x + ((o5 - d.l_r) >> 1), double(fm(Dai.a, a0, Dai.b * a1)), double(fm(Dai.c, a0, Dai.d * a1)));
-        }
-      } else if ((ty & 0xff) == ST_BACK) {
-        if (kind != OP_NONE) {
-          const Blk<JT> Rk = ld4(o1);
-          JT a0 = Rk.a, a1 = Rk.c;
-          Blk<JT> Di = ld4(o2);
-          const Blk<JT> A0 = ld4(o4), A1 = ld4(o6);
-          const double2 xa = ld2(o5), xb = ld2(o7);
-          const JT x00 = JT(xa.x), x01 = JT(xa.y), x10 = JT(xb.x), x11 = JT(xb.y);
-          if (kind == OP_INVBACK) Di = blk_inv(Di);
-          a0 = fm(-A0.b, x01, fm(-A0.a, x00, a0));
-          a1 = fm(-A0.d, x01, fm(-A0.c, x00, a1));
-          a0 = fm(-A1.b, x11, fm(-A1.a, x10, a0));
-          a1 = fm(-A1.d, x11, fm(-A1.c, x10, a1));
-          st2(o3, double(fm(Di.a, a0, Di.b * a1)), double(fm(Di.c, a0, Di.d * a1)));
+          const JT a0 = fm(-Aab.b, xb1, fm(-Aab.a, xb0, ra0)), a1 = fm(-Aab.d, xb1, fm(-Aab.c, xb0, ra1));
+          str(o6, double(rb0), double(rb1));
+          st4(o6 - d.l_r + d.l_dinv, Dbi);
+          str(o5, double(a0), double(a1));
+          st4(o5 - d.l_r + d.l_dinv, Dai);
         }
       } else {
         if (kind != OP_NONE) {
-          const Blk<JT> Rk = ld4(o1);
-          JT a0 = Rk.a, a1 = Rk.c;
-          const Blk<JT> A0 = ld4(o2), A1 = ld4(o4), A2 = ld4(o6);
-          const double2 xa = ld2(o3), xb = ld2(o5), xc = ld2(o7);
-          const JT x00 = JT(xa.x), x01 = JT(xa.y), x10 = JT(xb.x), x11 = JT(xb.y), x20 = JT(xc.x), x21 = JT(xc.y);
+          const double2 ri = ldr(o1), rk0 = ldr(o3), rk1 = ldr(o6);
+          const Blk<JT> A0 = ld4(o2), A1 = ld4(o5);
+          Blk<JT> D0 = ld4(o4), D1 = ld4(o7);
+          if (kind & OP_COL_INV1) D0 = blk_inv(D0);
+          if (kind & OP_COL_INV2) D1 = blk_inv(D1);
+          const JT x00 = fm(D0.a, JT(rk0.x), D0.b * JT(rk0.y)), x01 = fm(D0.c, JT(rk0.x), D0.d * JT(rk0.y));
+          const JT x10 = fm(D1.a, JT(rk1.x), D1.b * JT(rk1.y)), x11 = fm(D1.c, JT(rk1.x), D1.d * JT(rk1.y));
+          JT a0 = JT(ri.x), a1 = JT(ri.y);
           a0 = fm(-A0.b, x01, fm(-A0.a, x00, a0));
           a1 = fm(-A0.d, x01, fm(-A0.c, x00, a1));
           a0 = fm(-A1.b, x11, fm(-A1.a, x10, a0));
           a1 = fm(-A1.d, x11, fm(-A1.c, x10, a1));
-          a0 = fm(-A2.b, x21, fm(-A2.a, x20, a0));
-          a1 = fm(-A2.d, x21, fm(-A2.c, x20, a1));
-          st4(o1, Blk<JT>{a0, Rk.b, a1, Rk.d});
+          str(o1, double(a0), double(a1));
         }
       }
       unpack(nxt, un);   // (before the fence: in the shadow of this step's stores)
       ANM_MESH_SYNC();
+#if defined(ANM_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+      if ((ty & 0xff) == ST_PROD) ANM_MESH_ACC(2);
+      else if ((ty & 0xff) == ST_SUM) ANM_MESH_ACC(3);
+      else if ((ty & 0xff) == ST_TAIL) ANM_MESH_ACC(4);
+      else ANM_MESH_ACC(5);
+#endif
     }
     // ---- update (group-uniform `active`); d1 is the relative magnitude step
+    // x_i = D_i^-1 r_i: what the program leaves is every bus's final r and (unless nothing was eliminated into it) D^-1
     double dth = 0.0, d1 = 0.0;
-    if (active && isbus) { dth = LX[2 * bus]; d1 = LX[2 * bus + 1]; }
-    if constexpr (WG) __syncthreads();   // x and V share their place: every wavefront has read x before V is published
+    if (active && isbus) {
+      const double2 rr = ldr(d.l_r + 4 * bus);
+      Blk<JT> Di = ld4(xinv ? d.l_blk + 4 * diag : d.l_dinv + 4 * bus);
+      if (xinv) Di = blk_inv(Di);
+      dth = double(fm(Di.a, JT(rr.x), Di.b * JT(rr.y)));
+      d1 = double(fm(Di.c, JT(rr.x), Di.d * JT(rr.y)));
+    }
     if (active && isbus) {
       vm = fma(-d1, fabs(vm), vm);
       double sd_, cd_;
@@ -959,7 +961,18 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       sn = fma(s0v, cd_, -(c0 * sd_));
     }
     it = active ? it + 1 : it;
+#if defined(ANM_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    ANM_MESH_ACC(6);
+    ph_acc[7] += 1;
+#endif
   }
+#if defined(ANM_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  {
+    const int slot_w = WG ? int(blockIdx.x) : int(blockIdx.x) * n_waves + wave;   // WG: the workgroup's first wavefront speaks for it
+    if ((t & 63) == 0 && (!WG || t == 0) && slot_w < ANM_MAX_WAVES)
+      for (int k = 0; k < 8; ++k) g_anm_phase[k][slot_w] = ph_acc[k];
+  }
+#endif
   const bool f_nan = g_nan;
   const bool converged = !g_nan && !g_bad;
 

@@ -48,12 +48,18 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
   }
 
   // ---- the program, as k_mesh interprets it
-  struct W { int o; double v; };
-  std::vector<char> product_written(d.lds_per_env, 0);
+  struct W { int o; double v; int lane; };
   for (int st = 0; st < d.n_steps; ++st) {
     const int ty = P.hi[d.off_stype + st] & 0xff, run = P.hi[d.off_stype + st] >> 8;
     std::vector<W> writes;
-    auto ld4 = [&](int o, double* m) { for (int u = 0; u < 4; ++u) m[u] = S[o + u]; };
+    std::vector<int> read_by(d.lds_per_env, -1);     // lane that read a place in this step (-2: several)
+    int lane = 0;
+    auto rd = [&](int o) {
+      if (o < 0 || o >= d.lds_per_env) return double(NAN);
+      read_by[o] = (read_by[o] == -1 || read_by[o] == lane) ? lane : -2;
+      return S[o];
+    };
+    auto ld4 = [&](int o, double* m) { for (int u = 0; u < 4; ++u) m[u] = rd(o + u); };
     auto mul = [&](const double* a, const double* b, double* c) {
       c[0] = a[0] * b[0] + a[1] * b[2]; c[1] = a[0] * b[1] + a[1] * b[3];
       c[2] = a[2] * b[0] + a[3] * b[2]; c[3] = a[2] * b[1] + a[3] * b[3];
@@ -63,6 +69,7 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
       Di[0] = D[3] / det; Di[1] = -D[1] / det; Di[2] = -D[2] / det; Di[3] = D[0] / det;
     };
     for (int l = 0; l < G; ++l) {
+      lane = l;
       unsigned w[4];
       for (int u = 0; u < 4; ++u) w[u] = unsigned(P.hi[d.off_desc + (size_t(st) * G + l) * 4 + u]);
       const int kind = w[0] & 0xffff, o1 = w[0] >> 16, o2 = w[1] & 0xffff, o3 = w[1] >> 16, o4 = w[2] & 0xffff,
@@ -70,41 +77,33 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
       if (kind == 0) continue;
       // an operation may only ride in a step of its own type
       const int want = (kind == mesh::OP_PROD) ? mesh::ST_PROD : (kind == mesh::OP_SUM) ? mesh::ST_SUM
-                       : (kind == mesh::OP_BACK || kind == mesh::OP_INVBACK) ? mesh::ST_BACK
                        : (kind == mesh::OP_TAIL2) ? mesh::ST_TAIL
-                       : (kind == mesh::OP_FUSE1 || kind == mesh::OP_FUSE2) ? mesh::ST_FUSE : mesh::ST_ACC;
+                       : (kind >= mesh::OP_COL && kind <= (mesh::OP_COL | mesh::OP_COL_INV1 | mesh::OP_COL_INV2)) ? mesh::ST_COL : -1;
       if (want != ty) return -5;
       if (ty == mesh::ST_PROD) {
-        double D[4], Di[4], Aik[4], L[4], X[4], M[4];
-        ld4(o1, D); inv(D, Di); ld4(o2, Aik); mul(Aik, Di, L); ld4(o3, X); mul(L, X, M);
-        for (int u = 0; u < 4; ++u) writes.push_back(W{o4 + u, M[u]});
-        if (o4 < d.l_m || o4 + 4 > d.l_m + 4 * d.n_m) return -6;
-        product_written[o4] = 1;
-        if (o5) for (int u = 0; u < 4; ++u) writes.push_back(W{o5 + u, Di[u]});
-      } else if (ty == mesh::ST_FUSE) {
-        if (run < 1 || run > 2 || (kind == mesh::OP_FUSE2 && run < 2)) return -8;
-        double Z[4];
-        ld4(o1, Z);
-        const int trip[2][3] = {{o2, o3, o4}, {o5, o6, o7}};
-        for (int c = 0; c < (kind == mesh::OP_FUSE2 ? 2 : 1); ++c) {
-          double D[4], Di[4], Aik[4], L[4], X[4], M[4];
-          ld4(trip[c][0], D); inv(D, Di); ld4(trip[c][1], Aik); mul(Aik, Di, L); ld4(trip[c][2], X); mul(L, X, M);
-          for (int u = 0; u < 4; ++u) Z[u] -= M[u];
-        }
-        for (int u = 0; u < 4; ++u) writes.push_back(W{o1 + u, Z[u]});
+        double D[4], Di[4], Aik[4], L[4], X[4], M[4], Z[4];
+        ld4(o1, D); inv(D, Di); ld4(o2, Aik); mul(Aik, Di, L); ld4(o3, X); mul(L, X, M); ld4(o6, Z);
+        for (int u = 0; u < 4; ++u) writes.push_back(W{o4 + u, Z[u] - M[u], l});
+        // the first contribution goes to the destination it read; the others, negated, to a product slot
+        const bool parked = o4 >= d.l_m && o4 + 4 <= d.l_m + 4 * d.n_m;
+        if (parked ? o6 != d.l_zero : o6 != o4) return -6;
+        if (o5) for (int u = 0; u < 4; ++u) writes.push_back(W{o5 + u, Di[u], l});
       } else if (ty == mesh::ST_TAIL) {
         double Da[4], Dai[4], Aab[4], Aba[4], Db[4], Dbi[4], L[4], M[4];
         ld4(o1, Da); inv(Da, Dai); ld4(o2, Aab); ld4(o3, Aba); ld4(o4, Db);
         mul(Aba, Dai, L); mul(L, Aab, M);
         for (int u = 0; u < 4; ++u) Db[u] -= M[u];
-        const double ra0 = S[o5], ra1 = S[o5 + 2];
-        const double rb0 = S[o6] - (L[0] * ra0 + L[1] * ra1), rb1 = S[o6 + 2] - (L[2] * ra0 + L[3] * ra1);
+        const double ra0 = rd(o5), ra1 = rd(o5 + 2);
+        const double rb0 = rd(o6) - (L[0] * ra0 + L[1] * ra1), rb1 = rd(o6 + 2) - (L[2] * ra0 + L[3] * ra1);
         inv(Db, Dbi);
         const double xb0 = Dbi[0] * rb0 + Dbi[1] * rb1, xb1 = Dbi[2] * rb0 + Dbi[3] * rb1;
         const double a0 = ra0 - (Aab[0] * xb0 + Aab[1] * xb1), a1 = ra1 - (Aab[2] * xb0 + Aab[3] * xb1);
-        const int xb = d.l_x + ((o6 - d.l_r) >> 1), xa = d.l_x + ((o5 - d.l_r) >> 1);
-        writes.push_back(W{xb, xb0}); writes.push_back(W{xb + 1, xb1});
-        writes.push_back(W{xa, Dai[0] * a0 + Dai[1] * a1}); writes.push_back(W{xa + 1, Dai[2] * a0 + Dai[3] * a1});
+        writes.push_back(W{o6, rb0, l}); writes.push_back(W{o6 + 2, rb1, l});
+        writes.push_back(W{o5, a0, l}); writes.push_back(W{o5 + 2, a1, l});
+        for (int u = 0; u < 4; ++u) {
+          writes.push_back(W{o6 - d.l_r + d.l_dinv + u, Dbi[u], l});
+          writes.push_back(W{o5 - d.l_r + d.l_dinv + u, Dai[u], l});
+        }
       } else if (ty == mesh::ST_SUM) {
         if (run < 1 || run > 4 || o6 > run) return -2;   // o6: how many products this lane really has
         double Z[4];
@@ -112,40 +111,50 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
         const int slots[4] = {o2, o3, o4, o5};
         for (int c = 0; c < (run > 2 ? 4 : run); ++c) {
           if (c >= o6 && slots[c] != d.l_zero) return -7;
-          for (int u = 0; u < 4; ++u) Z[u] -= S[slots[c] + u];
+          for (int u = 0; u < 4; ++u) Z[u] += rd(slots[c] + u);
         }
-        for (int u = 0; u < 4; ++u) writes.push_back(W{o1 + u, Z[u]});
+        for (int u = 0; u < 4; ++u) writes.push_back(W{o1 + u, Z[u], l});
       } else {
-        double a0 = S[o1], a1 = S[o1 + 2];
-        const int first = (ty == mesh::ST_BACK) ? 4 : 2;
-        const int offs[8] = {0, o1, o2, o3, o4, o5, o6, o7};
-        for (int q = first; q < 8; q += 2) {
-          double Ab[4];
-          ld4(offs[q], Ab);
-          const double x0 = S[offs[q + 1]], x1 = S[offs[q + 1] + 1];
+        double a0 = rd(o1), a1 = rd(o1 + 2);
+        const int trip[2][3] = {{o2, o3, o4}, {o5, o6, o7}};
+        for (int c = 0; c < 2; ++c) {
+          double Ab[4], Dk[4];
+          ld4(trip[c][0], Ab);
+          const double r0 = rd(trip[c][1]), r1 = rd(trip[c][1] + 2);
+          ld4(trip[c][2], Dk);
+          if (kind & (c == 0 ? mesh::OP_COL_INV1 : mesh::OP_COL_INV2)) { double D[4] = {Dk[0], Dk[1], Dk[2], Dk[3]}; inv(D, Dk); }
+          const double x0 = Dk[0] * r0 + Dk[1] * r1, x1 = Dk[2] * r0 + Dk[3] * r1;
           a0 -= Ab[0] * x0 + Ab[1] * x1;
           a1 -= Ab[2] * x0 + Ab[3] * x1;
         }
-        if (ty == mesh::ST_BACK) {
-          double Di[4];
-          ld4(o2, Di);
-          if (kind == mesh::OP_INVBACK) { double D[4] = {Di[0], Di[1], Di[2], Di[3]}; inv(D, Di); }
-          writes.push_back(W{o3, Di[0] * a0 + Di[1] * a1});
-          writes.push_back(W{o3 + 1, Di[2] * a0 + Di[3] * a1});
-        } else {
-          writes.push_back(W{o1, a0}); writes.push_back(W{o1 + 2, a1});
-        }
+        writes.push_back(W{o1, a0, l}); writes.push_back(W{o1 + 2, a1, l});
       }
     }
-    // no two lanes of a step may write the same place, and nothing a step reads may be written in it (checked
-    // through the NaN-initialised memory and the comparison below: a violated order shows up as a wrong solution)
+    // no two lanes of a step may write the same place, and nothing a step reads may be written in it by another lane
+    // (a violated order also shows up as a wrong solution: the memory starts as NaN)
     std::vector<char> seen(d.lds_per_env, 0);
     for (const W& q : writes) {
       if (q.o < 0 || q.o >= d.lds_per_env || seen[q.o]) return -3;
       seen[q.o] = 1;
       if (q.o >= d.l_zero && q.o < d.l_zero + 6) return -4;
+      if (read_by[q.o] != -1 && read_by[q.o] != q.lane) return -9;
     }
     for (const W& q : writes) S[q.o] = q.v;
+  }
+  // what every bus lane forms when the program has ended: x_i = D_i^-1 r_i (IF_XINV: D_i was never inverted)
+  std::vector<double> xs(2 * NB, NAN);
+  for (int i = 1; i < NB; ++i) {
+    double Di[4];
+    if (I(mesh::IF_XINV, i - 1)) {
+      const double* D = &S[d.l_blk + 4 * I(mesh::IF_DIAG, i - 1)];
+      const double det = D[0] * D[3] - D[1] * D[2];
+      Di[0] = D[3] / det; Di[1] = -D[1] / det; Di[2] = -D[2] / det; Di[3] = D[0] / det;
+    } else {
+      for (int u = 0; u < 4; ++u) Di[u] = S[d.l_dinv + 4 * i + u];
+    }
+    const double r0 = S[d.l_r + 4 * i], r1 = S[d.l_r + 4 * i + 2];
+    xs[2 * i] = Di[0] * r0 + Di[1] * r1;
+    xs[2 * i + 1] = Di[2] * r0 + Di[3] * r1;
   }
 
   // ---- dense reference: Gaussian elimination with partial pivoting
@@ -167,7 +176,7 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
   double e = 0.0;
   for (int i = 1; i < NB; ++i)
     for (int u = 0; u < 2; ++u) {
-      const double x = S[d.l_x + 2 * i + u];
+      const double x = xs[2 * i + u];
       const double dd = std::fabs(x - b[2 * (i - 1) + u]);
       e = std::fmax(e, (dd == dd) ? dd : INFINITY);
     }
