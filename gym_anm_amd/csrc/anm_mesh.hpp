@@ -118,8 +118,14 @@ inline size_t lds_bytes(const Dims& d, int waves) {
   if (is_workgroup(d)) return size_t(d.lds_per_env) * sizeof(double);
   return size_t(waves) * (64 / d.G) * d.lds_per_env * sizeof(double) + size_t(d.n_stage) * sizeof(int);
 }
-// wavefronts per workgroup (they share one copy of the tables): what puts most wavefronts on a compute unit's
-// 160 KB of LDS, the larger workgroup on a tie
+// wavefronts per workgroup (they share one copy of the tables): what puts most wavefronts on a compute unit -- its
+// 160 KB of LDS, and two wavefronts per SIMD (k_mesh holds more than 170 registers per lane).  On a tie the larger
+// workgroup for groups of 32 lanes and more (fewer copies of the tables to stage: the batch of the meshed 30-bus
+// network -4 %), the smaller one below: a workgroup gives its wavefront slots back when its LAST wavefront ends, and
+// with 8 environments per wavefront a fair share of the wavefronts carry a diverging solve to the iteration cap
+// (ANM6 through this family, 65 536 transitions: 358 us with one wavefront per workgroup, 445 us with four;
+// profiles/r04_m_mesh_step_program.txt)
+constexpr int MAX_WAVES_PER_CU = 8;
 inline int waves_per_block(const Dims& d) {
   if (is_workgroup(d)) return d.G / 64;
   if (const char* ev = getenv("ANM_MESH_WAVES")) {   // tuning experiments
@@ -129,8 +135,8 @@ inline int waves_per_block(const Dims& d) {
   int best = 1;
   size_t best_waves = 0;
   for (int w = 1; w <= 4; w *= 2) {
-    const size_t per_cu = lds_bytes(d, w) <= 160 * 1024 ? (160 * 1024 / lds_bytes(d, w)) * w : 0;
-    if (per_cu >= best_waves) { best_waves = per_cu; best = w; }
+    const size_t per_cu = lds_bytes(d, w) <= 160 * 1024 ? std::min<size_t>(MAX_WAVES_PER_CU, (160 * 1024 / lds_bytes(d, w)) * w) : 0;
+    if (per_cu > best_waves || (per_cu == best_waves && d.G >= 32)) { best_waves = per_cu; best = w; }
   }
   return best;
 }

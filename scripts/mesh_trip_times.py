@@ -1,6 +1,6 @@
 """Cycles per part of a Newton trip of the general lane-group kernel (tuning build with -DANM_PHASE_TIMING):
 
-    ANM_BUILD_TAG=phases ANM_EXTRA_HIPCC_FLAGS=-DANM_PHASE_TIMING python scripts/mesh_trip_times.py [mesh30|mesh200|case30] [max_iter]
+    ANM_BUILD_TAG=phases ANM_EXTRA_HIPCC_FLAGS=-DANM_PHASE_TIMING python scripts/mesh_trip_times.py [mesh30|mesh200|case30|anm6] [max_iter]
 
 Prints, for the wavefront with most trips (the one that holds a diverging solve: alone on its SIMD at the end) and for a
 median wavefront, the shader-clock cycles per trip of: publish V + branch products, bus sums + stop test + diagonal,
@@ -14,6 +14,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "mesh30"
 cap = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 net, E, ls = {"mesh30": (networks.synthetic_meshed_network(30, 6, 4), 16384, 1.0),
               "case30": (networks.synthetic_radial_network(30, 0), 16384, 1.0),
+              "anm6": (networks.anm6_network(), 65536, 1.0),
               "mesh200": (networks.synthetic_meshed_network(200, 13, 30), 4096, 40.0 / 200)}[which]
 dev = "cuda:0"
 sim = BatchedSimulator(net, 0.25, 100, num_envs=E, device=dev, tol=1e-6, max_iter=cap, impl="mesh")
