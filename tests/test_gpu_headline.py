@@ -545,3 +545,122 @@ def test_general_step_with_rows_wider_than_the_default_lds_limit():
 @pytest.mark.parametrize("impl", ["radial", "mesh"])
 def test_a_different_network_in_every_environment(impl):
     pc.per_environment_networks(KW, impl)
+
+
+def test_reset_and_step_through_views_of_a_mixed_batch():
+    """anm_reset_f64 / anm_step_f64 with a view bound (include/anm_mi355x.h: anm_model_bind_view): environments over three
+    topologies interleaved in ONE batch whose rows are padded to the widest network, each topology's launch told which
+    rows are its own -- against the same environments run on their own (same kernel family, so every number is equal),
+    and the padding of every row untouched.  ANMEnv.reset / step: anm_env.py:235-311, 333-453."""
+    import ctypes as C
+
+    from gym_anm_amd import _lib, networks
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv, _stream_ptr
+
+    nets = [networks.anm6_network(), networks.three_bus_loop_network(gen_max=1.5), networks.synthetic_meshed_network(20, 3, 6)]
+    per = 96
+    E_ = per * len(nets)
+    env_net = np.arange(E_) % len(nets)
+
+    def make(net, k):
+        class Task(BatchedANMEnv):
+            def __init__(self):
+                super().__init__(net, "state", 1, 0.25, 0.99, 100, np.array([[0, 24]]), (10, 500), 3, num_envs=per, device=DEV,
+                                 tol=1e-8, impl="mesh")
+
+            def init_state(self):
+                raise AssertionError("the test resets to explicit states")
+
+            def next_vars(self, s_t):
+                raise AssertionError("the test passes the exogenous values itself")
+
+        return Task()
+
+    own = [make(n, k) for k, n in enumerate(nets)]
+    viewed = [make(n, k) for k, n in enumerate(nets)]      # their models serve the padded batch through a view
+    dims = [e.simulator for e in own]
+    W = lambda f: max(f(s) for s in dims)  # noqa: E731
+    w_act = W(lambda s: s.dims.action_dim)
+    w_st = max(e.state_N for e in own)
+    w_exo = W(lambda s: s.N_load + s.N_non_slack_gen)
+    w_des = max(1, W(lambda s: s.N_des))
+    PAD = -777.0
+    f64 = dict(dtype=torch.float64, device=DEV)
+    state, obs, init = (torch.full((E_, w_st), PAD, **f64) for _ in range(3))
+    soc = torch.full((E_, w_des), PAD, **f64)
+    action = torch.full((E_, w_act), PAD, **f64)
+    exo = torch.full((E_, w_exo), PAD, **f64)
+    aux = torch.full((E_, 1), PAD, **f64)
+    reward, e_loss, penalty = (torch.zeros(E_, **f64) for _ in range(3))
+    conv, term = (torch.zeros(E_, dtype=torch.uint8, device=DEV) for _ in range(2))
+    timestep, nr_iters, reset_count = (torch.zeros(E_, dtype=torch.int32, device=DEV) for _ in range(3))
+    idx, views = [], []
+    for k, v in enumerate(viewed):
+        ix = torch.as_tensor(np.nonzero(env_net == k)[0], dtype=torch.int32, device=DEV)
+        idx.append(ix)
+        bv = _lib.BatchView(ix.data_ptr(), 0, 0, 0, w_des, w_act, w_st, w_exo, 1, 0)
+        views.append(bv)
+        sim = v.simulator
+        sim.backend.check(sim.backend.lib.anm_model_bind_view(sim._handle, C.byref(bv)), "anm_model_bind_view")
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+
+    def rows_equal(k, what):
+        o, sim, ix = own[k], own[k].simulator, idx[k].long()
+        sd, nd = o.state_N, sim.N_des
+        torch.cuda.synchronize()
+        for name, mine, theirs in (("state", state[ix, :sd], o._state_buf), ("obs", obs[ix, :sd], o._state_obs),
+                                   ("terminated", term[ix], o._term_u8), ("timestep", timestep[ix], o.timestep),
+                                   ("nr_iters", nr_iters[ix], sim.nr_iters)):
+            assert torch.equal(mine, theirs), (what, k, name)
+        if nd:
+            assert torch.equal(soc[ix, :nd], sim.soc[:, :nd]), (what, k, "soc")
+        assert bool((state[ix, sd:] == PAD).all()) and bool((obs[ix, sd:] == PAD).all()) and bool((soc[ix, nd:] == PAD).all())
+
+    # ---- reset to explicit initial states (every 17th far outside the device ranges: mapped back like the others)
+    for k, o in enumerate(own):
+        sim, m = o.simulator, o.simulator.model
+        D, nd, ng, sd = m.N_device, m.N_des, m.N_non_slack_gen, o.state_N
+        s0 = torch.zeros((per, sd), dtype=torch.float64)
+        u = torch.rand((per, sd), generator=g, dtype=torch.float64)
+        s0[:, :D] = (2 * u[:, :D] - 1) * 3.0
+        s0[:, D:2 * D] = (2 * u[:, D:2 * D] - 1) * 0.5
+        s0[:, 2 * D:2 * D + nd] = u[:, 2 * D:2 * D + nd] * 5.0
+        s0[:, 2 * D + nd:2 * D + nd + ng] = u[:, 2 * D + nd:2 * D + nd + ng] * 10.0
+        s0[:, -1] = 7.0
+        s0[::17, :D] *= 40.0
+        s0 = s0.to(DEV)
+        o._launch_reset(s0, None)
+        init[idx[k].long(), :sd] = s0
+        v = viewed[k].simulator
+        rc = v.backend.lib.anm_reset_f64(
+            v._handle, per, init.data_ptr(), None, 3, 0, reset_count.data_ptr(), soc.data_ptr(), state.data_ptr(), obs.data_ptr(),
+            conv.data_ptr(), term.data_ptr(), timestep.data_ptr(), nr_iters.data_ptr(), None, None, C.byref(v.opts), _stream_ptr(o.device))
+        v.backend.check(rc, "anm_reset_f64")
+        rows_equal(k, "reset")
+        assert torch.equal(conv[idx[k].long()], o._conv_u8)
+
+    # ---- steps with the exogenous values handed over (anm_env.py:369-397)
+    for t in range(5):
+        for k, o in enumerate(own):
+            sim, m = o.simulator, o.simulator.model
+            ix = idx[k].long()
+            na, ne = sim.dims.action_dim, sim.N_load + sim.N_non_slack_gen
+            lo, hi = torch.as_tensor(o.action_space.low), torch.as_tensor(o.action_space.high)
+            a = (lo + (hi - lo) * torch.rand((per, na), generator=g, dtype=torch.float64)).to(DEV).contiguous()
+            xlo = torch.as_tensor(np.concatenate((m.dev_p_min[m.load_idx], 0 * m.dev_p_max[m.gen_idx])) * m.baseMVA)
+            xhi = torch.as_tensor(np.concatenate((0 * m.dev_p_min[m.load_idx], m.dev_p_max[m.gen_idx])) * m.baseMVA)
+            x = (xlo + (xhi - xlo) * torch.rand((per, ne), generator=g, dtype=torch.float64)).to(DEV).contiguous()
+            ax = torch.full((per, 1), float((8 + t) % 24), **f64)
+            o._step_call(a.data_ptr(), x.data_ptr(), ax.data_ptr())
+            action[ix, :na], exo[ix, :ne], aux[ix] = a, x, ax
+            v = viewed[k].simulator
+            rc = v.backend.lib.anm_step_f64(
+                v._handle, per, action.data_ptr(), exo.data_ptr(), aux.data_ptr(), soc.data_ptr(), state.data_ptr(), term.data_ptr(),
+                timestep.data_ptr(), obs.data_ptr(), reward.data_ptr(), e_loss.data_ptr(), penalty.data_ptr(), nr_iters.data_ptr(),
+                None, 0, 3, 0, reset_count.data_ptr(), None, None, C.byref(v.opts), _stream_ptr(o.device))
+            v.backend.check(rc, "anm_step_f64")
+            rows_equal(k, "step %d" % t)
+            for name, mine, theirs in (("reward", reward[ix], o.reward), ("e_loss", e_loss[ix], o.e_loss),
+                                       ("penalty", penalty[ix], o.penalty)):
+                assert torch.equal(mine, theirs), (t, k, name)
