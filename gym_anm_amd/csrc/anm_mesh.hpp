@@ -339,6 +339,37 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     tail_a = piv[d.n_levels - 2][0];
     tail_b = piv[d.n_levels - 1][0];
   }
+  // The DENSE END of the order -- the trailing run of levels with ONE pivot each that is coupled to every later bus (what
+  // the fill leaves of a meshed core) -- is eliminated Gauss-Jordan style: the product step of such a pivot k also takes k
+  // out of the rows of the EARLIER buses of the run (A_ij -= A_ik D_k^-1 A_kj, r_i -= A_ik D_k^-1 r_k for i before k: all
+  // blocks exist, the run is dense; one contribution per destination, so the product operation subtracts it itself).
+  // Lanes are plentiful, steps are not: the buses of the run then owe the back substitution only the terms of the last
+  // buses (the tail) and become ready TOGETHER, where the column sweep walked them one step per bus.  As far back as the
+  // operations of a level still fit one step (G lanes).
+  std::vector<char> gj(NB, 0);
+  {
+    const int last_lv = d.n_levels - 1 - (tail_a >= 0 ? 2 : 0);    // last level with a product step
+    int n_later = tail_a >= 0 ? 2 : 0;
+    std::vector<int> run;                                         // pivots of the run, last first
+    for (int lv = last_lv; lv >= 0 && !getenv("ANM_MESH_NO_GJ"); --lv) {
+      if (piv[lv].size() != 1 || int(upper[piv[lv][0]].size()) != n_later || n_later == 0) break;
+      run.push_back(piv[lv][0]);
+      ++n_later;
+    }
+    // operations of the level of the run's q-th pivot from the END when the run has n members taken:
+    // (rows below + earlier members of the run) x (later buses + the right-hand side)
+    size_t take = run.size();
+    for (; take > 0; --take) {
+      bool fits_all = true;
+      for (size_t q = 0; q < take; ++q) {
+        const size_t later = upper[run[q]].size(), earlier = take - 1 - q;
+        if ((later + earlier) * (later + 1) > size_t(G)) fits_all = false;
+      }
+      if (fits_all) break;
+    }
+    for (size_t q = 0; q < take; ++q) gj[run[q]] = 1;
+  }
+  std::vector<int> gj_before;   // members of the run already eliminated, in order
   for (int lv = 0; lv < d.n_levels; ++lv) {
     if (tail_a >= 0 && lv >= d.n_levels - 2) continue;   // folded into the ST_TAIL step
     // destinations (block (i, j); j == NB: r_i) and, in pivot order, who contributes to them
@@ -346,13 +377,20 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     std::vector<std::pair<int, int>> dsts;
     std::vector<std::vector<Contribution>> contrib;
     std::vector<std::vector<int>> dst_of(NB, std::vector<int>(NB + 1, -1));
-    for (int k : piv[lv])
-      for (int i : upper[k])
+    for (int k : piv[lv]) {
+      std::vector<int> rows = upper[k];
+      if (gj[k]) {
+        rows.insert(rows.end(), gj_before.begin(), gj_before.end());
+        gj_before.push_back(k);
+      }
+      for (int i : rows)
         for (size_t q = 0; q <= upper[k].size(); ++q) {
           const int j = q < upper[k].size() ? upper[k][q] : NB;
+          if (blk[i][k] < 0 || (j < NB && blk[i][j] < 0)) { err = "internal: a block of the dense end is missing"; return false; }
           if (dst_of[i][j] < 0) { dst_of[i][j] = int(dsts.size()); dsts.push_back({i, j}); contrib.push_back({}); }
           contrib[dst_of[i][j]].push_back(Contribution{i, k, j});
         }
+    }
     if (dsts.empty()) continue;
     // The FIRST contribution of a destination is subtracted by the product operation itself (the destination is no
     // operand of its level: neither of its indices is a pivot of the level); the others are parked, NEGATED, and added
@@ -414,7 +452,8 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   std::vector<std::vector<int>> pend(NB);
   std::vector<char> ready(NB, 0), self_inv(NB, 0);
   for (int k = 1; k < NB; ++k) {
-    pend[k] = upper[k];
+    for (int j : upper[k])
+      if (!(gj[k] && gj[j])) pend[k].push_back(j);     // (inside the dense end the products took the later buses out)
     self_inv[k] = upper[k].empty() && k != tail_b;
   }
   if (tail_a >= 0) pend[tail_a].clear();             // (the tail step takes A_ab x_b out of r_a)
