@@ -90,7 +90,7 @@ enum DField : int { DF_YII_RE = 0, DF_YII_IM, DF_VMIN, DF_VMAX, DF_YFT_RE, DF_YF
                     DF_BR_FIELDS = DF_BRC + 9 - DF_YFT_RE, DF_COUNT = DF_YFT_RE + 2 * DF_BR_FIELDS };
 
 struct Dims {
-  int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, n_levels, slack_dev, NBLK, n_fill, br_slots;
+  int G, NB, ND, NBR, NLOAD, NGEN, NDES, NSET, SDIM, FS, n_levels, zone_level, slack_dev, NBLK, n_fill, br_slots;
   int off_lists, n_lists, off_fill;                        // ints: [IF_COUNT][G], lists, fill ids (staged in LDS) ...
   int n_steps, off_stype, off_desc, n_stage, max_deg;      // ... step types (| run length << 8) [n_steps], descriptors [n_steps][G][4]
   int off_lane, off_dev, off_obs_lo, off_obs_hi, n_double;  // doubles
@@ -146,8 +146,9 @@ inline bool fits(const anm_network_desc& n) {
   return n.n_bus >= 2 && n.n_bus - 1 <= MAX_GROUP && n.n_dev <= MAX_GROUP && n.n_branch <= MAX_GROUP * BR_SLOTS;
 }
 
-// Symbolic analysis + per-lane tables for one network.
-inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
+// Symbolic analysis + per-lane tables for one network; the levels from `zone_level` on are eliminated Gauss-Jordan
+// style (see "the ZONE" below; build_plan picks the level).
+inline bool build_plan_zone(const anm_network_desc& n, Plan& P, std::string& err, int zone_level) {
   if (!fits(n)) { err = "the general lane-group kernel takes networks of at most 513 buses, 1024 branches, 512 devices"; return false; }
   Dims& d = P.d;
   d.NB = n.n_bus; d.ND = n.n_dev; d.NBR = n.n_branch;
@@ -252,10 +253,51 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
       for (int i : nb) level[i] = std::max(level[i], level[k] + 1);
     }
   }
-  d.NBLK = nblk;
-  d.n_fill = int(fill_ids.size());
   d.n_levels = 0;
   for (int i = 1; i < NB; ++i) d.n_levels = std::max(d.n_levels, level[i] + 1);
+  std::vector<std::vector<int>> piv(d.n_levels);
+  for (int k : order) piv[level[k]].push_back(k);
+  // the last two buses of the order, each alone in its level (the second-to-last is then coupled to the last only)
+  int tail_a = -1, tail_b = -1;
+  if (!getenv("ANM_MESH_NO_TAIL") && d.n_levels >= 2 && piv[d.n_levels - 1].size() == 1 && piv[d.n_levels - 2].size() == 1 &&
+      upper[piv[d.n_levels - 2][0]].size() == 1 && upper[piv[d.n_levels - 2][0]][0] == piv[d.n_levels - 1][0]) {
+    tail_a = piv[d.n_levels - 2][0];
+    tail_b = piv[d.n_levels - 1][0];
+  }
+  // The ZONE: the levels from zone_level on (the tail apart) are eliminated Gauss-Jordan style -- the product step of a
+  // pivot k of the zone also takes k out of the rows of the EARLIER buses i of the zone that are coupled to it
+  // (A_ij -= A_ik D_k^-1 A_kj for the later buses j of k, r_i -= A_ik D_k^-1 r_k; a block (i, j) that does not exist yet
+  // is more fill).  Lanes are plentiful, steps are not: the buses of the zone then owe the back substitution only the
+  // terms of the tail and become ready TOGETHER, where the column sweep walks one step per link of their dependency
+  // chain (the dense end of the order -- one pivot per level, each coupled to all later buses: what the fill leaves of a
+  // meshed core -- cost one step per bus).  rows_up[k]: those earlier rows; zstruct[i]: the later buses row i of the
+  // zone is still coupled to.
+  const int last_lv = d.n_levels - 1 - (tail_a >= 0 ? 2 : 0);    // last level with a product step
+  d.zone_level = std::min(std::max(zone_level, 0), last_lv + 1);
+  std::vector<std::vector<int>> rows_up(NB);
+  std::vector<std::set<int>> zstruct(NB);
+  std::vector<char> in_zone(NB, 0);
+  {
+    std::vector<int> zone_done;
+    for (int lv = d.zone_level; lv <= last_lv; ++lv)
+      for (int k : piv[lv]) { in_zone[k] = 1; zstruct[k] = std::set<int>(upper[k].begin(), upper[k].end()); }
+    for (int lv = d.zone_level; lv <= last_lv; ++lv) {
+      for (int k : piv[lv])
+        for (int i : zone_done)
+          if (zstruct[i].count(k)) rows_up[k].push_back(i);
+      for (int k : piv[lv])            // (pivots of a level are not coupled to each other: the order does not matter)
+        for (int i : rows_up[k]) {
+          for (int j : upper[k]) {
+            if (blk[i][j] < 0) { blk[i][j] = nblk++; fill_ids.push_back(blk[i][j]); }
+            zstruct[i].insert(j);
+          }
+          zstruct[i].erase(k);
+        }
+      for (int k : piv[lv]) zone_done.push_back(k);
+    }
+  }
+  d.NBLK = nblk;
+  d.n_fill = int(fill_ids.size());
 
   // ---- LDS layout of one environment (doubles).  The branch products W (written and summed before the step
   // program starts) and the parked products of the elimination are never alive together and share their place
@@ -329,47 +371,8 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   const Desc none = {0, 0, 0, 0, 0, 0, 0, 0};
   auto new_step = [&](int ty) { stype.push_back(ty); steps.push_back(std::vector<Desc>()); return int(steps.size()) - 1; };
   const int oB = d.l_blk, oR = d.l_r, oDI = d.l_dinv, oZ = d.l_zero;
-  std::vector<std::vector<int>> piv(d.n_levels);
-  for (int k : order) piv[level[k]].push_back(k);
   int n_m = 0;
-  // the last two buses of the order, each alone in its level (the second-to-last is then coupled to the last only)
-  int tail_a = -1, tail_b = -1;
-  if (!getenv("ANM_MESH_NO_TAIL") && d.n_levels >= 2 && piv[d.n_levels - 1].size() == 1 && piv[d.n_levels - 2].size() == 1 &&
-      upper[piv[d.n_levels - 2][0]].size() == 1 && upper[piv[d.n_levels - 2][0]][0] == piv[d.n_levels - 1][0]) {
-    tail_a = piv[d.n_levels - 2][0];
-    tail_b = piv[d.n_levels - 1][0];
-  }
-  // The DENSE END of the order -- the trailing run of levels with ONE pivot each that is coupled to every later bus (what
-  // the fill leaves of a meshed core) -- is eliminated Gauss-Jordan style: the product step of such a pivot k also takes k
-  // out of the rows of the EARLIER buses of the run (A_ij -= A_ik D_k^-1 A_kj, r_i -= A_ik D_k^-1 r_k for i before k: all
-  // blocks exist, the run is dense; one contribution per destination, so the product operation subtracts it itself).
-  // Lanes are plentiful, steps are not: the buses of the run then owe the back substitution only the terms of the last
-  // buses (the tail) and become ready TOGETHER, where the column sweep walked them one step per bus.  As far back as the
-  // operations of a level still fit one step (G lanes).
-  std::vector<char> gj(NB, 0);
-  {
-    const int last_lv = d.n_levels - 1 - (tail_a >= 0 ? 2 : 0);    // last level with a product step
-    int n_later = tail_a >= 0 ? 2 : 0;
-    std::vector<int> run;                                         // pivots of the run, last first
-    for (int lv = last_lv; lv >= 0 && !getenv("ANM_MESH_NO_GJ"); --lv) {
-      if (piv[lv].size() != 1 || int(upper[piv[lv][0]].size()) != n_later || n_later == 0) break;
-      run.push_back(piv[lv][0]);
-      ++n_later;
-    }
-    // operations of the level of the run's q-th pivot from the END when the run has n members taken:
-    // (rows below + earlier members of the run) x (later buses + the right-hand side)
-    size_t take = run.size();
-    for (; take > 0; --take) {
-      bool fits_all = true;
-      for (size_t q = 0; q < take; ++q) {
-        const size_t later = upper[run[q]].size(), earlier = take - 1 - q;
-        if ((later + earlier) * (later + 1) > size_t(G)) fits_all = false;
-      }
-      if (fits_all) break;
-    }
-    for (size_t q = 0; q < take; ++q) gj[run[q]] = 1;
-  }
-  std::vector<int> gj_before;   // members of the run already eliminated, in order
+  std::vector<char> dinv_stored(NB, 0);
   for (int lv = 0; lv < d.n_levels; ++lv) {
     if (tail_a >= 0 && lv >= d.n_levels - 2) continue;   // folded into the ST_TAIL step
     // destinations (block (i, j); j == NB: r_i) and, in pivot order, who contributes to them
@@ -379,14 +382,11 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     std::vector<std::vector<int>> dst_of(NB, std::vector<int>(NB + 1, -1));
     for (int k : piv[lv]) {
       std::vector<int> rows = upper[k];
-      if (gj[k]) {
-        rows.insert(rows.end(), gj_before.begin(), gj_before.end());
-        gj_before.push_back(k);
-      }
+      rows.insert(rows.end(), rows_up[k].begin(), rows_up[k].end());
       for (int i : rows)
         for (size_t q = 0; q <= upper[k].size(); ++q) {
           const int j = q < upper[k].size() ? upper[k][q] : NB;
-          if (blk[i][k] < 0 || (j < NB && blk[i][j] < 0)) { err = "internal: a block of the dense end is missing"; return false; }
+          if (blk[i][k] < 0 || (j < NB && blk[i][j] < 0)) { err = "internal: a block of the zone is missing"; return false; }
           if (dst_of[i][j] < 0) { dst_of[i][j] = int(dsts.size()); dsts.push_back({i, j}); contrib.push_back({}); }
           contrib[dst_of[i][j]].push_back(Contribution{i, k, j});
         }
@@ -408,6 +408,7 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
       prods.push_back(Desc{OP_PROD, oB + 4 * blk[x.k][x.k], oB + 4 * blk[x.i][x.k], src, where,
                            dinv_done[x.k] ? 0 : oDI + 4 * x.k, z, 0});
       dinv_done[x.k] = 1;
+      dinv_stored[x.k] = 1;
     };
     for (size_t q = 0; q < dsts.size(); ++q) {
       const auto& c = contrib[q];
@@ -451,10 +452,11 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   // step); a bus nothing was eliminated into still has D itself: the operation inverts it (OP_COL_INV1 / _INV2 bits).
   std::vector<std::vector<int>> pend(NB);
   std::vector<char> ready(NB, 0), self_inv(NB, 0);
+  if (tail_a >= 0) dinv_stored[tail_a] = dinv_stored[tail_b] = 1;
   for (int k = 1; k < NB; ++k) {
-    for (int j : upper[k])
-      if (!(gj[k] && gj[j])) pend[k].push_back(j);     // (inside the dense end the products took the later buses out)
-    self_inv[k] = upper[k].empty() && k != tail_b;
+    if (in_zone[k]) pend[k].assign(zstruct[k].begin(), zstruct[k].end());   // (the products took the rest of the zone out)
+    else pend[k] = upper[k];
+    self_inv[k] = !dinv_stored[k];
   }
   if (tail_a >= 0) pend[tail_a].clear();             // (the tail step takes A_ab x_b out of r_a)
   for (int k = 1; k < NB; ++k) ready[k] = pend[k].empty();
@@ -551,6 +553,34 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   if (lds_bytes(d, 1) > 160 * 1024) {
     err = "network too large for the general lane-group kernel (LDS)";
     return false;
+  }
+  return true;
+}
+
+// wavefronts a compute unit holds of a plan (LDS, registers)
+inline size_t waves_per_cu(const Dims& d) {
+  const int w = waves_per_block(d);
+  const size_t blocks = (160 * 1024) / lds_bytes(d, w);
+  return std::min<size_t>(MAX_WAVES_PER_CU, blocks * w);
+}
+
+// The plan of a network: the one with the fewest steps per Newton trip among the zones "from level z on" (no zone at
+// all, the last level, the last two ...; at most ZONE_CANDIDATES of them, stopping when three in a row bring nothing),
+// as long as the extra fill costs no wavefront on a compute unit.  Deterministic in the topology alone (parameter
+// classes of a model share their integer tables).
+constexpr int ZONE_CANDIDATES = 10;
+inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
+  if (!build_plan_zone(n, P, err, 1 << 30)) return false;
+  if (getenv("ANM_MESH_NO_ZONE")) return true;
+  const size_t base_waves = waves_per_cu(P.d);
+  const int top = P.d.zone_level;            // = the first level beyond the last one with a product step: no zone
+  int misses = 0;
+  for (int z = top - 1; z >= 0 && top - z <= ZONE_CANDIDATES && misses < 3; --z) {
+    Plan Q;
+    std::string e2;
+    if (!build_plan_zone(n, Q, e2, z)) break;               // (more fill than the LDS takes)
+    if (Q.d.n_steps < P.d.n_steps && waves_per_cu(Q.d) >= base_waves) { P = Q; misses = 0; }
+    else ++misses;
   }
   return true;
 }
