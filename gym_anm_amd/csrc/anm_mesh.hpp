@@ -81,6 +81,8 @@ constexpr int BR_SLOTS = 2;
 // s0 = the operation (0: the lane idles in this step).  Nothing a step reads is written in the same step by ANOTHER
 // lane, and D_k, A_ik, A_kj stay as they are (the factor L_ik = A_ik D_k^-1 is never stored: every product recomputes
 // it, lanes are plentiful), so the operations of a level may be dealt to the lanes in any number of rounds.
+// A ZONE of trailing levels is eliminated Gauss-Jordan style (build_plan_zone): there the product step of a pivot also
+// takes it out of the earlier rows of the zone, so those rows owe the column sweep the terms of the tail only.
 // (Rounds 2-4: the back substitution went row-wise -- x_k stored, up to four steps per level; products and sums were
 // two steps on every level; "fused levels", every contribution subtracted by its product operation two at a time, were
 // tried in round 3 and lost what they won to the longer steps: profiles/r03_n_mesh_fused_levels.txt.)

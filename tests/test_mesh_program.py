@@ -67,7 +67,17 @@ def test_networks_larger_than_a_wavefront(checker, n_bus, seed, n_chords, group)
 def test_program_lengths(checker):
     """What a Newton trip pays for is the number of fence-separated steps: products subtract the first contribution to a
     destination themselves (single-pivot levels are one step), the back substitution goes by columns along its
-    dependency chain (the row-wise form of rounds 2-3 took 12 / 11 / 59 / 67 steps for these four networks)"""
-    for net, most in ((networks.synthetic_meshed_network(30, 6, 4), 11), (networks.synthetic_radial_network(30, 0), 11),
-                      (networks.synthetic_meshed_network(64, 9, 20), 31), (networks.synthetic_meshed_network(200, 13, 30), 40)):
+    dependency chain, and a zone of trailing levels is eliminated Gauss-Jordan style when that shortens the program
+    (the row-wise form of rounds 2-3 took 12 / 11 / 59 / 67 steps for these four networks)"""
+    for net, most in ((networks.synthetic_meshed_network(30, 6, 4), 10), (networks.synthetic_radial_network(30, 0), 10),
+                      (networks.synthetic_meshed_network(64, 9, 20), 27), (networks.synthetic_meshed_network(200, 13, 30), 33)):
         assert _check(checker, net, 5)[0] <= most
+
+
+def test_no_zone_and_every_zone(checker, monkeypatch):
+    """the schedules the zone search chooses among: none (ANM_MESH_NO_ZONE) is valid too, and never shorter"""
+    nets = [networks.synthetic_meshed_network(20, 3, 6), networks.synthetic_meshed_network(30, 6, 4), networks.synthetic_meshed_network(100, 12, 16)]
+    chosen = [_check(checker, n, 7)[0] for n in nets]
+    monkeypatch.setenv("ANM_MESH_NO_ZONE", "1")
+    plain = [_check(checker, n, 7)[0] for n in nets]
+    assert all(c <= q for c, q in zip(chosen, plain)) and any(c < q for c, q in zip(chosen, plain))
