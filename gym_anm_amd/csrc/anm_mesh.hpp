@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <array>
+#include <map>
 #include <cstdlib>
 #include <set>
 #include <string>
@@ -150,7 +151,7 @@ inline bool fits(const anm_network_desc& n) {
 
 // Symbolic analysis + per-lane tables for one network; the levels from `zone_level` on are eliminated Gauss-Jordan
 // style (see "the ZONE" below; build_plan picks the level).
-inline bool build_plan_zone(const anm_network_desc& n, Plan& P, std::string& err, int zone_level) {
+inline bool build_plan_zone(const anm_network_desc& n, Plan& P, std::string& err, int zone_level, int c_max = 1 << 30) {
   if (!fits(n)) { err = "the general lane-group kernel takes networks of at most 513 buses, 1024 branches, 512 devices"; return false; }
   Dims& d = P.d;
   d.NB = n.n_bus; d.ND = n.n_dev; d.NBR = n.n_branch;
@@ -254,6 +255,32 @@ inline bool build_plan_zone(const anm_network_desc& n, Plan& P, std::string& err
         }
       for (int i : nb) level[i] = std::max(level[i], level[k] + 1);
     }
+  }
+  if (c_max < (1 << 30)) {
+    // at most c_max contributions per destination and level (1: no sums steps at all): a pivot moves to the first level
+    // at or after the one its dependencies give it where its contributions still fit (later is always allowed: what it
+    // reads is final, and the buses that wait for it are placed after it)
+    std::vector<int> lv2(NB, 0);
+    std::vector<std::map<std::pair<int, int>, int>> cnt;
+    for (int k : order) {
+      int lv = 0;
+      for (int q = 1; q < NB; ++q) {   // eliminated neighbours of k: those with k in their upper
+        if (q == k) continue;
+        for (int j : upper[q]) if (j == k) lv = std::max(lv, lv2[q] + 1);
+      }
+      for (;; ++lv) {
+        if (int(cnt.size()) <= lv) cnt.resize(lv + 1);
+        bool ok = true;
+        for (int i : upper[k]) {
+          for (int j : upper[k]) if (cnt[lv].count({i, j}) && cnt[lv][{i, j}] >= c_max) ok = false;
+          if (cnt[lv].count({i, NB}) && cnt[lv][{i, NB}] >= c_max) ok = false;
+        }
+        if (ok) break;
+      }
+      lv2[k] = lv;
+      for (int i : upper[k]) { for (int j : upper[k]) cnt[lv][{i, j}]++; cnt[lv][{i, NB}]++; }
+    }
+    level = lv2;
   }
   d.n_levels = 0;
   for (int i = 1; i < NB; ++i) d.n_levels = std::max(d.n_levels, level[i] + 1);
@@ -566,23 +593,31 @@ inline size_t waves_per_cu(const Dims& d) {
   return std::min<size_t>(MAX_WAVES_PER_CU, blocks * w);
 }
 
-// The plan of a network: the one with the fewest steps per Newton trip among the zones "from level z on" (no zone at
-// all, the last level, the last two ...; at most ZONE_CANDIDATES of them, stopping when three in a row bring nothing),
-// as long as the extra fill costs no wavefront on a compute unit.  Deterministic in the topology alone (parameter
+// The plan of a network: the program with the fewest steps per Newton trip among
+//   * the zones "from level z on" (none, the last level, the last two ...; a search down the levels stops when five in a
+//     row bring nothing), and
+//   * for each, levels as the dependencies give them (a destination may collect several contributions per level: one
+//     sums step per four of them) or levels that admit ONE contribution per destination (no sums steps at all: what
+//     trees like -- a 30-bus feeder 10 -> 7 steps),
+// as long as the extra fill costs no wavefront on a compute unit.  Deterministic in the topology alone (the parameter
 // classes of a model share their integer tables).
-constexpr int ZONE_CANDIDATES = 10;
 inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   if (!build_plan_zone(n, P, err, 1 << 30)) return false;
   if (getenv("ANM_MESH_NO_ZONE")) return true;
   const size_t base_waves = waves_per_cu(P.d);
-  const int top = P.d.zone_level;            // = the first level beyond the last one with a product step: no zone
-  int misses = 0;
-  for (int z = top - 1; z >= 0 && top - z <= ZONE_CANDIDATES && misses < 3; --z) {
-    Plan Q;
-    std::string e2;
-    if (!build_plan_zone(n, Q, e2, z)) break;               // (more fill than the LDS takes)
-    if (Q.d.n_steps < P.d.n_steps && waves_per_cu(Q.d) >= base_waves) { P = Q; misses = 0; }
-    else ++misses;
+  for (int c_max : {1 << 30, 1}) {
+    Plan Q0;
+    std::string e0;
+    if (!build_plan_zone(n, Q0, e0, 1 << 30, c_max)) continue;
+    if (Q0.d.n_steps < P.d.n_steps && waves_per_cu(Q0.d) >= base_waves) P = Q0;
+    int misses = 0;
+    for (int z = Q0.d.zone_level - 1; z >= 0 && misses < 5; --z) {   // (zone_level of "no zone" = one past the last product level)
+      Plan Q;
+      std::string e2;
+      if (!build_plan_zone(n, Q, e2, z, c_max)) break;             // (more fill than the LDS takes)
+      if (Q.d.n_steps < P.d.n_steps && waves_per_cu(Q.d) >= base_waves) { P = Q; misses = 0; }
+      else ++misses;
+    }
   }
   return true;
 }
