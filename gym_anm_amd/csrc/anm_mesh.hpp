@@ -1173,21 +1173,20 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     double* f = full + e * W_FS;
     if (isbus) {
       f[d.f_bus_p + bus] = bus_p; f[d.f_bus_q + bus] = bus_q;
-      f[d.f_bus_vm + bus] = hypot(vr, vi); f[d.f_bus_va + bus] = atan2(vi, vr);
-      f[d.f_bus_im + bus] = hypot(ir, ii); f[d.f_bus_ia + bus] = atan2(ii, ir);
+      f[d.f_bus_vm + bus] = dump_abs(vr, vi); f[d.f_bus_va + bus] = dump_arg(vi, vr);
+      f[d.f_bus_im + bus] = dump_abs(ir, ii); f[d.f_bus_ia + bus] = dump_arg(ii, ir);
     }
 #pragma unroll
     for (int sl = 0; sl < BR_SLOTS; ++sl)
       if (isbr[sl]) {
         const int b = sl * G + l;
         f[d.f_br_p + b] = br_pf[sl]; f[d.f_br_q + b] = br_qf[sl]; f[d.f_br_s + b] = br_s[sl];
-        const double mag = hypot(br_ifr[sl], br_ifi[sl]);
-        f[d.f_br_im + b] = (mag == 0.0) ? 0.0 : (br_ifr[sl] / mag) * mag;
-        f[d.f_br_ia + b] = atan2(br_ifi[sl], br_ifr[sl]);
+        f[d.f_br_im + b] = dump_signed_abs(br_ifr[sl], dump_abs(br_ifr[sl], br_ifi[sl]));
+        f[d.f_br_ia + b] = dump_arg(br_ifi[sl], br_ifr[sl]);
       }
     if (l == 0) {
       f[d.f_bus_p] = slack_p; f[d.f_bus_q] = slack_q; f[d.f_bus_vm] = 1.0; f[d.f_bus_va] = 0.0;
-      f[d.f_bus_im] = hypot(i0r, i0i); f[d.f_bus_ia] = atan2(i0i, i0r);
+      f[d.f_bus_im] = dump_abs(i0r, i0i); f[d.f_bus_ia] = dump_arg(i0i, i0r);
     }
     if (typ != DEV_NONE) { f[d.f_dev_p + l] = dev_p; f[d.f_dev_q + l] = dev_q; }
     if (typ == DEV_STORAGE) f[d.f_des_soc + slot] = soc;

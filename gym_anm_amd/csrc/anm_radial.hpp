@@ -654,24 +654,23 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (isbus) {
       const int b = l + 1;
       f[d.f_bus_p + b] = bus_p; f[d.f_bus_q + b] = bus_q;
-      f[d.f_bus_vm + b] = hypot(vr, vi); f[d.f_bus_va + b] = atan2(vi, vr);
-      f[d.f_bus_im + b] = hypot(ir, ii); f[d.f_bus_ia + b] = atan2(ii, ir);
+      f[d.f_bus_vm + b] = dump_abs(vr, vi); f[d.f_bus_va + b] = dump_arg(vi, vr);
+      f[d.f_bus_im + b] = dump_abs(ir, ii); f[d.f_bus_ia + b] = dump_arg(ii, ir);
       const int bi = RI(IF_BR_INDEX);
       f[d.f_br_p + bi] = br_pf; f[d.f_br_q + bi] = br_qf; f[d.f_br_s + bi] = br_s;
-      const double mag = hypot(br_ifr, br_ifi);
-      f[d.f_br_im + bi] = (mag == 0.0) ? 0.0 : (br_ifr / mag) * mag;
-      f[d.f_br_ia + bi] = atan2(br_ifi, br_ifr);
+      f[d.f_br_im + bi] = dump_signed_abs(br_ifr, dump_abs(br_ifr, br_ifi));
+      f[d.f_br_ia + bi] = dump_arg(br_ifi, br_ifr);
     }
     if (l == 0) {
       f[d.f_bus_p] = slack_p; f[d.f_bus_q] = slack_q; f[d.f_bus_vm] = 1.0; f[d.f_bus_va] = 0.0;
-      f[d.f_bus_im] = hypot(i0r, i0i); f[d.f_bus_ia] = atan2(i0i, i0r);
+      f[d.f_bus_im] = dump_abs(i0r, i0i); f[d.f_bus_ia] = dump_arg(i0i, i0r);
     }
     if (typ != DEV_NONE) { f[d.f_dev_p + l] = dev_p; f[d.f_dev_q + l] = dev_q; }
     if (typ == DEV_STORAGE) f[d.f_des_soc + slot] = soc;
     if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) f[d.f_gen_pmax + slot] = p_pot;
   };
 
-  // (one call site for the dump: its hypot / atan2 code exists once, not once per mode)
+  // (one call site for the dump: its |z| / arg z code exists once, not once per mode)
   bool dump = false;
   do {
   if (mode == 0) {
