@@ -199,12 +199,12 @@ struct LaneView {
 // holds, `it` iterations already done.  gvalid (uniform per group): the group holds a solve.  Every lane of
 // the wavefront must call.  On return: the final iterate, `it`, and the group's verdict in tb / tn
 // (tb != 0: ||F||inf > tol or NaN; tn != 0: F has a NaN).
-// LDSX (trees without a DPP plan; xl: 10 arrays of 64 doubles private to the wavefront): the hand-overs go
-// through LDS -- a lane PUBLISHES what its parent (or its children) will need in its own slot of an array, the
-// consumer reads the slot of the lane it needs -- instead of ds_bpermute: a pair of doubles is one
-// ds_write2/ds_read2 instead of four bpermutes, and the 5 child slots x 6 values of a bushy level cost 15 reads
-// instead of 60 bpermutes.  Padding lanes never publish; their slots hold the neutral values (zeroed here, V = 1).
-template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false>
+// LDSX (trees without a DPP plan; xl: 640 doubles private to the wavefront, 16-byte aligned): the hand-overs go
+// through LDS -- a lane PUBLISHES what its parent (or its children) will need in its own slot, the consumer reads
+// the slot of the lane it needs -- instead of ds_bpermute: a pair of doubles is one 16-byte write / read instead of
+// four bpermutes, and the 5 child slots x 6 values of a bushy level cost 15 reads instead of 60 bpermutes.
+// Padding lanes never publish; their slots hold the neutral values (zeroed here, V = 1).
+template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
                                               double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
                                               double tol, int max_iter, double* xl = nullptr) {
@@ -214,9 +214,17 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
   [[maybe_unused]] const int pl = X.psrc4 >> 2;                       // lane of the parent (or a padding lane)
   [[maybe_unused]] int cl[T::T_MAXCH > 0 ? T::T_MAXCH : 1];           // lanes of the children (or a padding lane)
   static_for<0, T::T_MAXCH>([&](auto Cc) { cl[Cc] = X.csrc4[Cc] >> 2; });
-  enum { XA_V = 0, XA_W = 2, XA_SC = 4, XA_LR = 8 };                  // V and the Newton step share arrays 0, 1
+  // LDS hand-overs: what a lane publishes sits TOGETHER in its slot -- (re, im) pairs and the six values a parent folds
+  // as 16-byte units -- so that every access is a ds_read_b128 / ds_write_b128: four LDS cycles per wavefront
+  // instruction where two 8-byte accesses 64 slots apart (ds_read2st64_b64, what separate arrays give) take eight.
+  // The 12 wavefronts of a compute unit share ONE LDS pipe, and this loop keeps it busier than any VALU.
+  //   xV[lane] = V (re, im), later the Newton step;  xW[lane] = W_pb;  xS[3 lane + 0 .. 2] = (Sc.a, Sc.b), (Sc.c, Sc.d), (Lr0, Lr1)
+  [[maybe_unused]] double2* const xV = reinterpret_cast<double2*>(xl);
+  [[maybe_unused]] double2* const xW = xV + 64;
+  [[maybe_unused]] double2* const xS = xV + 128;
   if constexpr (LDSX) {
-    static_for<XA_W, XA_LR + 2>([&](auto A) { xl[A * 64 + wl] = 0.0; });
+    xW[wl] = double2{0.0, 0.0};
+    xS[3 * wl] = double2{0.0, 0.0}; xS[3 * wl + 1] = double2{0.0, 0.0}; xS[3 * wl + 2] = double2{0.0, 0.0};
     ANM_WAVE_SYNC();
   }
   const int height = V.height, depth = V.depth, nch = V.nch;
@@ -244,9 +252,10 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       const double vr = vm * cs, vi = vm * sn;
       double vpr, vpi;
       if constexpr (LDSX) {
-        xl[XA_V * 64 + wl] = vr; xl[(XA_V + 1) * 64 + wl] = vi;
+        xV[wl] = double2{vr, vi};
         ANM_WAVE_SYNC();
-        vpr = xl[XA_V * 64 + pl]; vpi = xl[(XA_V + 1) * 64 + pl];
+        const double2 vp = xV[pl];
+        vpr = vp.x; vpi = vp.y;
       } else {
         vpr = X.from_parent(vr, 1.0); vpi = X.from_parent(vi, 0.0);
       }
@@ -259,13 +268,14 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       // S_b = W_bb + W_bp + sum over the children c of W_pb(c)
       double sr = wbb_r + wbp_r, si = wbb_i + wbp_i;
       if constexpr (LDSX) {
-        xl[XA_W * 64 + wl] = wpb_r; xl[(XA_W + 1) * 64 + wl] = wpb_i;
+        xW[wl] = double2{wpb_r, wpb_i};
         ANM_WAVE_SYNC();
       }
       static_for<0, T::T_MAXCH>([&](auto Cc) {
         double cr, ci;
         if constexpr (LDSX) {
-          cr = xl[XA_W * 64 + cl[Cc]]; ci = xl[(XA_W + 1) * 64 + cl[Cc]];
+          const double2 cw = xW[cl[Cc]];
+          cr = cw.x; ci = cw.y;
         } else {
           cr = X.template from_child<Cc>(wpb_r); ci = X.template from_child<Cc>(wpb_i);
         }
@@ -325,23 +335,20 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         if (height == h) {
           static_for<0, NC>([&](auto Cc) {
             if constexpr (LDSX) {
-              // ANM_LDSX_FETCH (3) child slots are fetched together, then folded (a padding lane's slots hold zeros):
+              // FETCH (3; 2 where the caller is short of registers) child slots are fetched together, then folded (a padding lane's slots hold zeros):
               // staging all NC slots costs up to 60 registers (and the third wavefront per SIMD), one slot at a time one
               // LDS latency per child
-              constexpr int F = ANM_LDSX_FETCH;
+              constexpr int F = FETCH;
               if constexpr (Cc % F == 0) {
                 constexpr int NF = (NC - Cc) < F ? (NC - Cc) : F;   // slots of this round
-                double qv[NF][6];
+                double2 qv[NF][3];
                 static_for<0, NF>([&](auto Q) {
-                  const int cq = cl[Cc + Q];
-                  static_for<0, 6>([&](auto A) {
-                    constexpr int arr = (A < 4) ? XA_SC + A : XA_LR + (A - 4);
-                    qv[Q][A] = xl[arr * 64 + cq];
-                  });
+                  const int cq = 3 * cl[Cc + Q];
+                  qv[Q][0] = xS[cq]; qv[Q][1] = xS[cq + 1]; qv[Q][2] = xS[cq + 2];
                 });
                 static_for<0, NF>([&](auto Q) {
-                  Dg.a -= JT(qv[Q][0]); Dg.b -= JT(qv[Q][1]); Dg.c -= JT(qv[Q][2]); Dg.d -= JT(qv[Q][3]);
-                  r0 -= JT(qv[Q][4]); r1 -= JT(qv[Q][5]);
+                  Dg.a -= JT(qv[Q][0].x); Dg.b -= JT(qv[Q][0].y); Dg.c -= JT(qv[Q][1].x); Dg.d -= JT(qv[Q][1].y);
+                  r0 -= JT(qv[Q][2].x); r1 -= JT(qv[Q][2].y);
                 });
               }
             } else if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
@@ -356,9 +363,9 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
             Lr0 = fm(Lk.a, r0, Lk.b * r1);
             Lr1 = fm(Lk.c, r0, Lk.d * r1);
             if constexpr (LDSX) {
-              xl[XA_SC * 64 + wl] = double(Sc.a); xl[(XA_SC + 1) * 64 + wl] = double(Sc.b);
-              xl[(XA_SC + 2) * 64 + wl] = double(Sc.c); xl[(XA_SC + 3) * 64 + wl] = double(Sc.d);
-              xl[XA_LR * 64 + wl] = double(Lr0); xl[(XA_LR + 1) * 64 + wl] = double(Lr1);
+              xS[3 * wl] = double2{double(Sc.a), double(Sc.b)};
+              xS[3 * wl + 1] = double2{double(Sc.c), double(Sc.d)};
+              xS[3 * wl + 2] = double2{double(Lr0), double(Lr1)};
             }
           }
         }
@@ -370,7 +377,8 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         JT p0 = JT(0), p1 = JT(0);
         if constexpr (dd > 0) {
           if constexpr (LDSX) {
-            p0 = JT(xl[XA_V * 64 + pl]); p1 = JT(xl[(XA_V + 1) * 64 + pl]);
+            const double2 dp = xV[pl];
+            p0 = JT(dp.x); p1 = JT(dp.y);
           } else {
             p0 = X.from_parent(d0, JT(0));
             p1 = X.from_parent(d1, JT(0));
@@ -384,7 +392,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           }
           d0 = fm(Dg.a, a0, Dg.b * a1);
           d1 = fm(Dg.c, a0, Dg.d * a1);
-          if constexpr (LDSX && dd < T::T_MAXD) { xl[XA_V * 64 + wl] = double(d0); xl[(XA_V + 1) * 64 + wl] = double(d1); }
+          if constexpr (LDSX && dd < T::T_MAXD) xV[wl] = double2{double(d0), double(d1)};
         }
         if constexpr (LDSX && dd < T::T_MAXD) ANM_WAVE_SYNC();
       });

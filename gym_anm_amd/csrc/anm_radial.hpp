@@ -247,7 +247,7 @@ struct IO {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
-enum { A_VR = 0, A_VI, A_UPR, A_UPI, A_S0, A_S1, A_S2, A_S3, A_L0, A_L1, A_N };  // LDS arrays
+enum { A_VR = 0, A_VI, A_UPR, A_UPI, A_S0, A_S1, A_N = 10 };  // LDS of a wavefront: 10 x 64 doubles (see k_radial)
 
 #ifndef ANM_RADIAL_WAVES
 #define ANM_RADIAL_WAVES 1
@@ -268,7 +268,17 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   const double* __restrict__ rd =
       PG ? rd0 + int64_t(cls.env_class[my_env < n_env ? my_env : 0]) * cls.stride
          : rd0 + int64_t(__builtin_amdgcn_readfirstlane(cls.env_class[(first_env < n_env ? first_env : 0) * cls.per_env])) * cls.stride;
-  __shared__ double sh[A_N][64];
+  // Hand-overs between the lanes of an environment go through LDS in 16-BYTE units -- (re, im) pairs, and the six values
+  // a parent folds as three of them -- so that every access is a ds_read_b128 / ds_write_b128 (four LDS cycles per
+  // wavefront instruction; two 8-byte accesses 64 slots apart, what separate arrays give, take eight): the wavefronts of
+  // a compute unit share ONE LDS pipe, and the Newton loop keeps it busier than any VALU (config 4: 82 -> 76 us).
+  //   pV[lane]: V;  pU[lane]: W_pb, later the Newton step;  pS[3 lane + 0 .. 2]: (Sc.a, Sc.b), (Sc.c, Sc.d), (Lr0, Lr1)
+  //   -- the layout group::newton_groups<.., LDSX> uses on the same memory.  What happens once per transition (device
+  //   sums before the loop, the currents after it) keeps plain arrays sh[A_*][lane] on that memory: the phases do not overlap.
+  __shared__ __align__(16) double sh[A_N][64];
+  double2* const pV = reinterpret_cast<double2*>(&sh[0][0]);
+  double2* const pU = pV + 64;
+  double2* const pS = pV + 128;
   __shared__ int sh_lists[256];  // children / bus-device index lists (read every Newton iteration)
   const int t = threadIdx.x;
   const int G = d.G;
@@ -456,9 +466,11 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     int git = 0;
     unsigned tb, tn;
     // (trees without a DPP plan hand over through the LDS arrays the table-driven loop would use)
-    static_assert(A_N >= 10, "group::newton_groups<.., LDSX> takes 10 arrays of 64 doubles");
-    group::newton_groups<TT, JT, 10, TT::T_DPP == 0>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn, so.tol,
-                                                      so.max_iter, &sh[0][0]);
+    static_assert(A_N >= 10, "group::newton_groups<.., LDSX> takes 640 doubles");
+    // (per-environment parameters cost this kernel nine registers: two child slots per fetch round instead of three keep
+    // it at three wavefronts per SIMD)
+    group::newton_groups<TT, JT, 10, TT::T_DPP == 0, PG ? 2 : ANM_LDSX_FETCH>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn,
+                                                                            so.tol, so.max_iter, &sh[0][0]);
     const int back4 = 4 * (gb + (isbus ? TT::T_POS[l + 1] : l));
     vm = group::bperm(gvm, back4); cs = group::bperm(gcs, back4); sn = group::bperm(gsn, back4);
     // iteration count and verdict are uniform over a group: every lane takes those of the lane playing bus 1
@@ -472,10 +484,10 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     // ---- V; the parent's V comes through LDS
     vr = vm * cs;
     vi = vm * sn;
-    sh[A_VR][t] = vr; sh[A_VI][t] = vi;
+    pV[t] = double2{vr, vi};
     ANM_GROUP_SYNC();
     vpr = 1.0; vpi = 0.0;
-    if (parent >= 0) { vpr = sh[A_VR][pl]; vpi = sh[A_VI][pl]; }
+    if (parent >= 0) { const double2 vp = pV[pl]; vpr = vp.x; vpi = vp.y; }
     // W_bb = conj(Y_bb) vm^2;  P = V_b conj(V_p): W_bp = conj(Y_bp) P, W_pb = conj(Y_pb) conj(P)
     const double m2 = vm * vm;
     const double wbb_r = ybb_r * m2, wbb_i = -(ybb_i * m2);
@@ -483,14 +495,13 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     const double wbp_r = fma(ybp_r, pr, ybp_i * pim), wbp_i = fma(ybp_r, pim, -(ybp_i * pr));
     wpb_r = fma(ypb_r, pr, -(ypb_i * pim));
     wpb_i = -fma(ypb_r, pim, ypb_i * pr);
-    sh[A_UPR][t] = wpb_r;
-    sh[A_UPI][t] = wpb_i;
+    pU[t] = double2{wpb_r, wpb_i};
     ANM_GROUP_SYNC();
     double sr = wbb_r + wbp_r, si = wbb_i + wbp_i;
     for (int k = ch_beg; k < ch_end; ++k) {
-      const int c = gb + lists[k];
-      sr += sh[A_UPR][c];
-      si += sh[A_UPI][c];
+      const double2 cw = pU[gb + lists[k]];
+      sr += cw.x;
+      si += cw.y;
     }
     // ---- mismatch; "||F||inf > tol" and "F has a NaN" over the group, on lane masks (as anm_group.hpp and anm_mesh.hpp:
     // two compares and a few scalar instructions instead of ten ds_bpermute butterflies): all the reference's loop
@@ -513,35 +524,36 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     for (int lev = d.max_depth; lev >= 0; --lev) {
       if (isbus && depth == lev) {
         for (int k = ch_beg; k < ch_end; ++k) {
-          const int c = gb + lists[k];
-          Dg.a -= JT(sh[A_S0][c]); Dg.b -= JT(sh[A_S1][c]); Dg.c -= JT(sh[A_S2][c]); Dg.d -= JT(sh[A_S3][c]);
-          r0 -= JT(sh[A_L0][c]); r1 -= JT(sh[A_L1][c]);
+          const int c = 3 * (gb + lists[k]);
+          const double2 q0 = pS[c], q1 = pS[c + 1], q2 = pS[c + 2];
+          Dg.a -= JT(q0.x); Dg.b -= JT(q0.y); Dg.c -= JT(q1.x); Dg.d -= JT(q1.y);
+          r0 -= JT(q2.x); r1 -= JT(q2.y);
         }
         Dg = blk_inv(Dg);
         if (parent >= 0) {
           const Blk<JT> Lk = blk_mul(Jpb, Dg);
           const Blk<JT> Sc = blk_mul(Lk, Jbp);
-          sh[A_S0][t] = double(Sc.a); sh[A_S1][t] = double(Sc.b); sh[A_S2][t] = double(Sc.c); sh[A_S3][t] = double(Sc.d);
-          sh[A_L0][t] = double(fm(Lk.a, r0, Lk.b * r1));
-          sh[A_L1][t] = double(fm(Lk.c, r0, Lk.d * r1));
+          pS[3 * t] = double2{double(Sc.a), double(Sc.b)};
+          pS[3 * t + 1] = double2{double(Sc.c), double(Sc.d)};
+          pS[3 * t + 2] = double2{double(fm(Lk.a, r0, Lk.b * r1)), double(fm(Lk.c, r0, Lk.d * r1))};
         }
       }
       ANM_GROUP_SYNC();
     }
-    // ---- back substitution, roots first (dx published in A_UPR/A_UPI)
+    // ---- back substitution, roots first (dx published in pU)
     JT d0 = JT(0), d1 = JT(0);
     for (int lev = 0; lev <= d.max_depth; ++lev) {
       if (isbus && depth == lev) {
         JT a0 = r0, a1 = r1;
         if (parent >= 0) {
-          const JT p0 = JT(sh[A_UPR][pl]), p1 = JT(sh[A_UPI][pl]);
+          const double2 dp = pU[pl];
+          const JT p0 = JT(dp.x), p1 = JT(dp.y);
           a0 = fm(-Jbp.b, p1, fm(-Jbp.a, p0, a0));
           a1 = fm(-Jbp.d, p1, fm(-Jbp.c, p0, a1));
         }
         d0 = fm(Dg.a, a0, Dg.b * a1);
         d1 = fm(Dg.c, a0, Dg.d * a1);
-        sh[A_UPR][t] = double(d0);
-        sh[A_UPI][t] = double(d1);
+        pU[t] = double2{double(d0), double(d1)};
       }
       ANM_GROUP_SYNC();
     }
