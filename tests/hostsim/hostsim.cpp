@@ -294,6 +294,12 @@ int anm_model_set_obs(anm_model*, int32_t n_obs, const int32_t*, const double*, 
   return n_obs > 0 ? fail("the host test double gathers with anm_gather_obs_f64") : 0;
 }
 
+// TEST HOOK (not part of the C ABI): |z| and arg z as the electrical-state dump forms them (csrc/anm_device.hpp: dump_abs,
+// dump_arg; on the host the division inside is the exact one, on the GPU a reciprocal + Newton sequence)
+void anm_hostsim_dump_abs_arg(int64_t n, const double* x, const double* y, double* mag, double* ang) {
+  for (int64_t i = 0; i < n; ++i) { mag[i] = anm::dump_abs(x[i], y[i]); ang[i] = anm::dump_arg(y[i], x[i]); }
+}
+
 int anm_gather_obs_f64(int64_t n, int32_t full_dim, const double* full, int32_t state_dim, int32_t K, const double* state,
                        const uint8_t* terminated, int32_t n_obs, const int32_t* index, const double* scale,
                        const double* low, const double* high, double* obs, void*) {

@@ -765,3 +765,30 @@ def test_convergence_flags_after_a_masked_reset():
 
 def test_general_step_with_rows_wider_than_the_default_lds_limit():
     pc.general_step_with_wide_rows(_KW)
+
+
+def test_dump_abs_and_arg_against_numpy():
+    """|z| and arg z of the electrical-state dump (csrc/anm_device.hpp: dump_abs, dump_arg -- one division and a degree-9
+    polynomial instead of hypot / atan2) against np.abs / np.angle (simulator.py:551-636) over the plane, on the axes, at
+    the origin and with NaNs."""
+    import ctypes as C
+
+    lib = hostsim_backend(NetworkModel(NETS["anm6"], 0.25, 100).topology()).lib
+    fn = lib.anm_hostsim_dump_abs_arg
+    fn.restype, fn.argtypes = None, [C.c_int64] + [C.POINTER(C.c_double)] * 4
+    rng = np.random.default_rng(7)
+    n = 400000
+    x = rng.normal(size=n) * 10.0 ** rng.uniform(-6, 6, size=n)
+    y = rng.normal(size=n) * 10.0 ** rng.uniform(-6, 6, size=n)
+    edge = np.array([[1, 0], [-1, 0], [0, 1], [0, -1], [0, 0], [1, 1], [-1, -1], [-1, 1], [1, -1], [1e-300, 1e-300], [3, 4],
+                     [np.tan(np.pi / 8), 1.0], [1.0, np.tan(np.pi / 8)], [np.nan, 1.0], [1.0, np.nan]], dtype=float)
+    x = np.concatenate((x, edge[:, 0])); y = np.concatenate((y, edge[:, 1]))
+    mag, ang = np.empty_like(x), np.empty_like(x)
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    fn(x.size, P(x), P(y), P(mag), P(ang))
+    z = x + 1j * y
+    fin = np.isfinite(x) & np.isfinite(y)
+    assert np.max(np.abs(ang[fin] - np.angle(z[fin]))) < 2e-15
+    big = fin & (np.maximum(np.abs(x), np.abs(y)) > 1e-150)   # (per-unit quantities: |z| is formed without scaling against underflow)
+    np.testing.assert_allclose(mag[big], np.abs(z[big]), rtol=1e-15, atol=0)
+    assert np.isnan(ang[~fin]).all() and np.isnan(mag[~fin]).all()
