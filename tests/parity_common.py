@@ -944,3 +944,28 @@ def per_environment_networks(kw, impl, n_variants=24, E_=192, n_check=48):
             npt.assert_allclose(obs[e].cpu().numpy(), oo, rtol=0, atol=1e-8)
             npt.assert_allclose(float(rew[e]), rr, rtol=1e-9, atol=1e-9)
     return sim
+
+
+def structured_network(shape):
+    """Shapes the random feeders do not produce (bus 0 the slack; devices of the random feeder of the same size): a hub
+    with 20 leaves, a ring, a path, a complete graph, five feeders off the slack, a ladder of two coupled chains."""
+    n = {"star": 22, "ring": 17, "path": 25, "complete": 8, "feeders": 21, "ladder": 21}[shape]
+    if shape == "star":
+        edges = [(0, 1)] + [(1, i) for i in range(2, n)]
+    elif shape == "ring":
+        edges = [(0, 1)] + [(i, i + 1) for i in range(1, n - 1)] + [(n - 1, 1)]
+    elif shape == "path":
+        edges = [(i, i + 1) for i in range(n - 1)]
+    elif shape == "complete":
+        edges = [(0, 1)] + [(i, j) for i in range(1, n) for j in range(i + 1, n)]
+    elif shape == "feeders":
+        edges = [(0, 1 + 4 * k) for k in range(5)] + [(1 + 4 * k + j, 2 + 4 * k + j) for k in range(5) for j in range(3)]
+    else:
+        half = (n - 1) // 2
+        edges = [(0, 1)] + [(i, i + 1) for i in range(1, half)] + [(half + i, half + i + 1) for i in range(1, half)] + \
+                [(i, half + i) for i in range(1, half + 1)]
+    net = networks.synthetic_radial_network(n, 1)
+    rng = np.random.default_rng(5)
+    net["branch"] = np.array([[f, t, float(rng.uniform(0.005, 0.03)), float(rng.uniform(0.03, 0.08)), 0.0, 30.0, 1, 0]
+                              for f, t in edges])
+    return net

@@ -347,15 +347,27 @@ def test_mesh_networks_larger_than_a_wavefront_against_oracle(n_bus, seed, n_cho
     assert sim.backend.lib.anm_model_lanes_per_env(sim._handle) == group
 
 
-def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeless):
+@pytest.mark.parametrize("shape", ["star", "ring", "path", "complete", "feeders", "ladder"])
+def test_mesh_structured_topologies_against_oracle(shape):
+    """Shapes the random feeders do not produce (parity_common.structured_network: a hub with 20 leaves, a ring, a path, a
+    complete graph, five feeders off the slack, a ladder) through the general lane-group kernel, case by case against
+    the oracle: each stresses another corner of the step program (many contributions to one block, chains, a dense
+    end that is the whole network, several elimination roots)."""
+    net = pc.structured_network(shape)
+    _mesh_network_against_oracle(len(net["bus"]), 3, 0, 64, 0.5, 2, net=net)
+
+
+def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeless, net=None):
     import anm_oracle as O
     from gym_anm_amd import networks
     from gym_anm_amd.model import NetworkModel
     from gym_anm_amd.simulator import BatchedSimulator
 
-    net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if n_chords else networks.synthetic_radial_network(n_bus, seed)
+    if net is None:
+        net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if n_chords else networks.synthetic_radial_network(n_bus, seed)
     model = NetworkModel(net, 0.25, 100)
-    sim = BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl="mesh" if n_bus <= 12 else None)
+    tree = len(net["branch"]) == len(net["bus"]) - 1
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl="mesh" if (n_bus <= 12 or tree) else None)
     assert sim.impl == "mesh"
     npt.assert_allclose(sim.device_ybus(), model.Y_bus, rtol=1e-15, atol=0)
     rng = np.random.default_rng(seed)

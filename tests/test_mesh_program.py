@@ -81,3 +81,16 @@ def test_no_zone_and_every_zone(checker, monkeypatch):
     monkeypatch.setenv("ANM_MESH_NO_ZONE", "1")
     plain = [_check(checker, n, 7)[0] for n in nets]
     assert all(c <= q for c, q in zip(chosen, plain)) and any(c < q for c, q in zip(chosen, plain))
+
+
+@pytest.mark.parametrize("shape", ["star", "ring", "path", "complete", "feeders", "ladder"])
+def test_structured_topologies(checker, shape):
+    """shapes the random feeders do not produce (tests/parity_common.py: structured_network): a hub with 20 leaves (one
+    level, many contributions to ONE diagonal block), a ring and a path (chains compressed level by level), a complete
+    graph (everything is the dense end), five feeders off the slack (several elimination roots: no common tail), a ladder"""
+    import parity_common as pc
+
+    net = pc.structured_network(shape)
+    for seed in range(3):
+        steps, levels, group = _check(checker, net, 100 + seed)
+        assert steps <= 3 * levels + 6
