@@ -466,6 +466,19 @@ def test_random_radial_networks_generic_lane_group_kernel(n_bus, seed):
     assert n_conv >= 20
 
 
+@pytest.mark.parametrize("shape", ["star", "path", "feeders"])
+def test_structured_trees_generic_lane_group_kernel(shape):
+    """Trees the random feeders do not produce -- a hub with 20 leaves (one parent folds 20 children), a path of 24
+    buses (as many levels as buses), five feeders off the slack (five roots) -- through the table-driven radial kernel."""
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    net = pc.structured_network(shape)
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=128, device=DEV, impl="radial")
+    assert sim.impl == "radial"
+    npt.assert_allclose(sim.device_ybus(), sim.model.Y_bus, rtol=1e-15, atol=0)
+    assert _compare_with_oracle(sim, net, _random_inputs(sim, 3), 40) >= 10
+
+
 @pytest.mark.parametrize("n_bus,seed", [(4, 11), (7, 12)])
 def test_new_topology_is_compiled_on_first_use(n_bus, seed):
     """A topology without a prebuilt library is specialised with hipcc on first use
