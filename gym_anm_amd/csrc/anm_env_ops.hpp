@@ -690,20 +690,30 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   // ---- coalesced stores of the state and obs rows
   auto store_rows = [&](double* gbase, const double* row, bool wr) {
     const unsigned long long mask = __ballot(wr && store);
+    if (mask == 0ull) return;   // no row of this wavefront is written (the state rows that equal their obs rows: the usual case)
     static_for<0, S>([&](auto K) { lds[lane * SP + K] = row[K]; });
     ANM_WAVE_SYNC();
     // element j*64 + lane of the block is (row l, column k); all LDS reads first, then the stores
     double v[S];
-    bool on[S];
-    static_for<0, S>([&](auto J) {
-      const int idx = J * 64 + lane;
-      const int l = idx / S, k = idx - l * S;
-      v[J] = lds[l * SP + k];
-      on[J] = ((mask >> l) & 1ull) != 0;
-    });
-    static_for<0, S>([&](auto J) {
-      if (on[J]) gbase[J * 64 + lane] = v[J];
-    });
+    if (mask == ~0ull) {        // every row is written (the obs rows of a full wavefront): no per-element predicate
+      static_for<0, S>([&](auto J) {
+        const int idx = J * 64 + lane;
+        const int l = idx / S, k = idx - l * S;
+        v[J] = lds[l * SP + k];
+      });
+      static_for<0, S>([&](auto J) { gbase[J * 64 + lane] = v[J]; });
+    } else {
+      bool on[S];
+      static_for<0, S>([&](auto J) {
+        const int idx = J * 64 + lane;
+        const int l = idx / S, k = idx - l * S;
+        v[J] = lds[l * SP + k];
+        on[J] = ((mask >> l) & 1ull) != 0;
+      });
+      static_for<0, S>([&](auto J) {
+        if (on[J]) gbase[J * 64 + lane] = v[J];
+      });
+    }
     ANM_WAVE_SYNC();
   };
   store_rows(io.state + e0 * S, out.state, out.write_state && !state_dup);
