@@ -600,6 +600,13 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   StepCtx<T> ctx;
   PFState<T> st;
   EnvWork<T> w;
+  // the per-environment scalars first: their loads are then in flight together with the action rows (behind the fences
+  // of the transposition below they would wait for a second trip to memory)
+  in.was_term = io.terminated[ec] != 0;
+  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
+  in.aux_prev = double(io.aux_index[ec]);
+  in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
+  const int32_t ts_prev = io.timestep ? io.timestep[ec] : 0;  // read now: the epilogue only stores
   // ---- coalesced loads: 64 x ADIM doubles of actions
   {
     const double* g = io.action + e0 * D::ADIM;
@@ -621,11 +628,6 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
     static_for<0, D::ADIM>([&](auto I) { in.action[I] = lds[lr * AP + I]; });
     ANM_WAVE_SYNC();
   }
-  in.was_term = io.terminated[ec] != 0;
-  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
-  in.aux_prev = double(io.aux_index[ec]);
-  in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
-  const int32_t ts_prev = io.timestep ? io.timestep[ec] : 0;  // read now: the epilogue only stores
 
   const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
   step_begin<T, JT>(C, C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
