@@ -126,18 +126,108 @@ def transition_figure(dev, net, E, cap, n, load_scale=1.0, note=""):
 
 
 def case30_side_figure(dev, E=16384, n=20):
+    """BASELINE.json config 4: the synthetic random radial 30-bus feeder (seed 0), 16 384 transitions per launch, the
+    reference's cap and a cap of 20.  Every rank measures it on its own GPU (main reduces: sum of rates, slowest launch)."""
     from gym_anm_amd import networks
 
     out = {}
     for cap in (100, 20):
         out["case30_radial_16384_cap%d" % cap] = transition_figure(dev, networks.synthetic_radial_network(30, 0), E, cap, n)
-    # the general lane-group family: a meshed 30-bus network inside a wavefront, a meshed 200-bus network as one
-    # workgroup of 256 lanes per environment (loads scaled with 40 / n_bus: the synthetic feeders carry the same load
-    # per bus whatever their size)
+    return out
+
+
+def mesh_side_figure(dev, E=16384, n=20):
+    """the general lane-group family: a meshed 30-bus network inside a wavefront, a meshed 200-bus network as one
+    workgroup of 256 lanes per environment (loads scaled with 40 / n_bus: the synthetic feeders carry the same load
+    per bus whatever their size)"""
+    from gym_anm_amd import networks
+
+    out = {}
     out["mesh30_16384_cap100"] = transition_figure(dev, networks.synthetic_meshed_network(30, 6, 4), E, 100, n,
-                                                   note="; LDS-bound (block-sparse Jacobian in LDS), see DESIGN.md 4.6")
+                                                   note="; LDS-bound (block-sparse Jacobian in LDS), see DESIGN.md")
     out["mesh200_4096_cap100"] = transition_figure(dev, networks.synthetic_meshed_network(200, 13, 30), 4096, 100, max(4, n // 4), 40.0 / 200,
-                                                   note="; one workgroup of 256 lanes per environment, see DESIGN.md 4.6")
+                                                   note="; one workgroup of 256 lanes per environment, see DESIGN.md")
+    return out
+
+
+def _timed_env_steps(env, pool, n, dev):
+    for i in range(10):
+        env.step(pool[i % len(pool)])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(n):
+        env.step(pool[i % len(pool)])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n, ev0.elapsed_time(ev1) * 1e-3 / n
+
+
+def baseline_configs_side_figure(dev, args, n=100):
+    """The BASELINE.json configurations the headline does not cover, each as a timed line of this run:
+    config 2 -- ANM6Easy, 4 096 environments, fp64 (one wavefront on one SIMD in sixteen: a latency figure);
+    config 3 -- ANM6Easy, 65 536 environments with the Jacobian + LU in fp32 (mismatch, stop test and update stay fp64),
+    timed like the headline, plus the tolerance report: the same 65 536 seeded transitions through the fp64 and the fp32
+    solve -- largest deviation of |V|, theta and the branch flows, flag mismatches, iteration histograms."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import ANM6EasyVec
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    out = {}
+    nbytes = algorithmic_bytes_per_env_step(6, 18, 1, 1)
+    for key, E, prec in (("anm6easy_4096", 4096, "f64"), ("anm6easy_65536_f32", 65536, "f32")):
+        env = ANM6EasyVec(num_envs=E, device=dev, seed=4321, tol=args.tol, max_iter=args.max_iter, precision=prec, autoreset=True)
+        env.check_actions = False
+        env.reset(seed=4321)
+        gen = torch.Generator(device=dev).manual_seed(17)
+        lo, hi = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
+        pool = [lo + (hi - lo) * torch.rand((E, 6), generator=gen, dtype=torch.float64, device=dev) for _ in range(8)]
+        wall, evs = _timed_env_steps(env, pool, n, dev)
+        out[key] = {"env_steps_per_s": E / wall, "us_per_step": wall * 1e6, "us_per_step_events": evs * 1e6,
+                    "dtype": "f64" if prec == "f64" else "f64 (f32 Jacobian/LU)", "nr_tol": args.tol, "nr_max_iter": args.max_iter,
+                    "roofline": {"bound": "hbm", "achieved": nbytes * E / evs / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": nbytes * E / evs / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_env_step": nbytes}}
+        del env
+    # tolerance report of config 3 (Simulator.transition with the electrical-state dump, same inputs, both precisions)
+    E = 65536
+    res = {}
+    for prec in ("f64", "f32"):
+        sim = BatchedSimulator(networks.anm6_network(), 0.25, 100, num_envs=E, device=dev, tol=args.tol, max_iter=args.max_iter,
+                               precision=prec)
+        m, b = sim.model, sim.model.baseMVA
+        g = torch.Generator(device=dev).manual_seed(0)
+
+        def U(lo, hi):
+            lo, hi = torch.as_tensor(lo, device=dev), torch.as_tensor(hi, device=dev)
+            return lo + (hi - lo) * torch.rand((E, lo.numel()), generator=g, dtype=torch.float64, device=dev)
+
+        pl = U(m.dev_p_min[m.load_idx] * b, 0 * m.dev_p_min[m.load_idx])
+        pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * b)
+        ps = U(m.dev_p_min[m.setp_idx] * b, m.dev_p_max[m.setp_idx] * b)
+        qs = U(m.dev_q_min[m.setp_idx] * b, m.dev_q_max[m.setp_idx] * b)
+        sim.soc.copy_(U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx]))
+        st, _, _, _, conv = sim.transition(pl, pp, ps, qs)
+        res[prec] = {"vm": st.tensor("bus_v_magn", "pu").clone(), "va": st.tensor("bus_v_ang", "rad").clone(),
+                     "bp": st.tensor("branch_p", "pu").clone(), "bq": st.tensor("branch_q", "pu").clone(),
+                     "bs": st.tensor("branch_s", "pu").clone(), "conv": conv.clone(), "it": sim.nr_iters.clone()}
+        del sim
+    a, c = res["f64"], res["f32"]
+    both = a["conv"] & c["conv"]
+
+    def hist(t):
+        v, n_ = torch.unique(t[both], return_counts=True)
+        return {str(int(k)): int(x) for k, x in zip(v.tolist(), n_.tolist())}
+
+    out["anm6easy_65536_f32"]["tolerance_report"] = {
+        "transitions": E, "converged_f64": int(a["conv"].sum()), "converged_f32": int(c["conv"].sum()),
+        "flag_mismatches": int((a["conv"] != c["conv"]).sum()),
+        "max_abs_dV_pu": float((a["vm"] - c["vm"]).abs()[both].max()), "max_abs_dtheta_rad": float((a["va"] - c["va"]).abs()[both].max()),
+        "max_abs_dbranch_p_pu": float((a["bp"] - c["bp"]).abs()[both].max()), "max_abs_dbranch_q_pu": float((a["bq"] - c["bq"]).abs()[both].max()),
+        "max_abs_dbranch_s_pu": float((a["bs"] - c["bs"]).abs()[both].max()),
+        "nr_iters_hist_f64": hist(a["it"]), "nr_iters_hist_f32": hist(c["it"]),
+        "note": "same seeded inputs through Simulator.transition with the Jacobian + LU in fp64 and in fp32; deviations over the "
+                "transitions both solves converged on; BASELINE asks for 1e-6 p.u. against the reference"}
     return out
 
 
@@ -223,7 +313,13 @@ def mpc_side_figure(dev):
     return out
 
 
-def main():
+# --------------------------------------------------------------------------------------------
+# Ranks.  One process per GPU; the environment batch is sharded contiguously, no data-path collective.
+# `python bench.py --gpus N` starts its own ranks (torch.distributed.run) when it was not started by a launcher;
+# everything about ranks that does not need a GPU is in the functions below so that the CPU tier can drive it with
+# two gloo ranks (tests/test_bench_launcher.py).
+# --------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -240,44 +336,137 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary figures (cap-20, case30) so that a rocprofv3 trace of this command holds "
                          "only launches of the headline configuration")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the simulator has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    rccl_ranks = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank)
-        import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        # RCCL really spans `world` ranks: one all-reduce of ones must come back as the world size
-        ones = torch.ones(1, dtype=torch.float64, device=dev)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        rccl_ranks = int(round(float(ones.item())))
-        if rccl_ranks != world or dist.get_world_size() != world:
-            raise SystemExit("RCCL sees %d ranks (get_world_size %d), expected %d" % (rccl_ranks, dist.get_world_size(), world))
+def rank_info(environ=None):
+    """(rank, local_rank, world, launched): what torch.distributed.run put in the environment (launched = it did)."""
+    env = os.environ if environ is None else environ
+    return (int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), int(env.get("WORLD_SIZE", "1")),
+            "RANK" in env and "WORLD_SIZE" in env)
 
-    from gym_anm_amd.envs import ANM6EasyVec
 
-    scaling = "weak"
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch_command(n, script, argv):
+    """`python bench.py --gpus N ...` typed without a launcher: the same command under torch.distributed.run, one rank
+    per GPU of this node, rendezvous on 127.0.0.1 (what the driver's own multi-GPU command line looks like)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+            "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+
+
+def self_launch(n, script=None, argv=None):
+    import subprocess
+
+    cmd = self_launch_command(n, os.path.abspath(script or sys.argv[0]), sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL on this pool: dmabuf IPC only
+    return subprocess.call(cmd, env=env)
+
+
+def shard(args, world, rank):
+    """environments of this rank, global index of its first one, scaling mode"""
     if args.global_envs:
         if args.global_envs % world:
             raise SystemExit("--global-envs %d is not a multiple of the %d ranks" % (args.global_envs, world))
-        args.num_envs = args.global_envs // world
-        scaling = "strong"
-    E = args.num_envs
-    env = ANM6EasyVec(num_envs=E, device=dev, seed=1234, tol=args.tol, max_iter=args.max_iter,
-                      precision=args.precision, autoreset=True, env_offset=rank * E)  # fmt: skip
+        per = args.global_envs // world
+        return per, rank * per, "strong"
+    return args.num_envs, rank * args.num_envs, "weak"
+
+
+class Comm:
+    """The reporting collectives (nothing else crosses ranks): barrier, MAX and SUM of a few scalars."""
+
+    def __init__(self, backend, rank, world, device, launched):
+        self.dist, self.rank, self.world, self.device, self.ranks_seen = None, rank, world, device, None
+        if world > 1 or launched:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"device_id": device} if device.type == "cuda" else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            self.dist = dist
+            # the communicator really spans `world` ranks: one all-reduce of ones must come back as the world size
+            self.ranks_seen = int(round(self.reduce([1.0], "sum")[0]))
+            if self.ranks_seen != world or dist.get_world_size() != world:
+                raise SystemExit("the communicator sees %d ranks (get_world_size %d), expected %d"
+                                 % (self.ranks_seen, dist.get_world_size(), world))
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def reduce(self, values, op):
+        """element-wise SUM / MAX over the ranks of a short list of floats (the same list on every rank afterwards)"""
+        if self.dist is None:
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def reduce_side_figure(comm, fig):
+    """A per-rank side figure {name: {"env_steps_per_s", "us_per_launch", ...}} measured by EVERY rank on its own GPU
+    -> the job's figure: rates summed, launch times the slowest rank's; the rank-0 entry keeps its other fields."""
+    names = sorted(fig)
+    rates = comm.reduce([fig[k]["env_steps_per_s"] for k in names], "sum")
+    slow = comm.reduce([fig[k]["us_per_launch"] for k in names], "max")
+    out = {}
+    for k, r, u in zip(names, rates, slow):
+        out[k] = dict(fig[k])
+        out[k]["env_steps_per_s"] = r
+        out[k]["us_per_launch"] = u
+        out[k]["ranks"] = comm.world
+        if comm.world > 1 and "roofline" in out[k]:
+            rl = dict(out[k]["roofline"])
+            rl["note"] = rl.get("note", "") + "; roofline of rank 0's GPU, env_steps_per_s summed over the ranks, us_per_launch the slowest rank's"
+            out[k]["roofline"] = rl
+    return out
+
+
+def default_make_env(num_envs, device, args, env_offset, seed):
+    from gym_anm_amd.envs import ANM6EasyVec
+
+    return ANM6EasyVec(num_envs=num_envs, device=device, seed=seed, tol=args.tol, max_iter=args.max_iter,
+                       precision=args.precision, autoreset=True, env_offset=env_offset)  # fmt: skip
+
+
+def main(argv=None, make_env=None, backend="nccl", device_type="cuda", script=None):
+    """make_env / backend / device_type: the CPU tier's launcher test passes the host test double, "gloo" and "cpu";
+    the benchmark itself never does (no flag selects them)."""
+    args = parse_args(argv)
+    rank, local_rank, world, launched = rank_info()
+    if not launched and args.gpus > 1:
+        # typed as `python bench.py --gpus N`: start one rank per GPU and let rank 0 print the line
+        raise SystemExit(self_launch(args.gpus, script, argv))
+    if world != args.gpus:
+        args.gpus = world
+    gpu = device_type == "cuda"
+    if gpu and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the simulator has no CPU path")
+    if gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if gpu else torch.device("cpu")
+    comm = Comm(backend, rank, world, dev, launched)
+    rccl_ranks = comm.ranks_seen
+
+    E, env_offset, scaling = shard(args, world, rank)
+    env = (make_env or default_make_env)(E, dev, args, env_offset, 1234)
     env.check_actions = False  # the Box check is a device reduction + host sync; actions are in the Box by construction
     env.reset(seed=1234 + rank)
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -286,61 +475,68 @@ def main():
     n_pool = 16
     pool = [lo + (hi - lo) * torch.rand((E, 6), generator=gen, dtype=torch.float64, device=dev) for _ in range(n_pool)]
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     for i in range(args.warmup):
         env.step(pool[i % n_pool])
     iters_sum = torch.zeros((), dtype=torch.float64, device=dev)
     term_sum = torch.zeros((), dtype=torch.float64, device=dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
+    if gpu:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    comm.barrier()
     t0 = time.perf_counter()
-    ev0.record()  # torch's current stream == the stream every step kernel is launched on (_step_call)
+    if gpu:
+        ev0.record()  # torch's current stream == the stream every step kernel is launched on (_step_call)
     for i in range(args.steps):
         env.step(pool[i % n_pool])
-    ev1.record()
-    barrier()
+    if gpu:
+        ev1.record()
+    comm.barrier()
     elapsed = time.perf_counter() - t0
-    step_events_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps  # HIP events over the timed region: kernel + launch gap
+    # HIP events over the timed region: kernel + launch gap
+    step_events_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps if gpu else elapsed / args.steps
     # statistics of the workload (outside the timed region)
     for i in range(8):
         env.step(pool[i % n_pool])
         iters_sum += env.simulator.nr_iters.double().mean()
         term_sum += env.terminated.double().mean()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        total = torch.tensor([float(E * args.steps)], dtype=torch.float64, device=dev)
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)
-        total_steps = float(total.item())
-    else:
-        total_steps = float(E * args.steps)
-    elapsed = float(t.item())
-
-    # cross-check: the same launch issued back to back from C (no Python between launches), HIP events
-    # on the launch stream; one fixed action batch
-    import ctypes as C
+    elapsed = comm.reduce([elapsed], "max")[0]                       # the slowest rank's clock
+    total_steps = comm.reduce([float(E * args.steps)], "sum")[0]     # the units all ranks processed
 
     sim = env.simulator
-    ms = C.c_float(0.0)
-    n_launch = max(50, min(args.steps, 400))
-    with torch.cuda.device(dev):
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rc = sim.backend.lib.anm_time_step_launches(
-            sim._handle, E, pool[0].data_ptr(), sim.soc.data_ptr(), env._state_buf.data_ptr(), env._term_u8.data_ptr(),
-            env.timestep.data_ptr(), env._state_obs.data_ptr(), env.reward.data_ptr(), env.e_loss.data_ptr(),
-            env.penalty.data_ptr(), 1, env.rng_seed, env.env_offset, env._reset_count.data_ptr(), env._aux_index_ptr,
-            env._ws_ref, C.byref(sim.opts), stream,
-            n_launch, C.byref(ms),
-        )  # fmt: skip
-    sim.backend.check(rc, "anm_time_step_launches")
-    # the kernel's own duration: launches issued back to back from C, HIP events on the launch stream around them
-    # (nothing between two launches; agrees with the rocprofv3 kernel-trace average, profiles/).  The events over the
-    # timed region above additionally hold the gap the Python caller leaves between two launches.
-    kernel_s = ms.value * 1e-3
+    kernel_s = step_events_s
+    n_launch = args.steps
+    if gpu:
+        # cross-check: the same launch issued back to back from C (no Python between launches), HIP events
+        # on the launch stream; one fixed action batch
+        import ctypes as C
+
+        ms = C.c_float(0.0)
+        n_launch = max(50, min(args.steps, 400))
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = sim.backend.lib.anm_time_step_launches(
+                sim._handle, E, pool[0].data_ptr(), sim.soc.data_ptr(), env._state_buf.data_ptr(), env._term_u8.data_ptr(),
+                env.timestep.data_ptr(), env._state_obs.data_ptr(), env.reward.data_ptr(), env.e_loss.data_ptr(),
+                env.penalty.data_ptr(), 1, env.rng_seed, env.env_offset, env._reset_count.data_ptr(), env._aux_index_ptr,
+                env._ws_ref, C.byref(sim.opts), stream,
+                n_launch, C.byref(ms),
+            )  # fmt: skip
+        sim.backend.check(rc, "anm_time_step_launches")
+        # the kernel's own duration: launches issued back to back from C, HIP events on the launch stream around them
+        # (nothing between two launches; agrees with the rocprofv3 kernel-trace average, profiles/).  The events over the
+        # timed region above additionally hold the gap the Python caller leaves between two launches.
+        kernel_s = ms.value * 1e-3
+
+    def timed_steps(n):
+        for i in range(10):
+            env.step(pool[i % n_pool])
+        if gpu:
+            torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(n):
+            env.step(pool[i % n_pool])
+        if gpu:
+            torch.cuda.synchronize(dev)
+        return time.perf_counter() - t1
 
     # secondary figure: same workload with a 20-iteration cap.  Diverging solves (the only ones that
     # ever exceed ~8 iterations) are then cut off early; on every sample tested the terminated flags
@@ -349,14 +545,7 @@ def main():
     alt = None
     if rank == 0 and args.max_iter == 100 and not args.headline_only:
         sim.opts.max_iter = 20
-        for i in range(10):
-            env.step(pool[i % n_pool])
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            env.step(pool[i % n_pool])
-        torch.cuda.synchronize(dev)
-        alt_elapsed = time.perf_counter() - t1
+        alt_elapsed = timed_steps(args.steps)
         alt = {"nr_max_iter": 20, "value_1gpu": E * args.steps / alt_elapsed, "ms_per_step": 1e3 * alt_elapsed / args.steps}
         sim.opts.max_iter = args.max_iter
 
@@ -364,28 +553,30 @@ def main():
     alt_tol = None
     if rank == 0 and args.tol != 1e-5 and not args.headline_only:
         sim.opts.tol = 1e-5
-        for i in range(10):
-            env.step(pool[i % n_pool])
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            env.step(pool[i % n_pool])
-        torch.cuda.synchronize(dev)
-        dt1 = time.perf_counter() - t1
+        dt1 = timed_steps(args.steps)
         alt_tol = {"nr_tol": 1e-5, "nr_max_iter": args.max_iter, "value_1gpu": E * args.steps / dt1,
                    "ms_per_step": 1e3 * dt1 / args.steps, "mean_nr_iters": float(sim.nr_iters.double().mean())}
         sim.opts.tol = args.tol
 
-    # BASELINE.json config 4 as a side figure (not the headline): 30-bus radial feeder, 16384 envs,
-    # Simulator.transition with the full electrical-state dump, lane-group kernel family.
+    # Side figures.  BASELINE.json config 4 (30-bus radial feeder, 16384 transitions per launch, lane-group family) is
+    # measured by EVERY rank on its own GPU (north_star: "larger random radial networks at 1/2/4/8 GPUs") and reported
+    # as sum of rates / slowest launch like the headline; the others (one-GPU configurations) by rank 0 of a 1-GPU run.
     other = None
-    if rank == 0 and world == 1 and not args.headline_only:
+    if gpu and not args.headline_only:
         other = {}
-        for fig in (lambda: case30_side_figure(dev), lambda: throughput_side_figure(dev, args), lambda: mpc_side_figure(dev)):
-            try:
-                other.update(fig())
-            except Exception as ex:  # never let a side figure break the headline line
-                other.setdefault("errors", []).append(str(ex)[:200])
+        try:
+            fig = case30_side_figure(dev)
+        except Exception as ex:  # never let a side figure break the headline line (every rank must still reduce)
+            fig = {"case30_radial_16384_cap%d" % c: {"env_steps_per_s": 0.0, "us_per_launch": 0.0, "error": str(ex)[:200]}
+                   for c in (100, 20)}
+        other.update(reduce_side_figure(comm, fig))
+        if rank == 0 and world == 1:
+            for f in (lambda: mesh_side_figure(dev), lambda: throughput_side_figure(dev, args),
+                      lambda: baseline_configs_side_figure(dev, args), lambda: mpc_side_figure(dev)):
+                try:
+                    other.update(f())
+                except Exception as ex:
+                    other.setdefault("errors", []).append(str(ex)[:200])
 
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(6, 18, 1, 1)
@@ -398,7 +589,7 @@ def main():
         valu = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt["num_envs"] == E and pt["nr_max_iter"] == args.max_iter and pt["precision"] == args.precision:
+            if gpu and pt["num_envs"] == E and pt["nr_max_iter"] == args.max_iter and pt["precision"] == args.precision:
                 traffic = pt["hbm_bytes_per_launch"]
                 traffic_source = "profiles/pmc_traffic.json (%s): PMC passes of an earlier run of this configuration, not of this run" % pt.get("source", "?")
                 # what really bounds the kernel: fp64 VALU issue.  A wave64 fp64 instruction occupies its
@@ -442,12 +633,14 @@ def main():
                 "kernel": "k_step_rows<double, false>" if args.precision == "f64" else "k_step_rows<float, false>",
                 "kernel_ms": kernel_s * 1e3, "launches_timed": n_launch,
                 "kernel_ms_source": "HIP events on the launch stream around %d launches issued back to back from C "
-                                    "(anm_time_step_launches), live in this run" % n_launch,
+                                    "(anm_time_step_launches), live in this run, rank 0's GPU" % n_launch,
                 "step_ms_hip_events": step_events_s * 1e3, "steps_timed": args.steps,
                 "algorithmic_bytes_per_env_step": bytes_per, "valu_fp64_issue": valu,
                 "note": "fp64-ALU/latency-bound (Newton-Raphson in registers), not HBM-bound: see DESIGN.md",
             },
         }  # fmt: skip
+        if not gpu:
+            out["config"]["test_double"] = "host test double (CPU tier launcher test): not a measurement"
         # secondary: algorithmic fp64 flops (per Newton iteration F ~ 8 nnz + 10 n, J ~ 16 nnz + 12 n,
         # dense LU (2/3)(2n)^3 + 2(2n)^2, sincos n; ANM6: n = 5, nnz = 16 -> ~1.4 kflop, plus the final F)
         n_, nnz_ = 5, 16
@@ -461,12 +654,10 @@ def main():
             out["config"]["alt_reference_tol"] = alt_tol
         if other is not None:
             out["config"]["other_workloads"] = other
-        if world == 1 and not args.no_cpu_baseline:
+        if gpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":
