@@ -109,6 +109,8 @@ ABI = {
     "anm_model_set_class_obs_bounds": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p]),
     "anm_model_bind_env_classes": (C.c_int, [C.c_void_p, _P, C.c_int64]),
     "anm_model_bind_state_same": (C.c_int, [C.c_void_p, _P]),
+    "anm_model_bind_nr_diff": (C.c_int, [C.c_void_p, _P]),
+    "anm_model_bind_nr_start": (C.c_int, [C.c_void_p, _P]),
     "anm_model_bind_view": (C.c_int, [C.c_void_p, C.POINTER(BatchView)]),
     "anm_model_obs_fusable": (C.c_int, [C.c_void_p]),
     "anm_model_set_obs": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p]),

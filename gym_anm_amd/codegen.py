@@ -461,14 +461,20 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-gpu-rdc", "-Wno-unused-value", "-fno-slp-vectorize", "-ffp-contract=on"]  # fmt: skip
 
 
-def _build_stamp(header_text, flags):
+# what csrc/anm_mpc_only.hip is made of (its own #include closure): the MPC-only libraries do not go stale when a
+# step kernel changes
+MPC_ONLY_SOURCES = ("anm_device.hpp", "anm_mpc.hpp", "anm_mpc_capi.inc", "anm_mpc_capi_types.inc", "anm_mpc_only.hip", "anm_pack.hpp")
+
+
+def _build_stamp(header_text, flags, mpc_only=False):
     """Content hash of everything a library is built from (descriptor, kernel sources, C-ABI header,
     compiler flags).  Freshness is decided by this stamp, not by mtimes: the built libraries travel
     between machines with the tree and file times do not survive that reliably."""
     h = hashlib.sha256()
     h.update(header_text.encode())
     h.update("\0".join(flags).encode())
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hpp", ".hip", ".h", ".inc"))]
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+             if f.endswith((".hpp", ".hip", ".h", ".inc")) and (not mpc_only or f in MPC_ONLY_SOURCES)]
     files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "anm_mi355x.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -509,7 +515,7 @@ def build_library(topo, name=None, force=False, verbose=False, extra_flags=(), m
     hdr, lib = header_path(name), lib_path(name, mpc_only)
     text = emit_header(topo, name)
     extra_flags = list(extra_flags) + os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
-    stamp = _build_stamp(text, HIPCC_FLAGS + extra_flags)
+    stamp = _build_stamp(text, HIPCC_FLAGS + extra_flags, mpc_only)
     stamp_path = lib + ".stamp"
 
     def fresh():
@@ -623,7 +629,7 @@ def build_mpc_class(name, force=False, verbose=False):
     lib = os.path.join(BUILD_DIR, "libmpc_class_%s%s.so" % (name, _tag()))
     text = mpc_class_header(name)
     extra = os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
-    stamp = _build_stamp(text, HIPCC_FLAGS + extra)
+    stamp = _build_stamp(text, HIPCC_FLAGS + extra, True)
     stamp_path = lib + ".stamp"
 
     def fresh():

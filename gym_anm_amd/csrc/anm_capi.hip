@@ -145,6 +145,8 @@ struct anm_model {
   const int32_t* d_env_class = nullptr;       // caller's device array [num_envs] (anm_model_bind_env_classes)
   bool class_per_env = false;                 // the classes do not come in aligned blocks of 64 environments
   uint8_t* d_state_same = nullptr;            // caller's device array [num_envs] (anm_model_bind_state_same)
+  double* d_nr_diff = nullptr;                // caller's device array [num_envs] (anm_model_bind_nr_diff)
+  const double* d_nr_start = nullptr;         // caller's device array [num_envs, 2 (n_bus - 1)] (anm_model_bind_nr_start)
   int32_t* d_zero = nullptr;                  // one zero: the class of every environment when no classes are bound
   std::vector<cplx> ybus;
 };
@@ -639,6 +641,18 @@ int anm_model_bind_state_same(anm_model* m, uint8_t* state_same) {
   return 0;
 }
 
+int anm_model_bind_nr_diff(anm_model* m, double* nr_diff) {
+  if (!m) return fail("anm_model_bind_nr_diff: null model");
+  m->d_nr_diff = nr_diff;
+  return 0;
+}
+
+int anm_model_bind_nr_start(anm_model* m, const double* x0) {
+  if (!m) return fail("anm_model_bind_nr_start: null model");
+  m->d_nr_start = x0;
+  return 0;
+}
+
 int anm_model_bind_view(anm_model* m, const anm_batch_view* v) {
   if (!m) return fail("anm_model_bind_view: null model");
   if (!v) {
@@ -781,7 +795,7 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   if (!m) return fail("anm_transition_f64: null model");
   if (n <= 0) return 0;
   if (!reward || !e_loss || !penalty || !converged) return fail("anm_transition_f64: null output");
-  TransitionIO io{p_load, p_pot, p_set, q_set, soc, full, reward, e_loss, penalty, converged, nr_iters};
+  TransitionIO io{p_load, p_pot, p_set, q_set, soc, full, reward, e_loss, penalty, converged, nr_iters, m->d_nr_diff, m->d_nr_start};
   int prec;
   SolverOpts so = solver(opts, prec);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -829,6 +843,7 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
   io.nr_iters = nr_iters;
   io.full = full;
   io.aux_index = aux_index;
+  io.nr_diff = m->d_nr_diff;
   int prec;
   SolverOpts so = solver(opts, prec);
   hipStream_t s = static_cast<hipStream_t>(stream);

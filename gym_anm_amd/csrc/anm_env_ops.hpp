@@ -87,6 +87,8 @@ struct TransitionIO {
   double* penalty;
   uint8_t* converged;
   int32_t* nr_iters;
+  double* nr_diff;   // [E] or null (anm_model_bind_nr_diff): ||F||inf of the final iterate
+  const double* nr_start;  // [E, 2 (NB - 1)] or null (anm_model_bind_nr_start): initial guess (angles, magnitudes)
 };
 
 template <class T, class JT>
@@ -101,13 +103,30 @@ ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64
     Q_set[I] = io.q_set[e * T::NSET + I];
   });
   static_for<0, T::NDES>([&](auto I) { w.soc[I] = io.soc[e * T::NDES + I]; });
-  transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
+  if (io.nr_start) {
+    // the reference's solver from a given initial guess (v_guess of _newton_raphson_sparse, solve_load_flow.py:176)
+    PFState<T> st;
+    transition_begin<T, JT>(C, C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, -1);
+    const double* x0 = io.nr_start + e * (2 * (T::NB - 1));
+    static_for<1, T::NB>([&](auto I) {
+      constexpr int i = I;
+      w.vm[i] = x0[T::NB - 1 + (i - 1)];
+      const SinCos r = sincos_huge(x0[i - 1]);   // (the library's sincos: any angle)
+      st.sn[i] = r.s;
+      st.cs[i] = r.c;
+    });
+    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
+    transition_end<T>(C, w, st, so.tol);
+  } else {
+    transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
+  }
   static_for<0, T::NDES>([&](auto I) { io.soc[e * T::NDES + I] = w.soc[I]; });
   io.reward[e] = w.reward;
   io.e_loss[e] = w.e_loss;
   io.penalty[e] = w.penalty;
   io.converged[e] = w.converged ? 1 : 0;
   if (io.nr_iters) io.nr_iters[e] = w.n_iter;
+  if (io.nr_diff) io.nr_diff[e] = w.diff;
   if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
 }
 
@@ -156,6 +175,7 @@ struct EnvIO {
   int iter_cap;             // two-phase step: Newton iterations done by the first launch
   int mid_cap;              // ... by the first straggler launch (0: it runs every record to the end, one level)
   int32_t* ws_list2;        // records the first straggler launch did not finish (count: counter 2 of the header)
+  double* nr_diff;          // [E] or null (anm_model_bind_nr_diff; reset only): ||F||inf of the final iterate
 };
 
 // Split an init_state row (anm_env.py / simulator.py:248-268) into transition inputs.
@@ -261,6 +281,7 @@ ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, cons
   io.terminated[e] = 0;
   if (io.timestep) io.timestep[e] = 0;
   if (io.nr_iters) io.nr_iters[e] = w.n_iter;
+  if (io.nr_diff) io.nr_diff[e] = w.diff;
   if (io.aux_index && io.K == 1) io.aux_index[e] = int32_t(s0[T::SDIM]);
   if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
 }

@@ -855,6 +855,12 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     }
   }
   double vm = 1.0, cs = 1.0, sn = 0.0, vr = 1.0, vi = 0.0;
+  if (mode == 0 && io.t.nr_start && isbus) {   // anm_model_bind_nr_start: the reference solver's v_guess instead of the flat start
+    const double* x0 = io.t.nr_start + ee * (2 * (d.NB - 1));
+    vm = x0[d.NB - 1 + l];
+    const SinCos r0 = sincos_huge(x0[l]);
+    sn = r0.s; cs = r0.c;
+  }
   int it = 0;
   bool g_bad = false, g_nan = false;   // the group's ||F||inf > tol / F has a NaN, as of its last evaluation
   bool active = true;
@@ -1111,6 +1117,32 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
     ir += LBW[(2 * side) * NBR + br];
     ii += LBW[(2 * side + 1) * NBR + br];
   }
+  // ||F||inf of the final iterate (anm_model_bind_nr_diff; see anm_radial.hpp): once, from the final V and I = Y V
+  double* const nr_diff = (mode == 0) ? io.t.nr_diff : ((mode == 1) ? io.e.nr_diff : nullptr);
+  double fdiff = 0.0;
+  if (nr_diff) {
+    const double fa = fabs(fma(vr, ir, vi * ii) - bus_p), fb = fabs(fma(vi, ir, -(vr * ii)) - bus_q);
+    double mx = isbus ? fmax(fa, fb) : 0.0;                            // (fmax drops a NaN: counted separately)
+    double nn = (isbus && (fa != fa || fb != fb)) ? 1.0 : 0.0;
+    if constexpr (WG) {
+      for (int m = 1; m < 64; m <<= 1) {
+        mx = fmax(mx, __shfl_xor(mx, m, 64));
+        nn += __shfl_xor(nn, m, 64);
+      }
+      __syncthreads();
+      if ((t & 63) == 0) { RED[32 + 2 * wave] = mx; RED[33 + 2 * wave] = nn; }
+      __syncthreads();
+      mx = 0.0; nn = 0.0;
+      for (int w = 0; w < n_waves; ++w) { mx = fmax(mx, RED[32 + 2 * w]); nn += RED[33 + 2 * w]; }
+      __syncthreads();   // (the slots serve group_sum2 next)
+    } else {
+      for (int m = 1; m < G; m <<= 1) {
+        mx = fmax(mx, __shfl_xor(mx, m, G));
+        nn += __shfl_xor(nn, m, G);
+      }
+    }
+    fdiff = (nn > 0.0) ? NAN : mx;
+  }
   // I_0 = Y_00 + sum over the branches at the slack bus (fixed butterfly order)
   double s0r = 0.0, s0i = 0.0;
 #pragma unroll
@@ -1199,6 +1231,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
       io.t.converged[e] = converged ? 1 : 0;
       if (io.t.nr_iters) io.t.nr_iters[e] = it;
+      if (nr_diff) nr_diff[e] = fdiff;
     }
     write_full();
     return;
@@ -1239,6 +1272,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
         for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
       }
       if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
+      if (l == 0 && nr_diff) nr_diff[e] = fdiff;
     } else {
       if (l == 0) {
         if (converged) put(d.SDIM, double(aux));

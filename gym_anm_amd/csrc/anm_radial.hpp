@@ -438,6 +438,12 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   const double ybb_r = RD(DF_YBB_RE), ybb_i = RD(DF_YBB_IM), ybp_r = RD(DF_YBP_RE), ybp_i = RD(DF_YBP_IM);
   const double ypb_r = RD(DF_YPB_RE), ypb_i = RD(DF_YPB_IM);
   double vm = 1.0, cs = 1.0, sn = 0.0;
+  if (mode == 0 && io.t.nr_start && isbus) {   // anm_model_bind_nr_start: the reference solver's v_guess instead of the flat start
+    const double* x0 = io.t.nr_start + ee * (2 * (d.NB - 1));
+    vm = x0[d.NB - 1 + l];
+    const SinCos r0 = sincos_huge(x0[l]);
+    sn = r0.s; cs = r0.c;
+  }
   double vr = 1.0, vi = 0.0, ir = 0.0, ii = 0.0, vpr = 1.0, vpi = 0.0;
   int it = 0;
   bool g_bad = false, g_nan = false;   // the group's ||F||inf > tol / F has a NaN, as of its last evaluation
@@ -462,7 +468,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     V.ypb_r = group::bperm(ypb_r, to4); V.ypb_i = group::bperm(ypb_i, to4);
     double gp = group::bperm(bus_p, to4), gq = group::bperm(bus_q, to4);
     if (!V.lane_bus) { V.ybb_r = V.ybb_i = V.ybp_r = V.ybp_i = V.ypb_r = V.ypb_i = 0.0; gp = gq = 0.0; }
-    double gvm = 1.0, gcs = 1.0, gsn = 0.0;   // flat start (solve_load_flow.py:36-39)
+    // flat start (solve_load_flow.py:36-39), or the bound initial guess moved to this loop's lane layout
+    double gvm = group::bperm(vm, to4), gcs = group::bperm(cs, to4), gsn = group::bperm(sn, to4);
+    if (!V.lane_bus) { gvm = 1.0; gcs = 1.0; gsn = 0.0; }
     int git = 0;
     unsigned tb, tn;
     // (trees without a DPP plan hand over through the LDS arrays the table-driven loop would use)
@@ -603,6 +611,21 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     ANM_GROUP_SYNC();
   }
   const bool converged = !f_nan && !f_bad;
+  // ||F||inf of the final iterate (anm_model_bind_nr_diff; the reference's `diff`, solve_load_flow.py:84-120, 218-224):
+  // the stop test above works on lane masks and never forms the norm, so it is recomputed here, once, from the final V
+  // and I = Y V: F_b = V_b conj(I_b) - (p_b + j q_b); NaN if an entry is NaN (numpy's norm propagates it)
+  double* const nr_diff = (mode == 0) ? io.t.nr_diff : ((mode == 1) ? io.e.nr_diff : nullptr);
+  double fdiff = 0.0;
+  if (nr_diff) {
+    const double fa = fabs(fma(vr, ir, vi * ii) - bus_p), fb = fabs(fma(vi, ir, -(vr * ii)) - bus_q);
+    double mx = isbus ? fmax(fa, fb) : 0.0;                            // (fmax drops a NaN: counted separately)
+    double nn = (isbus && (fa != fa || fb != fb)) ? 1.0 : 0.0;
+    for (int m = 1; m < G; m <<= 1) {
+      mx = fmax(mx, __shfl_xor(mx, m, G));
+      nn += __shfl_xor(nn, m, G);
+    }
+    fdiff = (nn > 0.0) ? NAN : mx;
+  }
 
   ANM_PHASE(3);
   // ---------------- slack injection, branch flows, reward --------------------------------------
@@ -691,6 +714,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
       io.t.converged[e] = converged ? 1 : 0;
       if (io.t.nr_iters) io.t.nr_iters[e] = it;
+      if (nr_diff) nr_diff[e] = fdiff;
     }
     dump = true;
     break;
@@ -733,6 +757,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
       }
       if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
+      if (l == 0 && nr_diff) nr_diff[e] = fdiff;
     } else {
       if (l == 0) {
         if (converged) put(d.SDIM, double(aux));

@@ -235,6 +235,7 @@ class BatchedSimulator:
         self.penalty = torch.zeros(E_, **f64)
         self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=self.device)
         self.nr_iters = torch.zeros(E_, dtype=torch.int32, device=self.device)
+        self.nr_diff = None   # track_nr_diff(): ||F||inf of the final iterate of every environment's last solve
         # the reference's component dictionaries (simulator.py:148-179), as read-only views
         self.buses, self.devices, self.branches = _component_views(self)
 
@@ -253,6 +254,26 @@ class BatchedSimulator:
                 self._handle = C.c_void_p()
         except Exception:
             pass
+
+    def track_nr_diff(self, on=True):
+        """Have ``transition`` / ``reset`` also report the solver's final mismatch ``||F(x)||inf`` per environment (the
+        ``diff`` the reference's ``_newton_raphson_sparse`` returns, solve_load_flow.py:176-226) in ``self.nr_diff``."""
+        self.nr_diff = torch.full((self.num_envs,), float("nan"), dtype=torch.float64, device=self.device) if on else None
+        with self._device_ctx():
+            self.backend.check(self.backend.lib.anm_model_bind_nr_diff(
+                self._handle, self.nr_diff.data_ptr() if on else None), "anm_model_bind_nr_diff")
+        return self.nr_diff
+
+    def set_nr_start(self, x0=None):
+        """Initial guess of the next ``transition`` calls' Newton solves, ``[num_envs, 2 (N_bus - 1)]`` in the layout of the
+        reference solver's ``v_guess`` (angles of the non-slack buses, then their magnitudes; solve_load_flow.py:176);
+        ``None``: the flat start again (what ``solve_pfe_newton_raphson`` passes, :42-43)."""
+        self._nr_start = None if x0 is None else torch.as_tensor(x0, dtype=torch.float64, device=self.device).contiguous()
+        if self._nr_start is not None and self._nr_start.shape != (self.num_envs, 2 * (self.N_bus - 1)):
+            raise ValueError("x0 must have shape (%d, %d)" % (self.num_envs, 2 * (self.N_bus - 1)))
+        with self._device_ctx():
+            self.backend.check(self.backend.lib.anm_model_bind_nr_start(
+                self._handle, None if self._nr_start is None else self._nr_start.data_ptr()), "anm_model_bind_nr_start")
 
     @property
     def Y_bus(self):

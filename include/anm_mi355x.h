@@ -175,6 +175,25 @@ int anm_model_bind_view(anm_model* m, const anm_batch_view* view);
  * bytes of the 401 an ANM6Easy env-step moves.  Kernels that always write both rows clear the flags. */
 int anm_model_bind_state_same(anm_model* m, uint8_t* state_same);
 
+/* The reference's solver returns the final mismatch next to the iteration count (`diff` of
+ * _newton_raphson_sparse, solve_load_flow.py:176-226: ||F(x)||inf of the iterate it stopped at).  With an array bound here
+ * (DEVICE double [num_envs], caller-owned, alive while bound; NULL unbinds) anm_transition_f64 and anm_reset_f64 write it per
+ * environment (a view: indexed by the environment, like every per-environment array): the largest |Re|, |Im| over the
+ * non-slack buses of V_i conj((Y V)_i) - (p_i + j q_i) at the final iterate, NaN when an entry is NaN -- in the
+ * thread-per-environment family the very number its loop tested last, in the lane-group families (whose stop test works
+ * on lane masks, no norm is ever formed) recomputed once from the final V and I = Y V.  Tests pin the Jacobian and the
+ * linear solve with it (tests/golden/iterates_*.npz); anm_step_f64 does not write it. */
+int anm_model_bind_nr_diff(anm_model* m, double* nr_diff);
+
+/* The reference's solver takes its initial guess as an argument (v_guess of _newton_raphson_sparse,
+ * solve_load_flow.py:176-226; solve_pfe_newton_raphson passes the flat start, :42-43 -- and so does this library while
+ * nothing is bound).  With an array bound here (DEVICE double [num_envs, 2 (n_bus - 1)], the reference's layout: the
+ * angles of the non-slack buses, then their magnitudes; caller-owned, alive while bound; NULL unbinds)
+ * anm_transition_f64 starts every environment's solve from its row instead.  Tests use it to compare ONE Newton step
+ * with the reference's from the reference's own iterate (a diverging solve amplifies rounding differences from step to
+ * step; one step does not).  anm_reset_f64 and anm_step_f64 always start flat, like the reference. */
+int anm_model_bind_nr_start(anm_model* m, const double* x0);
+
 /* precision of the Jacobian + block-LU inside Newton-Raphson; mismatch F, the stop test and the
  * state update are always fp64. */
 #define ANM_SOLVE_F64 0

@@ -32,6 +32,8 @@ struct anm_model {
   std::vector<double> series;
   int period = 0, K = 0;
   bool env_set = false;
+  double* nr_diff = nullptr;
+  const double* nr_start = nullptr;
 };
 
 struct anm_mpc {
@@ -136,7 +138,7 @@ int anm_model_get_ybus(const anm_model* m, double* y) {
 int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const double* p_pot, const double* p_set,
                        const double* q_set, double* soc, double* full, double* reward, double* e_loss,
                        double* penalty, uint8_t* converged, int32_t* nr_iters, const anm_solver_opts* opts, void*) {
-  TransitionIO io{p_load, p_pot, p_set, q_set, soc, full, reward, e_loss, penalty, converged, nr_iters};
+  TransitionIO io{p_load, p_pot, p_set, q_set, soc, full, reward, e_loss, penalty, converged, nr_iters, m->nr_diff, m->nr_start};
   int prec;
   SolverOpts so = solver(opts, prec);
   for (int64_t e = 0; e < n; ++e) {
@@ -158,6 +160,7 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
   io.series = m->series.data(); io.period = m->period; io.rng_seed = rng_seed; io.env_offset = env_offset;
   io.reset_count = reset_count;
   io.converged = converged; io.terminated = terminated; io.timestep = timestep; io.nr_iters = nr_iters; io.full = full; io.aux_index = aux_index;
+  io.nr_diff = m->nr_diff;
   int prec;
   SolverOpts so = solver(opts, prec);
   for (int64_t e = 0; e < n; ++e) {
@@ -288,6 +291,8 @@ int anm_mpc_act_f64(anm_mpc* m, int64_t num_envs, int32_t forecast, const double
   return host_mpc_run(m, num_envs, io, opts);
 }
 int anm_model_bind_view(anm_model*, const anm_batch_view* v) { return v ? fail("the host test double has no lane-group kernels") : 0; }
+int anm_model_bind_nr_diff(anm_model* m, double* p) { m->nr_diff = p; return 0; }
+int anm_model_bind_nr_start(anm_model* m, const double* p) { m->nr_start = p; return 0; }
 int anm_model_bind_state_same(anm_model*, uint8_t* p) { return p ? fail("the host test double writes every state row") : 0; }
 int anm_model_obs_fusable(const anm_model*) { return 0; }  // the test double has no fused gather
 int anm_model_set_obs(anm_model*, int32_t n_obs, const int32_t*, const double*, const double*, const double*) {

@@ -969,3 +969,204 @@ def structured_network(shape):
     net["branch"] = np.array([[f, t, float(rng.uniform(0.005, 0.03)), float(rng.uniform(0.03, 0.08)), 0.0, 30.0, 1, 0]
                               for f, t in edges])
     return net
+
+
+# ======================================================================================
+# Newton ITERATES against the reference (tests/golden/iterates_<net>.npz, oracle/make_golden_iterates.py): x_k and
+# ||F(x_k)||inf after k = 1 ... 12 iterations of the reference's own _newton_raphson_sparse(lim_iter=k)
+# (solve_load_flow.py:176-226).  Final V + iteration count cannot tell an exact Jacobian / linear solve (_dfdx :123-164,
+# spsolve :220) from a 1e-7-accurate one -- Newton corrects itself --, an iterate can: an error in step k is in x_k
+# at first order.  Tolerances (stated, and measured values are printed by the GPU tier):
+#   converging solves   |V_k - V_k^ref| <= 1e-11 p.u. on every bus, every recorded k (cumulative: flat start, cap k)
+#   diverging solves    cumulative for k <= 4 at 1e-9 * max(1, |V_k^ref|): these iterates are thrown to |V| ~ 1e3 ... 1e8 and
+#                       every further step multiplies the rounding differences it inherits by the local expansion rate of a
+#                       chaotic map (the host build, exact 1/x and no contraction, is 6e-12 off at k = 4, 6e-7 at k = 6,
+#                       7e-5 at k = 12: ANY other double-precision factorisation would be); beyond k = 4 the comparison
+#                       is ONE STEP at a time from the reference's own iterate (newton_one_step, anm_model_bind_nr_start):
+#                       all 12 iterates, relative to the larger of the two points, within max(1e-10, 16 eps cond(J(x_{k-1})))
+#                       (30-bus feeder: cond reaches 5e7 on these iterates, and LAPACK's dense solve is 2 eps cond from
+#                       the reference's SuperLU step there)
+#   mismatch            |diff_k - diff_k^ref| <= 1e-6 diff_k^ref + 1e-13 (the floor: rounding of p.u. sums of terms up to ~30)
+# ======================================================================================
+ITER_NETS = ("anm6", "case30", "3bus", "3bus_tx2", "3bus_tx7")
+ITER_ATOL_CONV, ITER_RTOL_DIV, ITER_DIFF_RTOL, ITER_DIFF_ATOL = 1e-11, 1e-9, 1e-6, 1e-13
+ONE_STEP_COND_FACTOR = 16
+ITER_DIV_CUM_K = 4   # diverging solves: cumulative comparison up to this iterate, one step at a time beyond
+
+
+def iterate_nets():
+    nets = golden_nets()
+    return {k: nets[k] for k in ITER_NETS}
+
+
+def _iterate_reference(g, k):
+    """rows that have an iterate k, its V (non-slack buses) and mismatch"""
+    rows = g["n_k"] >= k
+    V = g["vm_k"][:, k - 1] * np.exp(1j * g["th_k"][:, k - 1])
+    return rows, V, g["diff_k"][:, k]
+
+
+def _compare_iterate(name, k, g, V, it, diff, worst):
+    rows, Vref, dref = _iterate_reference(g, k)
+    # the reference's loop after at most k iterations: min(n_iter, k) of them were done
+    npt.assert_array_equal(it, np.minimum(g["n_iter"], k), err_msg="%s: iteration counts at cap %d" % (name, k))
+    div = g["diverging"].astype(bool)
+    for sel, lab in ((rows & ~div, "conv"), (rows & div, "div")):
+        if not sel.any():
+            continue
+        a, b = V[sel], Vref[sel]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), "%s k=%d: NaN pattern of the iterates" % (name, k)
+        fin = np.isfinite(b)
+        if lab == "div" and k > ITER_DIV_CUM_K:
+            continue
+        err = np.abs(a - b)[fin]
+        scale = np.ones_like(err) if lab == "conv" else np.maximum(1.0, np.abs(b)[fin])
+        rel = float((err / scale).max(initial=0.0))
+        worst[lab] = max(worst[lab], rel)
+        tol = ITER_ATOL_CONV if lab == "conv" else ITER_RTOL_DIV
+        assert rel <= tol, "%s: iterate %d of the %s solves deviates by %.3g (allowed %.1g)" % (name, k, "converging" if lab == "conv" else "diverging", rel, tol)
+    if diff is not None:
+        a, b = diff[rows], dref[rows]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), "%s k=%d: NaN pattern of the mismatch" % (name, k)
+        fin = np.isfinite(b) & ~div[rows]   # (a diverging iterate's mismatch is as far off as the iterate: see newton_one_step)
+        e = np.abs(a[fin] - b[fin])
+        worst["diff"] = max(worst["diff"], float((e / (np.abs(b[fin]) + ITER_DIFF_ATOL / ITER_DIFF_RTOL)).max(initial=0.0)))
+        assert np.all(e <= ITER_DIFF_RTOL * np.abs(b[fin]) + ITER_DIFF_ATOL), "%s: mismatch after %d iterations deviates" % (name, k)
+
+
+def newton_iterates_transition(name, net, device, backend=None, impl=None):
+    """anm_transition_f64 with max_iter = k, k = 1 ... 12: V_k from the electrical-state dump, ||F(x_k)||inf through
+    anm_model_bind_nr_diff, both against the reference's iterates."""
+    g = np.load(os.path.join(GOLDEN, "iterates_%s.npz" % name))
+    M = len(g["n_iter"])
+    sim = BatchedSimulator(net, float(g["delta_t"]), float(g["lamb"]), num_envs=M, device=device, tol=float(g["x_tol"]),
+                           impl=impl, handoff_after=None, _backend=backend)
+    diff_t = sim.track_nr_diff()
+    sl = full_slices(sim)
+    worst = {"conv": 0.0, "div": 0.0, "diff": 0.0}
+    for k in range(1, g["vm_k"].shape[1] + 1):
+        sim.opts.max_iter = k
+        sim.soc.copy_(torch.as_tensor(g["soc0"]))
+        sim.transition(g["P_load"], g["P_pot"], g["P_set"], g["Q_set"])
+        full = sim.full.cpu().numpy()
+        if k == 1:   # what the solver is given: the reference's p, q to the last bits (slack entry: the solver's own result)
+            npt.assert_allclose(full[:, sl["bus_p"]][:, 1:], g["bus_p"][:, 1:], rtol=0, atol=1e-12)
+            npt.assert_allclose(full[:, sl["bus_q"]][:, 1:], g["bus_q"][:, 1:], rtol=0, atol=1e-12)
+        V = (full[:, sl["bus_v_magn"]] * np.exp(1j * full[:, sl["bus_v_ang"]]))[:, 1:]
+        _compare_iterate(name, k, g, V, sim.nr_iters.cpu().numpy(), diff_t.cpu().numpy(), worst)
+    # the full solve: the mismatch the reference's loop ended with
+    sim.opts.max_iter = 100
+    sim.soc.copy_(torch.as_tensor(g["soc0"]))
+    sim.transition(g["P_load"], g["P_pot"], g["P_set"], g["Q_set"])
+    ok = g["converged"].astype(bool)
+    npt.assert_array_equal(sim.pfe_converged.cpu().numpy(), ok)
+    npt.assert_array_equal(sim.nr_iters.cpu().numpy()[ok], g["n_iter"][ok])
+    d = diff_t.cpu().numpy()
+    assert np.all(np.abs(d[ok] - g["diff"][ok]) <= ITER_DIFF_RTOL * g["diff"][ok] + ITER_DIFF_ATOL)
+    assert np.all(~(d[~ok] <= float(g["x_tol"])))   # not converged: above the tolerance, or NaN
+    return worst
+
+
+def newton_iterates_step(name, net, device, backend=None, handoff_after=None, impl=None):
+    """The same iterates through anm_step_f64 (host next_vars, electrical-state dump): the path on which a
+    thread-per-environment solve hands over to a lane group of its wavefront -- handoff_after = 0 sends EVERY solve
+    there from its first iteration (csrc/anm_group.hpp: the one-step v_rcp_f64 pivot inverse, DPP hand-overs)."""
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    g = np.load(os.path.join(GOLDEN, "iterates_%s.npz" % name))
+    M = len(g["n_iter"])
+    exo = torch.as_tensor(np.concatenate([g["P_load"], g["P_pot"], np.zeros((M, 1))], axis=1))
+
+    class Env(BatchedANMEnv):
+        def __init__(self):
+            super().__init__(net, "state", 1, float(g["delta_t"]), 0.995, float(g["lamb"]), aux_bounds=np.array([[0.0, 10.0]]),
+                             num_envs=M, device=device, tol=float(g["x_tol"]), track_full=True, handoff_after=handoff_after,
+                             impl=impl, _backend=backend)
+
+        def next_vars(self, s):
+            return exo.to(self.device)
+
+    env = Env()
+    env.check_actions = False   # the fixtures' set-points go beyond the action Box on purpose (wild cases)
+    sim, m = env.simulator, env.simulator.model
+    pos = {d: j for j, d in enumerate(m.setp_idx)}
+    gi, di = [pos[d] for d in m.gen_idx], [pos[d] for d in m.des_idx]
+    act = torch.as_tensor(np.concatenate([g["P_set"][:, gi], g["Q_set"][:, gi], g["P_set"][:, di], g["Q_set"][:, di]], axis=1))
+    sl = full_slices(sim)
+    worst = {"conv": 0.0, "div": 0.0, "diff": 0.0}
+    for k in range(1, g["vm_k"].shape[1] + 1):
+        sim.opts.max_iter = k
+        sim.soc.copy_(torch.as_tensor(g["soc0"]))
+        env._term_u8.zero_()
+        env.step(act)
+        full = sim.full.cpu().numpy()
+        V = (full[:, sl["bus_v_magn"]] * np.exp(1j * full[:, sl["bus_v_ang"]]))[:, 1:]
+        _compare_iterate(name, k, g, V, sim.nr_iters.cpu().numpy(), None, worst)
+    return worst
+
+
+def newton_one_step(name, net, device, backend=None, impl=None):
+    """ONE Newton step from the reference's own iterate x_{k-1} (anm_model_bind_nr_start, max_iter = 1) against the
+    reference's x_k, k = 1 ... 12, every recorded iterate of every case: what a step of THIS Jacobian and THIS linear
+    solve does to the very point the reference stepped from.  A diverging solve multiplies rounding differences from
+    step to step (the cumulative comparison above is therefore bounded to its first iterates); one step does not."""
+    g = np.load(os.path.join(GOLDEN, "iterates_%s.npz" % name))
+    M, N1 = len(g["n_iter"]), g["vm_k"].shape[2]
+    sim = BatchedSimulator(net, float(g["delta_t"]), float(g["lamb"]), num_envs=M, device=device, tol=float(g["x_tol"]),
+                           max_iter=1, impl=impl, handoff_after=None, _backend=backend)
+    diff_t = sim.track_nr_diff()
+    sl = full_slices(sim)
+    div = g["diverging"].astype(bool)
+    worst = {"conv": 0.0, "div": 0.0, "diff": 0.0}
+    import anm_oracle as _O   # (test infrastructure: the dense Jacobian of the reference's iterate, for its condition number)
+
+    ynet = _O.parse_network(net, float(g["delta_t"]), float(g["lamb"])).Y
+    flat = np.concatenate([np.zeros((M, N1)), np.ones((M, N1))], axis=1)
+    for k in range(1, g["vm_k"].shape[1] + 1):
+        rows, Vref, dref = _iterate_reference(g, k)
+        if not rows.any():
+            break
+        x0 = flat.copy()
+        if k > 1:
+            x0[rows] = np.concatenate([g["th_k"][rows, k - 2], g["vm_k"][rows, k - 2]], axis=1)
+        sim.set_nr_start(x0)
+        sim.soc.copy_(torch.as_tensor(g["soc0"]))
+        sim.transition(g["P_load"], g["P_pot"], g["P_set"], g["Q_set"])
+        full = sim.full.cpu().numpy()
+        V = (full[:, sl["bus_v_magn"]] * np.exp(1j * full[:, sl["bus_v_ang"]]))[:, 1:]
+        npt.assert_array_equal(sim.nr_iters.cpu().numpy()[rows], 1)
+        for sel, lab in ((rows & ~div, "conv"), (rows & div, "div")):
+            if not sel.any():
+                continue
+            a, b = V[sel], Vref[sel]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), "%s step %d: NaN pattern" % (name, k)
+            fin = np.isfinite(b)
+            if lab == "conv":
+                rel = float(np.abs(a - b)[fin].max(initial=0.0))
+                worst["conv"] = max(worst["conv"], rel)
+                assert rel <= ITER_ATOL_CONV, "%s: step %d of the converging solves lands %.3g p.u. from the reference's (allowed %.1g)" % (name, k, rel, ITER_ATOL_CONV)
+                continue
+            # diverging solves step from points with |V| ~ 1e3 ... 1e8 through Jacobians that are close to singular (that is why
+            # they diverge): what ANY double-precision solve can promise is eps * cond(J(x_{k-1})) relative to the larger of
+            # the two points.  The allowance is ONE_STEP_COND_FACTOR times that, per case, cond from the oracle's dense
+            # Jacobian of the reference's iterate (measured: LAPACK's partial-pivoting solve lands 2 eps cond from the
+            # reference's SuperLU step where cond = 2e7; the kernels 0.7 ... 1.5), and never below ITER_RTOL_DIV / 10.
+            Vprev = (x0[:, N1:] * np.exp(1j * x0[:, :N1]))[sel]
+            scale = np.maximum(1.0, np.maximum(np.abs(b), np.abs(Vprev).max(axis=1, keepdims=True)))
+            err = np.where(fin, np.abs(a - b) / scale, 0.0).max(axis=1)
+            for j, m_ in enumerate(np.flatnonzero(sel)):
+                cond = np.linalg.cond(_O.nr_jacobian(x0[m_], ynet, False))
+                allow = max(ITER_RTOL_DIV / 10, ONE_STEP_COND_FACTOR * np.finfo(float).eps * cond)
+                worst["div"] = max(worst["div"], float(err[j]))
+                if err[j] > ITER_RTOL_DIV / 100:   # (below that the floor of the allowance speaks, not the conditioning)
+                    worst["div_over_eps_cond"] = max(worst.get("div_over_eps_cond", 0.0), float(err[j] / (np.finfo(float).eps * cond)))
+                assert err[j] <= allow, ("%s: step %d of diverging case %d lands %.3g (relative) from the reference's; allowed %.3g = "
+                                         "max(%.0e, %d eps cond(J)), cond(J) = %.3g" % (name, k, m_, err[j], allow, ITER_RTOL_DIV / 10, ONE_STEP_COND_FACTOR, cond))
+        d = diff_t.cpu().numpy()
+        a, b = d[rows & ~div], dref[rows & ~div]
+        if len(b):
+            e = np.abs(a - b) / (np.abs(b) + ITER_DIFF_ATOL / ITER_DIFF_RTOL)
+            worst["diff"] = max(worst["diff"], float(e.max()))
+            assert np.all(np.abs(a - b) <= ITER_DIFF_RTOL * np.abs(b) + ITER_DIFF_ATOL), "%s: mismatch after step %d" % (name, k)
+    sim.set_nr_start(None)
+    return worst
