@@ -292,6 +292,7 @@ def mpc_side_figure(dev):
         # the whole of act() -- forecast gather, solve, scaling to MW, clipping -- as the caller sees it: ONE launch
         # (anm_mpc_act_f64), wall clock per call
         ag.warn_unconverged = False
+        ag.reuse_action_buffer = True   # (the zero-allocation form: act() hands out the solver's own action buffer)
         for _ in range(3):
             ag.act(env)
         torch.cuda.synchronize(dev)

@@ -273,7 +273,11 @@ def load_mpc_for_topology(topo, size_class=None) -> MpcBackend:
     cls = None if size_class is False else codegen.mpc_class_for(_topology_counts(topo))
     if size_class is True and cls is None:
         raise E.UnsupportedNetworkError("no MPC size class takes this network")
-    use_class = cls is not None and (size_class is True or not os.path.exists(exact))
+    # the network's own library when it is there and FRESH; a stale one (other sources, another ABI revision) is rebuilt
+    # where hipcc exists -- and where it does not, the size class serves the network instead of failing: a machine
+    # without a compiler is exactly what the classes are for
+    have_exact = os.path.exists(exact) and (codegen.mpc_library_is_fresh(topo) or codegen.hipcc_path() is not None)
+    use_class = cls is not None and (size_class is True or not have_exact)
     if use_class:
         name = "mpcclass:" + cls
     if name in _CACHE:

@@ -331,6 +331,10 @@ class MPCAgent:
                 + env.simulator.model.N_non_slack_gen + (1 if self.FUSED_FORECAST == 2 else 0))
 
     warn_unconverged = True   # False: act() neither synchronises nor launches anything but the solve (last_converged stays lazy)
+    # False (default): act() returns a tensor of its own, like the reference's fresh array and like the unfused path --
+    # actions kept across steps (rollout lists, replay buffers) stay what they were.  True: the fused path returns the
+    # solver's persistent buffer, which the next act() overwrites (no allocation, no copy kernel: what bench.py times)
+    reuse_action_buffer = False
 
     @property
     def last_converged(self):
@@ -352,13 +356,14 @@ class MPCAgent:
         """``env``: a batched environment -> ``[num_envs, action_dim]`` tensor; or one of the NumPy-facing
         single-environment classes (``ANMEnv``, ``ANM6``, ``ANM6Easy``) -> 1-D NumPy action, as in the reference's
         ``examples/mpc_*.py``.  With a stock forecast the whole call is ONE kernel launch (forecast gather, solve, scaling
-        to MW, clipping: ``anm_mpc_act_f64``) and the tensor returned is a buffer the next call overwrites."""
+        to MW, clipping: ``anm_mpc_act_f64``); the tensor returned is the caller's own unless ``reuse_action_buffer`` is set
+        (then it is the solver's buffer, overwritten by the next call)."""
         if hasattr(env, "vec"):
             return self.act(env.vec)[0].cpu().numpy()
         if self._fused(env):
             a = self.solver.act(self.FUSED_FORECAST, env, self._lo, self._hi)
             self._check_converged(a.shape[0])
-            return a
+            return a if self.reuse_action_buffer else a.clone()
         pl, pg = self.forecast(env)
         u0 = self.solve(pl, pg, self._soc(env)) * self.baseMVA
         ng = self.solver.dims.n_gen

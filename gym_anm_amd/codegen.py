@@ -500,6 +500,17 @@ def library_is_fresh(lib: str) -> bool:
     return stamp == _build_stamp(text, HIPCC_FLAGS + extra)
 
 
+def mpc_library_is_fresh(topo) -> bool:
+    """``libmpc_<topology>.so`` exists and was built from this tree's MPC sources, C-ABI header and flags"""
+    lib = lib_path(topology_name(topo), mpc_only=True)
+    try:
+        stamp = open(lib + ".stamp").read().strip()
+    except OSError:
+        return False
+    extra = os.environ.get("ANM_EXTRA_HIPCC_FLAGS", "").split()
+    return os.path.exists(lib) and stamp == _build_stamp(emit_header(topo, topology_name(topo)), HIPCC_FLAGS + extra, True)
+
+
 def build_library(topo, name=None, force=False, verbose=False, extra_flags=(), mpc_only=False):
     """Write the descriptor and compile ``libanm_<name>.so`` for gfx950 (no GPU needed to build).
 

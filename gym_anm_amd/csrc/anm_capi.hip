@@ -505,6 +505,8 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
 
 int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_desc* const* descs) {
   if (!m) return fail("anm_model_set_classes: null model");
+  if (n_classes > 1 && (m->view.index || m->view.w_state > 0))
+    return fail("anm_model_set_classes: not while a batch view is bound (anm_model_bind_view)");
   if (n_classes < 1 || n_classes > 65536) return fail("anm_model_set_classes: n_classes must be in [1, 65536]");
   if (n_classes > 1 && !descs) return fail("anm_model_set_classes: null descriptions");
   std::vector<std::vector<double>> xc, xh, xm;
@@ -602,6 +604,9 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
     restore_impl();
     return 0;
   }
+  if (m->view.index || m->view.w_state > 0)   // (the same rule as anm_model_bind_view, from the other side: k_mesh looks a block's
+    // class up by launch slot and an environment's by its index in the batch)
+    return fail("anm_model_bind_env_classes: not while a batch view is bound (anm_model_bind_view)");
   if (num_envs <= 0) return fail("anm_model_bind_env_classes: num_envs must be positive");
   const int n_classes = 1 + int(m->tpe_ok ? m->x_const.size() : (m->radial_ok ? m->x_hd.size() : m->x_md.size()));
   std::vector<int32_t> h(static_cast<size_t>(num_envs));

@@ -599,16 +599,19 @@ inline size_t waves_per_cu(const Dims& d) {
 //   * for each, levels as the dependencies give them (a destination may collect several contributions per level: one
 //     sums step per four of them) or levels that admit ONE contribution per destination (no sums steps at all: what
 //     trees like -- a 30-bus feeder 10 -> 7 steps),
-// as long as the extra fill costs no wavefront on a compute unit.  Deterministic in the topology alone (the parameter
-// classes of a model share their integer tables).
+// as long as the extra fill costs no wavefront on a compute unit.  Deterministic in the topology (the parameter classes of
+// a model share their integer tables) and in the tuning switches ANM_MESH_WAVES / ANM_MESH_NO_ZONE / ANM_MESH_NO_TAIL, which
+// waves_per_cu and build_plan_zone read from the environment.
 inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
   if (!build_plan_zone(n, P, err, 1 << 30)) return false;
   if (getenv("ANM_MESH_NO_ZONE")) return true;
   const size_t base_waves = waves_per_cu(P.d);
+  const Plan base = P;   // (the c_max = 1 << 30 search starts from the plan just built: no second build of it)
   for (int c_max : {1 << 30, 1}) {
     Plan Q0;
     std::string e0;
-    if (!build_plan_zone(n, Q0, e0, 1 << 30, c_max)) continue;
+    if (c_max == (1 << 30)) Q0 = base;
+    else if (!build_plan_zone(n, Q0, e0, 1 << 30, c_max)) continue;
     if (Q0.d.n_steps < P.d.n_steps && waves_per_cu(Q0.d) >= base_waves) P = Q0;
     int misses = 0;
     for (int z = Q0.d.zone_level - 1; z >= 0 && misses < 5; --z) {   // (zone_level of "no zone" = one past the last product level)

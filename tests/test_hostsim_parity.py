@@ -792,3 +792,11 @@ def test_dump_abs_and_arg_against_numpy():
     big = fin & (np.maximum(np.abs(x), np.abs(y)) > 1e-150)   # (per-unit quantities: |z| is formed without scaling against underflow)
     np.testing.assert_allclose(mag[big], np.abs(z[big]), rtol=1e-15, atol=0)
     assert np.isnan(ang[~fin]).all() and np.isnan(mag[~fin]).all()
+    # zeros, signs included: np.angle / np.arctan2 distinguish (+0, +-0) -> +-0 from (-0, +-0) -> +-pi
+    xs = np.array([0.0, 0.0, -0.0, -0.0, -0.0, 0.0, 5e-324, -5e-324])
+    ys = np.array([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, 0.0, 0.0])
+    m2, a2 = np.empty_like(xs), np.empty_like(xs)
+    fn(xs.size, P(xs), P(ys), P(m2), P(a2))
+    ref = np.arctan2(ys, xs)
+    np.testing.assert_array_equal(a2, ref)
+    np.testing.assert_array_equal(np.signbit(a2), np.signbit(ref))

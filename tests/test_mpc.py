@@ -288,8 +288,10 @@ def check_fused_act(env, n_env, steps=5, horizons=(1, 3)):
             fused = cls(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=N)
             plain = Unfused(env.simulator, env.action_space, env.gamma, safety_margin=0.92, planning_steps=N)
             assert fused._fused(env) and not plain._fused(env)
+            kept = []   # actions a caller keeps across steps stay what they were (the reference returns a fresh array)
             for _ in range(steps):
                 a = fused.act(env)
+                kept.append((a, a.clone()))
                 b = plain.act(env)
                 assert a.shape == b.shape == (n_env, env.action_space.shape[0])
                 assert torch.equal(a, b), (cls.__name__, N, float((a - b).abs().max()))
@@ -297,6 +299,9 @@ def check_fused_act(env, n_env, steps=5, horizons=(1, 3)):
                     assert torch.equal(getattr(fused.solver, name), getattr(plain.solver, name)), name
                 assert bool(fused.last_converged.all())
                 env.step(a.clone())
+            assert all(torch.equal(x, y) for x, y in kept) and len({x.data_ptr() for x, _ in kept}) == len(kept)
+            fused.reuse_action_buffer = True    # opt-in: the solver's own buffer, overwritten by the next call
+            assert fused.act(env).data_ptr() == fused.act(env).data_ptr()
 
 
 # ---- CPU tier: the solver source compiled for the host --------------------------------------------------------
