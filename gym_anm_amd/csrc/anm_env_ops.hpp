@@ -56,7 +56,7 @@ ANM_HD void write_state_obs(cptr_t C, const EnvWork<T>& w, Out& out) {
   auto put = [&](int k, double v) {
     out.put_st(k, v);
     // np.clip(obs, low, high)
-    out.put_ob(k, fmin(fmax(v, C[L::OBS_LO + k]), C[L::OBS_HI + k]));
+    out.put_ob(k, vmin(vmax(v, C[L::OBS_LO + k]), C[L::OBS_HI + k]));
   };
   static_for<0, T::ND>([&](auto Di) {
     constexpr int d = Di;
@@ -231,8 +231,10 @@ ANM_HD void finish_reset(cptr_t C, EnvWork<T>& w, const S0& s0, int K, double* s
 // time index uniform in [0, period), loads and generator potentials from the series at that index,
 // generator Q uniform in its p.u. range (stored in the MVAr slot, sic), storage SoC uniform in its
 // p.u. range (stored in the MWh slot, sic).  Counter-based: (seed, global env index, epoch).
-template <class T>
-ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32_t epoch, double (&s0)[T::SDIM + 1]) {
+// SER: where the exogenous series are read from -- io.series (global memory; the default) or a copy in LDS
+template <class T, class SER = const double*>
+ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32_t epoch, double (&s0)[T::SDIM + 1], SER ser = nullptr) {
+  if constexpr (std::is_same<SER, const double*>::value) { if (!ser) ser = io.series; }
   typedef Layout<T> L;
   uint32_t r[4];
   Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 0u, r);
@@ -243,7 +245,7 @@ ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32
     constexpr int d = Di;
     constexpr int typ = T::DEV_TYPE[d];
     if constexpr (typ == DEV_LOAD) {
-      s0[d] = io.series[T::DEV_SLOT[d] * io.period + aux];
+      s0[d] = ser[T::DEV_SLOT[d] * io.period + aux];
     } else if constexpr (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
       constexpr int g = T::DEV_SLOT[d];
       constexpr int u = g;  // uniform index
@@ -251,7 +253,7 @@ ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32
       uint32_t q[4];
       Philox::generate(io.rng_seed, io.env_offset + uint64_t(e), epoch, 1u + u / 2, q);
       const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
-      const double pm = io.series[(T::NLOAD + g) * io.period + aux];
+      const double pm = ser[(T::NLOAD + g) * io.period + aux];
       s0[d] = pm;
       s0[2 * T::ND + T::NDES + g] = pm;
       s0[T::ND + d] = sd[SD_QMIN] + (sd[SD_QMAX] - sd[SD_QMIN]) * uu;
@@ -311,6 +313,7 @@ struct StepIn {
   double exo[Dims<T>::NEXO > 0 ? Dims<T>::NEXO : 1];   // generic mode only
   double soc[T::NDES > 0 ? T::NDES : 1];
   double aux_prev;                                       // series mode: time index before the step
+  int aux_next = -1;                                     // ... or, >= 0, the next one, already formed (integer callers)
   int reset_count;
 };
 
@@ -347,9 +350,10 @@ struct StepCtx {
 };
 
 // first half of a step: inputs -> device maps, bus sums, up to `iter_cap` Newton iterations
-template <class T, class JT, class CD>
+template <class T, class JT, class CD, class SER = const double*>
 ANM_HD void step_begin(cptr_t C, CD Cd, const EnvIO& io, SolverOpts so, int64_t e, const StepIn<T>& in, StepCtx<T>& ctx,
-                       EnvWork<T>& w, PFState<T>& st, int iter_cap) {
+                       EnvWork<T>& w, PFState<T>& st, int iter_cap, SER ser = nullptr) {
+  if constexpr (std::is_same<SER, const double*>::value) { if (!ser) ser = io.series; }
   typedef Layout<T> L;
   const bool series = io.exo == nullptr;
   ctx.resetting = in.was_term && io.autoreset && series;
@@ -364,15 +368,16 @@ ANM_HD void step_begin(cptr_t C, CD Cd, const EnvIO& io, SolverOpts so, int64_t 
   int aux = 0;
   if (ctx.resetting) {
     double s0[T::SDIM + 1];  // sampled initial state (K == 1 in series mode)
-    aux = sample_series_init_state<T>(C, io, e, uint32_t(in.reset_count), s0);
+    aux = sample_series_init_state<T>(C, io, e, uint32_t(in.reset_count), s0, ser);
     static_for<0, T::NDES>([&](auto I) { ctx.soc_req[I] = s0[2 * T::ND + I]; });
     inputs_from_init_state<T>(C, s0, w, P_load, P_pot, P_set, Q_set);
   } else {
     // 1. exogenous variables (next_vars, anm6_easy.py:54-65 in series mode)
     if (series) {
-      aux = int(fmod(in.aux_prev + 1.0, double(io.period)));
-      static_for<0, T::NLOAD>([&](auto I) { P_load[I] = io.series[I * io.period + aux]; });
-      static_for<0, T::NGEN>([&](auto I) { P_pot[I] = io.series[(T::NLOAD + I) * io.period + aux]; });
+      // (a caller that keeps the time index as an integer has formed the next one itself: in.aux_next >= 0)
+      aux = in.aux_next >= 0 ? in.aux_next : int(fmod(in.aux_prev + 1.0, double(io.period)));
+      static_for<0, T::NLOAD>([&](auto I) { P_load[I] = ser[I * io.period + aux]; });
+      static_for<0, T::NGEN>([&](auto I) { P_pot[I] = ser[(T::NLOAD + I) * io.period + aux]; });
     } else {
       static_for<0, T::NLOAD>([&](auto I) { P_load[I] = in.exo[I]; });
       static_for<0, T::NGEN>([&](auto I) { P_pot[I] = in.exo[T::NLOAD + I]; });
@@ -449,15 +454,15 @@ ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const 
   if (!term) {
     // reward clipping (anm_env.py:423-427)
     const double sg = (w.e_loss > 0.0) ? 1.0 : ((w.e_loss < 0.0) ? -1.0 : 0.0);
-    const double el = sg * fmin(fabs(w.e_loss), c1);
-    const double pn = fmin(fmax(w.penalty, 0.0), c2);
+    const double el = sg * vmin(fabs(w.e_loss), c1);
+    const double pn = vmin(vmax(w.penalty, 0.0), c2);
     out.e_loss = el;
     out.penalty = pn;
     out.reward = -(el + pn);
     write_state_obs<T>(C, w, out);
     if (series) {
       out.put_st(T::SDIM, double(ctx.aux));
-      out.put_ob(T::SDIM, fmin(fmax(double(ctx.aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]));
+      out.put_ob(T::SDIM, vmin(vmax(double(ctx.aux), C[L::OBS_LO + T::SDIM]), C[L::OBS_HI + T::SDIM]));
     } else {
       if (io.K > 0) {
         static_for<0, KCAP>([&](auto Kc) {  // unconditional stores, see finish_reset
@@ -597,104 +602,11 @@ __device__ int64_t load_record(const double* r, StepCtx<T>& ctx, EnvWork<T>& w, 
   return int64_t(r[R::E]);
 }
 
-// I/O layer 2 (GPU, series mode, K = 1): one wavefront = 64 consecutive environments whose action /
-// state / obs rows are contiguous in memory.  Rows travel through LDS so that every global access is
-// a fully coalesced 512-byte wave transaction (the plain layer issues 16-byte stores with a 144-byte
-// lane stride: every store instruction touches 64 cache lines and partial lines are written twice).
-// The time index is kept in a compact int32 array instead of being re-read from the state rows.
-// FULL: also write the `full` electrical-state dump (a separate instantiation: the dump costs the
-// default kernel its second wave per SIMD)
-template <class T, class JT, bool FULL>
-__device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n, double* lds) {
-  typedef Dims<T> D;
+template <class T, bool FULL>
+__device__ __forceinline__ void epilogue_stores(const EnvIO& io, int64_t e0, int64_t e, int lane, bool store, int32_t ts_prev,
+                                                StepOut<T, 1>& out, const EnvWork<T>& w, double* lds) {
   constexpr int S = T::SDIM + 1;
-  constexpr int SP = S + 1;  // padded row stride (odd number of doubles: conflict-free column access)
-  const int lane = threadIdx.x;
-  const int64_t e0 = int64_t(blockIdx.x) * 64;
-  const int64_t e = e0 + lane;
-  const bool valid = e < n;
-  const int64_t ec = valid ? e : n - 1;
-  const int rows = int((n - e0) < 64 ? (n - e0) : 64);
-  ANM_PHASE(7);  // kernel entry
-  StepIn<T> in;
-  StepOut<T, 1> out;
-  StepCtx<T> ctx;
-  PFState<T> st;
-  EnvWork<T> w;
-  // the per-environment scalars first: their loads are then in flight together with the action rows (behind the fences
-  // of the transposition below they would wait for a second trip to memory)
-  in.was_term = io.terminated[ec] != 0;
-  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
-  in.aux_prev = double(io.aux_index[ec]);
-  in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
-  const int32_t ts_prev = io.timestep ? io.timestep[ec] : 0;  // read now: the epilogue only stores
-  // ---- coalesced loads: 64 x ADIM doubles of actions
-  {
-    const double* g = io.action + e0 * D::ADIM;
-    constexpr int AP = D::ADIM + 1;
-    // all loads are issued before the first use (one exposed memory latency, not ADIM of them):
-    // out-of-range lanes re-read the last element instead of branching around the load
-    const int last = rows * D::ADIM - 1;
-    double tmp[D::ADIM > 0 ? D::ADIM : 1];
-    static_for<0, D::ADIM>([&](auto J) {
-      const int idx = J * 64 + lane;
-      tmp[J] = g[idx < last ? idx : last];
-    });
-    static_for<0, D::ADIM>([&](auto J) {
-      const int idx = J * 64 + lane;
-      if (idx <= last) lds[(idx / D::ADIM) * AP + (idx % D::ADIM)] = tmp[J];
-    });
-    ANM_WAVE_SYNC();
-    const int lr = valid ? lane : rows - 1;
-    static_for<0, D::ADIM>([&](auto I) { in.action[I] = lds[lr * AP + I]; });
-    ANM_WAVE_SYNC();
-  }
-
-  const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
-  step_begin<T, JT>(C, C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
-  bool pending = false;
-  // in-wave straggler hand-over (anm_group.hpp): tree topologies.  In the two-launch mode the straggler launch
-  // does the continuing (on lane groups as well, op_step_stragglers); only solves that found no record slot
-  // continue here.
-  constexpr bool CAN_GROUP = T::TREE != 0 && group::Shape<T>::NG * group::Slot<T>::SIZE <= 64 * (T::SDIM + 2);
-  const int handoff = (CAN_GROUP && !two_phase && so.handoff >= 0 && so.handoff < so.max_iter) ? so.handoff : -1;
-  const bool overflow_to_groups = CAN_GROUP && two_phase && so.handoff >= 0 && so.handoff < so.max_iter;
-  int cap = two_phase ? io.iter_cap : (handoff >= 0 ? handoff : so.max_iter);
-  // One copy of the Newton loop serves both passes (a second inlined copy costs registers and code):
-  // pass 0 iterates up to `cap`; in two-launch mode the environments still iterating are then handed
-  // to the straggler launch, and pass 1 only runs for those that found no record slot (thread mode only).
-#pragma nounroll
-  for (int pass = 0; pass < 2; ++pass) {
-    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, cap);
-    if (!two_phase || pass == 1) break;
-    int* cnt = reinterpret_cast<int*>(io.ws);  // cnt[0]: records of this step (zeroed by the scatter launch)
-    {
-      // one reservation per wavefront (the lanes' ranks order its slots), not one atomic per straggler
-      const unsigned long long am = __ballot(valid && st.active);
-      if (am != 0ull) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(cnt, __popcll(am));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int slot = base + __popcll(am & ((1ull << lane) - 1ull));
-        if (valid && st.active && slot < io.ws_cap) {
-          save_record<T>(io.ws + Rec<T>::HEADER + int64_t(slot) * Rec<T>::SIZE, e, ctx, w, st);
-          pending = true;
-        }
-      }
-    }
-    if (pending) {  // handed over: this lane's own solve ends here (its outputs are not stored)
-      st.diff = 0.0;
-      st.active = false;
-    }
-    cap = so.max_iter;
-    if (overflow_to_groups || !ANM_WAVE_ANY(st.active)) break;  // else: record space exhausted (or a padding lane)
-  }
-  if constexpr (CAN_GROUP) {
-    if ((handoff >= 0 || overflow_to_groups) && ANM_WAVE_ANY(st.active && valid))
-      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
-  }
-  step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
-  const bool store = valid && !pending;
+  constexpr int SP = S + 1;
   // obs = clip(state) almost always IS the state: the duplicate row is then not written, only a flag
   bool state_dup = false;
   if (io.state_same) {
@@ -742,6 +654,124 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   store_rows(io.state + e0 * S, out.state, out.write_state && !state_dup);
   store_rows(io.obs + e0 * S, out.obs, out.write_obs);
   ANM_PHASE(6);
+}
+
+// I/O layer 2 (GPU, series mode, K = 1): one wavefront = 64 consecutive environments whose action /
+// state / obs rows are contiguous in memory.  Rows travel through LDS so that every global access is
+// a fully coalesced 512-byte wave transaction (the plain layer issues 16-byte stores with a 144-byte
+// lane stride: every store instruction touches 64 cache lines and partial lines are written twice).
+// The time index is kept in a compact int32 array instead of being re-read from the state rows.
+// FULL: also write the `full` electrical-state dump (a separate instantiation: the dump costs the
+// default kernel its second wave per SIMD)
+// (Measured and left out, profiles/r05_c_*: the epilogue re-reading its dozen output pointers from the kernarg segment instead of
+// keeping them in scalar registers through the whole kernel -- 80 fewer SGPR spills to vector lanes, nothing gained in the
+// throughput regime and 1.8 us LOST on the headline, where the epilogue of the chain-holding wavefront then starts with a
+// scalar load it has to wait for.)
+// (Measured and left out, profiles/r05_c_*: the series table copied to LDS by every wavefront, so that the look-up by the time
+// index is no second, dependent trip to memory -- 524 288 environments 176.3 -> 180.7 us: the trip hides behind the first
+// scalar loads of the constants, the copy does not.)
+template <class T, class JT, bool FULL>
+__device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n, double* lds) {
+  typedef Dims<T> D;
+  constexpr int S = T::SDIM + 1;
+  constexpr int SP = S + 1;  // padded row stride (odd number of doubles: conflict-free column access)
+  const int lane = threadIdx.x;
+  const int64_t e0 = int64_t(blockIdx.x) * 64;
+  const int64_t e = e0 + lane;
+  const bool valid = e < n;
+  const int64_t ec = valid ? e : n - 1;
+  const int rows = int((n - e0) < 64 ? (n - e0) : 64);
+  ANM_PHASE(7);  // kernel entry
+  StepIn<T> in;
+  StepOut<T, 1> out;
+  StepCtx<T> ctx;
+  PFState<T> st;
+  EnvWork<T> w;
+  // the per-environment scalars first: their loads are then in flight together with the action rows (behind the fences
+  // of the transposition below they would wait for a second trip to memory)
+  in.was_term = io.terminated[ec] != 0;
+  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[ec * T::NDES + I]; });
+  const int32_t aux_prev_i = io.aux_index[ec];
+  in.aux_prev = double(aux_prev_i);
+  in.reset_count = io.autoreset ? io.reset_count[ec] : 0;
+  const int32_t ts_prev = io.timestep ? io.timestep[ec] : 0;  // read now: the epilogue only stores
+
+  // ---- coalesced loads: 64 x ADIM doubles of actions
+  {
+    const double* g = io.action + e0 * D::ADIM;
+    constexpr int AP = D::ADIM + 1;
+    // all loads are issued before the first use (one exposed memory latency, not ADIM of them):
+    // out-of-range lanes re-read the last element instead of branching around the load
+    const int last = rows * D::ADIM - 1;
+    double tmp[D::ADIM > 0 ? D::ADIM : 1];
+    static_for<0, D::ADIM>([&](auto J) {
+      const int idx = J * 64 + lane;
+      tmp[J] = g[idx < last ? idx : last];
+    });
+    static_for<0, D::ADIM>([&](auto J) {
+      const int idx = J * 64 + lane;
+      if (idx <= last) lds[(idx / D::ADIM) * AP + (idx % D::ADIM)] = tmp[J];
+    });
+    ANM_WAVE_SYNC();
+    const int lr = valid ? lane : rows - 1;
+    static_for<0, D::ADIM>([&](auto I) { in.action[I] = lds[lr * AP + I]; });
+    ANM_WAVE_SYNC();
+  }
+  {
+    // the next time index from the integer one: (t + 1) mod period for t in [0, period) without a division; anything else
+    // (an initial state handed over with a time index beyond the period) goes through the reference's own expression
+    const int t1 = aux_prev_i + 1;
+    int an = t1 - (t1 >= io.period ? io.period : 0);
+    if (ANM_WAVE_ANY(an < 0 || an >= io.period)) an = int(fmod(in.aux_prev + 1.0, double(io.period)));
+    in.aux_next = an;
+  }
+
+  const bool two_phase = io.ws != nullptr && io.iter_cap < so.max_iter;
+  step_begin<T, JT>(C, C, io, so, ec, in, ctx, w, st, -1);  // device maps, bus sums, flat start; iterated below
+  bool pending = false;
+  // in-wave straggler hand-over (anm_group.hpp): tree topologies.  In the two-launch mode the straggler launch
+  // does the continuing (on lane groups as well, op_step_stragglers); only solves that found no record slot
+  // continue here.
+  constexpr bool CAN_GROUP = T::TREE != 0 && group::Shape<T>::NG * group::Slot<T>::SIZE <= 64 * (T::SDIM + 2);
+  const int handoff = (CAN_GROUP && !two_phase && so.handoff >= 0 && so.handoff < so.max_iter) ? so.handoff : -1;
+  const bool overflow_to_groups = CAN_GROUP && two_phase && so.handoff >= 0 && so.handoff < so.max_iter;
+  int cap = two_phase ? io.iter_cap : (handoff >= 0 ? handoff : so.max_iter);
+  // One copy of the Newton loop serves both passes (a second inlined copy costs registers and code):
+  // pass 0 iterates up to `cap`; in two-launch mode the environments still iterating are then handed
+  // to the straggler launch, and pass 1 only runs for those that found no record slot (thread mode only).
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+    pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, cap);
+    if (!two_phase || pass == 1) break;
+    int* cnt = reinterpret_cast<int*>(io.ws);  // cnt[0]: records of this step (zeroed by the scatter launch)
+    {
+      // one reservation per wavefront (the lanes' ranks order its slots), not one atomic per straggler
+      const unsigned long long am = __ballot(valid && st.active);
+      if (am != 0ull) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(cnt, __popcll(am));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int slot = base + __popcll(am & ((1ull << lane) - 1ull));
+        if (valid && st.active && slot < io.ws_cap) {
+          save_record<T>(io.ws + Rec<T>::HEADER + int64_t(slot) * Rec<T>::SIZE, e, ctx, w, st);
+          pending = true;
+        }
+      }
+    }
+    if (pending) {  // handed over: this lane's own solve ends here (its outputs are not stored)
+      st.diff = 0.0;
+      st.active = false;
+    }
+    cap = so.max_iter;
+    if (overflow_to_groups || !ANM_WAVE_ANY(st.active)) break;  // else: record space exhausted (or a padding lane)
+  }
+  if constexpr (CAN_GROUP) {
+    if ((handoff >= 0 || overflow_to_groups) && ANM_WAVE_ANY(st.active && valid))
+      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
+  }
+  step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
+  const bool store = valid && !pending;
+  epilogue_stores<T, FULL>(io, e0, e, lane, store, ts_prev, out, w, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
