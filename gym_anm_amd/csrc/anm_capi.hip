@@ -216,6 +216,13 @@ int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const rad
   return 0;
 }
 
+// the lane-group families gather a list-form observation from one LDS row of the electrical state per environment
+// (FS + KMAX doubles): the radial kernel in dynamic LDS next to its static 6 KB, the general kernel where its Jacobian
+// blocks were
+size_t radial_obs_lds_bytes(const anm_model* m) {
+  return size_t(64 / m->plan.d.G) * size_t(m->plan.d.FS + radial::KMAX) * sizeof(double);
+}
+
 int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
   const int per_wave = 64 / m->plan.d.G;
   const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
@@ -224,7 +231,8 @@ int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const r
   if constexpr (Topo::TREE != 0) spec = m->tpe_ok && m->plan.d.G == Topo::GRP && !getenv("ANM_RADIAL_GENERIC");
   const ClassSel cs = class_sel(m, true);
   const bool f32 = precision == ANM_SOLVE_F32;
-  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, cs); };
+  const size_t obs_lds = (io.mode == 2 && io.e.n_obs > 0) ? radial_obs_lds_bytes(m) : 0;   // rows of a list-form observation
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(64), obs_lds, s, m->plan.d, m->d_ri, m->d_rd, io, so, n, cs); };
   if (spec) {
     if constexpr (Topo::TREE != 0) {
       if (cs.per_group) { if (f32) go(radial::k_radial<float, Topo, true>); else go(radial::k_radial<double, Topo, true>); }
@@ -626,9 +634,9 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
   // (the same guard as anm_model_set_impl: the lane-group kernels do not gather a list-form observation -- moving a
   // model with one to them would silently turn its observation into clip(state))
   if (!blocks && m->impl == ANM_IMPL_THREAD && m->n_obs > 0)
-    return fail("anm_model_bind_env_classes: classes that change inside blocks of 64 environments need a lane-group kernel, "
-                "and a list-form observation (anm_model_set_obs) is gathered by the thread-per-environment step kernel only: "
-                "clear it first (anm_model_set_obs with n_obs = 0) or bind the classes in aligned blocks of 64");
+    return fail("anm_model_bind_env_classes: classes that change inside blocks of 64 environments move the model to a lane-group "
+                "kernel, and the list-form observation that is set (anm_model_set_obs) has the tables of the thread-per-environment "
+                "kernel: clear it first (n_obs = 0) and set it again after binding, or bind the classes in aligned blocks of 64");
   m->class_per_env = !blocks;
   m->d_env_class = env_class;
   if (blocks) restore_impl();
@@ -668,7 +676,7 @@ int anm_model_bind_view(anm_model* m, const anm_batch_view* v) {
   }
   if (!m->mesh_ok) return fail("anm_model_bind_view: a view is served by the general lane-group kernel, which cannot take this network");
   if (m->d_env_class) return fail("anm_model_bind_view: not together with parameter classes (anm_model_bind_env_classes)");
-  if (m->n_obs > 0) return fail("anm_model_bind_view: a list-form observation is gathered by the thread-per-environment step kernel only");
+  if (m->n_obs > 0) return fail("anm_model_bind_view: not together with a list-form observation (anm_model_set_obs): clear it first");
   if (m->d_state_same) return fail("anm_model_bind_view: not together with anm_model_bind_state_same (the flags are indexed by launch slot)");
   const mesh::Dims& d = m->mplan.d;
   const int K = m->K;
@@ -694,8 +702,12 @@ int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
 static unsigned magic_div(int d) { return d > 0 ? unsigned((0x100000000ull + uint64_t(d) - 1) / uint64_t(d)) : 0u; }
 
 int anm_model_obs_fusable(const anm_model* m) {
-  // (only the thread-per-environment step kernel gathers; the lane-group families write state / obs = clip(state))
-  return (m && m->tpe_ok && m->impl == ANM_IMPL_THREAD && GenLds<Topo>::FULL_OK) ? 1 : 0;
+  if (!m) return 0;
+  if (m->view.index || m->view.w_state > 0) return 0;
+  if (m->impl == ANM_IMPL_THREAD) return (m->tpe_ok && GenLds<Topo>::FULL_OK) ? 1 : 0;
+  if (m->impl == ANM_IMPL_RADIAL) return (m->radial_ok && radial_obs_lds_bytes(m) <= 48 * 1024) ? 1 : 0;
+  if (m->impl == ANM_IMPL_MESH) return (m->mesh_ok && m->mplan.d.l_bw - m->mplan.d.l_blk >= m->mplan.d.FS + radial::KMAX) ? 1 : 0;
+  return 0;
 }
 
 int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const double* scale, const double* low,
@@ -709,6 +721,46 @@ int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const d
     return fail("anm_model_set_obs: this model cannot gather inside the step kernel (use anm_gather_obs_f64)");
   if (!index || !scale || !low || !high) return fail("anm_model_set_obs: null argument");
   if (n_obs > 4096) return fail("anm_model_set_obs: more than 4096 observation entries");
+  if (m->impl != ANM_IMPL_THREAD) {
+    // lane-group families: the identity layout of `full` (runtime offsets of the network), the classes the list reads
+    const bool rad = m->impl == ANM_IMPL_RADIAL;
+    const int FS = rad ? m->plan.d.FS : m->mplan.d.FS;
+    int base[FC_COUNT + 1];
+    if (rad) {
+      const radial::Dims& d = m->plan.d;
+      const int b[FC_COUNT] = {d.f_bus_p, d.f_bus_q, d.f_bus_vm, d.f_bus_va, d.f_bus_im, d.f_bus_ia, d.f_dev_p, d.f_dev_q, d.f_des_soc,
+                               d.f_gen_pmax, d.f_br_p, d.f_br_q, d.f_br_s, d.f_br_im, d.f_br_ia};
+      for (unsigned c = 0; c < FC_COUNT; ++c) base[c] = b[c];
+    } else {
+      const mesh::Dims& d = m->mplan.d;
+      const int b[FC_COUNT] = {d.f_bus_p, d.f_bus_q, d.f_bus_vm, d.f_bus_va, d.f_bus_im, d.f_bus_ia, d.f_dev_p, d.f_dev_q, d.f_des_soc,
+                               d.f_gen_pmax, d.f_br_p, d.f_br_q, d.f_br_s, d.f_br_im, d.f_br_ia};
+      for (unsigned c = 0; c < FC_COUNT; ++c) base[c] = b[c];
+    }
+    base[FC_COUNT] = FS;
+    unsigned need = 0;
+    std::vector<int32_t> idx(2 * size_t(n_obs));
+    for (int k = 0; k < n_obs; ++k) {
+      const int i = index[k];
+      if (i < 0 || i >= FS + radial::KMAX) return fail("anm_model_set_obs: index out of range");
+      if (i < FS) {
+        unsigned c = 0;
+        while (c + 1 < FC_COUNT && base[c + 1] <= i) ++c;
+        need |= 1u << c;
+      }
+      idx[k] = idx[n_obs + k] = i;   // (both halves: the identity layout)
+    }
+    std::vector<double> tab(3 * size_t(n_obs));
+    for (int k = 0; k < n_obs; ++k) { tab[k] = scale[k]; tab[n_obs + k] = low[k]; tab[2 * n_obs + k] = high[k]; }
+    hipError_t e = hipMalloc(&m->d_obs_index, idx.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&m->d_obs_tab, tab.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(m->d_obs_index, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_obs_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip(e, "anm_model_set_obs");
+    m->obs_need = need;
+    m->n_obs = n_obs;
+    return 0;
+  }
   typedef FullState<Topo> F;
   const int FS = F::SIZE;
   int cls_size[FC_COUNT];
@@ -770,9 +822,9 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
                 "lane-group kernel can serve them");
   if (impl != ANM_IMPL_MESH && (m->view.index || m->view.w_state > 0))
     return fail("anm_model_set_impl: a batch view is bound (anm_model_bind_view): only the general lane-group kernel serves it");
-  if (impl != ANM_IMPL_THREAD && m->n_obs > 0)
-    return fail("anm_model_set_impl: a list-form observation is gathered inside the thread-per-environment step kernel "
-                "(anm_model_set_obs); clear it before switching to a lane-group kernel");
+  if (impl != m->impl && m->n_obs > 0)
+    return fail("anm_model_set_impl: a list-form observation is set (anm_model_set_obs), whose tables belong to the current "
+                "kernel family; clear it before switching and set it again afterwards");
   m->impl = impl;
   m->impl_unbound = -1;   // an explicit choice is not undone by a later unbind
   return 0;
@@ -909,7 +961,7 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
   io.state_same = m->d_state_same;
   io.n_obs = 0;
   io.state_magic = magic_div((m->tpe_ok ? Topo::SDIM : (m->radial_ok ? m->plan.d.SDIM : m->mplan.d.SDIM)) + m->K);
-  if (m->tpe_ok && (m->n_obs > 0 || full)) {
+  if (m->tpe_ok && m->impl == ANM_IMPL_THREAD && (m->n_obs > 0 || full)) {
     // rows of the electrical state in LDS: identity layout when the dump is asked for, else only the classes
     // the observation list reads
     const bool ident = full != nullptr;
@@ -926,6 +978,14 @@ static int make_step_io(anm_model* m, const double* action, const double* exo, c
       io.obs_lo = m->d_obs_tab + m->n_obs;
       io.obs_hi = m->d_obs_tab + 2 * m->n_obs;
     }
+  }
+  if (m->impl != ANM_IMPL_THREAD && m->n_obs > 0) {   // lane-group families: identity layout (see anm_model_set_obs)
+    io.n_obs = m->n_obs;
+    io.obs_need = m->obs_need;
+    io.obs_index = m->d_obs_index;
+    io.obs_scale = m->d_obs_tab;
+    io.obs_lo = m->d_obs_tab + m->n_obs;
+    io.obs_hi = m->d_obs_tab + 2 * m->n_obs;
   }
   io.ws = nullptr;
   if (ws && ws->buf && m->tpe_ok && !m->d_env_class) {  // (the straggler launch packs records of all blocks together)

@@ -1241,15 +1241,63 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
   }
 
   double* state = io.e.state + e * W_ST;
-  double* obs = io.e.obs + e * W_ST;
+  // the observation: clip(state, Box) next to the state row, or (a list is set: anm_env.py:497-521, 562-592; see
+  // anm_radial.hpp) n_obs entries gathered from this environment's electrical state
+  const bool list = mode == 2 && io.e.n_obs > 0;
+  const int OW = list ? io.e.n_obs : W_ST;
+  double* obs = io.e.obs + e * OW;
   cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
   auto put = [&](int k, double v) {
     state[k] = v;
-    obs[k] = fmin(fmax(v, lo[k]), hi[k]);
+    if (!list) obs[k] = fmin(fmax(v, lo[k]), hi[k]);
+  };
+  auto list_obs = [&](bool zero) {
+    if (!list) return;
+    if (zero) {   // terminal / absorbing: the observation is 0 (anm_env.py:365-367, 442-446)
+      for (int k = l; k < OW; k += G) obs[k] = 0.0;
+      return;
+    }
+    // the row lives where the Jacobian blocks were (l_blk ... l_bw: free once the solve is over; anm_model_set_obs has
+    // checked that FS + KMAX doubles fit there)
+    double* row = S + d.l_blk;
+    const unsigned need = io.e.obs_need;
+    auto want = [&](unsigned c) { return ((need >> c) & 1u) != 0u; };
+    ANM_MESH_SYNC();   // (every lane is done with the areas the row overwrites)
+    if (isbus) {
+      row[d.f_bus_p + bus] = bus_p; row[d.f_bus_q + bus] = bus_q;
+      if (want(FC_BUS_VM)) row[d.f_bus_vm + bus] = dump_abs(vr, vi);
+      if (want(FC_BUS_VA)) row[d.f_bus_va + bus] = dump_arg(vi, vr);
+      if (want(FC_BUS_IM)) row[d.f_bus_im + bus] = dump_abs(ir, ii);
+      if (want(FC_BUS_IA)) row[d.f_bus_ia + bus] = dump_arg(ii, ir);
+    }
+#pragma unroll
+    for (int sl = 0; sl < BR_SLOTS; ++sl)
+      if (isbr[sl]) {
+        const int b = sl * G + l;
+        row[d.f_br_p + b] = br_pf[sl]; row[d.f_br_q + b] = br_qf[sl]; row[d.f_br_s + b] = br_s[sl];
+        if (want(FC_BR_IM)) row[d.f_br_im + b] = dump_signed_abs(br_ifr[sl], dump_abs(br_ifr[sl], br_ifi[sl]));
+        if (want(FC_BR_IA)) row[d.f_br_ia + b] = dump_arg(br_ifi[sl], br_ifr[sl]);
+      }
+    if (l == 0) {
+      row[d.f_bus_p] = slack_p; row[d.f_bus_q] = slack_q; row[d.f_bus_vm] = 1.0; row[d.f_bus_va] = 0.0;
+      if (want(FC_BUS_IM)) row[d.f_bus_im] = dump_abs(i0r, i0i);
+      if (want(FC_BUS_IA)) row[d.f_bus_ia] = dump_arg(i0i, i0r);
+    }
+    if (typ != DEV_NONE) { row[d.f_dev_p + l] = dev_p; row[d.f_dev_q + l] = dev_q; }
+    if (typ == DEV_STORAGE) row[d.f_des_soc + slot] = soc;
+    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) row[d.f_gen_pmax + slot] = p_pot;
+    if (resetting || io.e.exo == nullptr) { if (l == 0) row[d.FS] = double(aux); }
+    else for (int k = l; k < K; k += G) row[d.FS + k] = io.e.aux_next[e * W_AUX + k];
+    ANM_MESH_SYNC();
+    for (int k = l; k < OW; k += G) {
+      const double v = row[io.e.obs_index[k]] * io.e.obs_scale[k];
+      obs[k] = fmin(fmax(v, io.e.obs_lo[k]), io.e.obs_hi[k]);
+    }
   };
   if (skip) {
     if (mode == 2) {  // absorbing terminal state
-      for (int k = l; k < SD_; k += G) obs[k] = 0.0;
+      if (list) list_obs(true);
+      else for (int k = l; k < SD_; k += G) obs[k] = 0.0;
       if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
     }
     return;
@@ -1261,7 +1309,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       io.e.soc[e * W_DES + slot] = soc;
     }
     if (mode == 2 && !converged) {
-      for (int k = l; k < SD_; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+      for (int k = l; k < SD_; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }
     } else {
       if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
       if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
@@ -1284,6 +1332,7 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
         if (io.e.timestep) io.e.timestep[e] = 0;
         io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
       }
+      list_obs(!converged);
     }
     write_full();
     return;
@@ -1300,8 +1349,9 @@ __global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __re
       for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * W_AUX + k]);
     }
   } else {
-    for (int k = l; k < SD_; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+    for (int k = l; k < SD_; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }
   }
+  list_obs(term);
   if (l == 0) {
     const double c1 = rd[SF_C1], c2 = rd[SF_C2];
     io.e.terminated[e] = term ? 1 : 0;

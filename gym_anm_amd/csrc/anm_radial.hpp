@@ -280,6 +280,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   double2* const pU = pV + 64;
   double2* const pS = pV + 128;
   __shared__ int sh_lists[256];  // children / bus-device index lists (read every Newton iteration)
+  // list-form observation gathered in this kernel (anm_model_set_obs; step mode): one row of the electrical state per
+  // environment, FS + KMAX doubles (the layout of `full`, the aux variables behind it) -- dynamic, 0 bytes without a list
+  extern __shared__ double sh_obs_rows[];
   const int t = threadIdx.x;
   const int G = d.G;
   const int l = t & (G - 1);
@@ -721,15 +724,62 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   }
 
   double* state = io.e.state + e * S;
-  double* obs = io.e.obs + e * S;
+  // the observation: clip(state, Box) next to the state row, or (a list is set: anm_env.py:497-521, 562-592) n_obs entries
+  // gathered from this environment's electrical state
+  const bool list = mode == 2 && io.e.n_obs > 0;
+  const int OW = list ? io.e.n_obs : S;
+  double* obs = io.e.obs + e * OW;
   cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
   auto put = [&](int k, double v) {
     state[k] = v;
-    obs[k] = fmin(fmax(v, lo[k]), hi[k]);
+    if (!list) obs[k] = fmin(fmax(v, lo[k]), hi[k]);
+  };
+  // (called by all lanes of an environment together -- every condition around it is uniform over the lane group -- so the
+  // row is written and read back in program order of one control path: LDS operations of a wavefront complete in order)
+  auto list_obs = [&](bool zero) {
+    if (!list) return;
+    if (zero) {   // terminal / absorbing: the observation is 0 (anm_env.py:365-367, 442-446)
+      for (int k = l; k < OW; k += G) obs[k] = 0.0;
+      return;
+    }
+    double* row = sh_obs_rows + (t / G) * (d.FS + KMAX);
+    const unsigned need = io.e.obs_need;
+    auto want = [&](unsigned c) { return ((need >> c) & 1u) != 0u; };
+    if (isbus) {
+      const int b = l + 1, bi = RI(IF_BR_INDEX);
+      if (want(FC_BUS_P)) row[d.f_bus_p + b] = bus_p;
+      if (want(FC_BUS_Q)) row[d.f_bus_q + b] = bus_q;
+      if (want(FC_BUS_VM)) row[d.f_bus_vm + b] = dump_abs(vr, vi);
+      if (want(FC_BUS_VA)) row[d.f_bus_va + b] = dump_arg(vi, vr);
+      if (want(FC_BUS_IM)) row[d.f_bus_im + b] = dump_abs(ir, ii);
+      if (want(FC_BUS_IA)) row[d.f_bus_ia + b] = dump_arg(ii, ir);
+      if (want(FC_BR_P)) row[d.f_br_p + bi] = br_pf;
+      if (want(FC_BR_Q)) row[d.f_br_q + bi] = br_qf;
+      if (want(FC_BR_S)) row[d.f_br_s + bi] = br_s;
+      if (want(FC_BR_IM)) row[d.f_br_im + bi] = dump_signed_abs(br_ifr, dump_abs(br_ifr, br_ifi));
+      if (want(FC_BR_IA)) row[d.f_br_ia + bi] = dump_arg(br_ifi, br_ifr);
+    }
+    if (l == 0) {
+      row[d.f_bus_p] = slack_p; row[d.f_bus_q] = slack_q; row[d.f_bus_vm] = 1.0; row[d.f_bus_va] = 0.0;
+      if (want(FC_BUS_IM)) row[d.f_bus_im] = dump_abs(i0r, i0i);
+      if (want(FC_BUS_IA)) row[d.f_bus_ia] = dump_arg(i0i, i0r);
+    }
+    if (typ != DEV_NONE) { row[d.f_dev_p + l] = dev_p; row[d.f_dev_q + l] = dev_q; }
+    if (typ == DEV_STORAGE) row[d.f_des_soc + slot] = soc;
+    if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) row[d.f_gen_pmax + slot] = p_pot;
+    // the aux variables sit behind the electrical state
+    if (resetting || io.e.exo == nullptr) { if (l == 0) row[d.FS] = double(aux); }
+    else for (int k = l; k < K; k += G) row[d.FS + k] = io.e.aux_next[e * K + k];
+    ANM_GROUP_SYNC();
+    for (int k = l; k < OW; k += G) {
+      const double v = row[io.e.obs_index[k]] * io.e.obs_scale[k];
+      obs[k] = fmin(fmax(v, io.e.obs_lo[k]), io.e.obs_hi[k]);
+    }
   };
   if (skip) {
     if (mode == 2) {  // absorbing terminal state
-      for (int k = l; k < S; k += G) obs[k] = 0.0;
+      if (list) list_obs(true);
+      else for (int k = l; k < S; k += G) obs[k] = 0.0;
       if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
     }
     break;
@@ -743,7 +793,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (mode == 2 && !converged) {
       // a redraw whose first power flow does not converge looks like the absorbing terminal state
       // until the next call draws again
-      for (int k = l; k < S; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+      for (int k = l; k < S; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }
     } else {
       if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
       if (typ == DEV_STORAGE) put(2 * d.ND + slot, soc * base);
@@ -766,6 +816,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         if (io.e.timestep) io.e.timestep[e] = 0;
         io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
       }
+      list_obs(!converged);
     }
     dump = true;
     break;
@@ -783,8 +834,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * K + k]);
     }
   } else {
-    for (int k = l; k < S; k += G) { state[k] = 0.0; obs[k] = 0.0; }
+    for (int k = l; k < S; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }
   }
+  list_obs(term);
   if (l == 0) {
     const double c1 = rd[SF_C1], c2 = rd[SF_C2];
     io.e.terminated[e] = term ? 1 : 0;

@@ -293,16 +293,19 @@ int anm_gather_obs_f64(int64_t num_envs, int32_t full_dim, const double* full, i
                        const double* state, const uint8_t* terminated, int32_t n_obs, const int32_t* index,
                        const double* scale, const double* low, const double* high, double* obs, void* stream);
 
-/* List-form observation produced INSIDE the step kernel (thread-per-environment family; the list form of
+/* List-form observation produced INSIDE the step kernel (every kernel family; the list form of
  * anm_env.py:497-521, 562-592): after this call anm_step_f64 writes obs as [E, n_obs] with
  *   obs[e, k] = clip(src(e, index[k]) * scale[k], low[k], high[k]),  0 for a terminated environment,
  * src(e, i) = entry i of the electrical state of the step (the layout of `full`, anm_model_full_layout)
  * for i < full_dim and aux variable i - full_dim beyond it.  Only the quantity classes the list names are
  * computed (no magnitude / angle that nobody observes), nothing is dumped to memory and no second launch
  * runs.  index/scale/low/high are HOST arrays of n_obs entries (copied).  n_obs = 0 restores the "state"
- * observation obs = clip(state).  anm_model_obs_fusable: 1 when the model supports this (implementation
- * ANM_IMPL_THREAD and its electrical state rows fit in LDS), else use `full` + anm_gather_obs_f64; while a list
- * is set, anm_model_set_impl refuses the lane-group implementations.  anm_reset_f64 is not affected. */
+ * observation obs = clip(state).  anm_model_obs_fusable: 1 when the model supports this under its current kernel family
+ * (thread per environment: its electrical-state rows fit in LDS; lane groups: one row of FS + 8 doubles per environment
+ * in LDS -- 48 KB per wavefront at most in the radial kernel, in place of the Jacobian blocks in the general one; not with a
+ * batch view), else use `full` + anm_gather_obs_f64.  The tables belong to the family that is current when the list is set:
+ * anm_model_set_impl and a class binding that would change the family are refused while a list is set (clear it, switch, set it
+ * again).  anm_reset_f64 is not affected. */
 int anm_model_obs_fusable(const anm_model* m);
 int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const double* scale, const double* low,
                       const double* high);

@@ -207,12 +207,62 @@ def test_all_state_variables_observation(fuse):
 
 
 @pytest.mark.parametrize("impl", ["radial", "mesh"])
-def test_all_state_variables_observation_lane_group_families(impl):
-    """The same list observation with the lane-group kernels of a library whose thread kernels WOULD fuse the gather:
-    only the thread-per-environment step kernel gathers, so these must take the dump + gather path (regression:
-    the fusable flag ignored the selected implementation and the observation was never gathered)."""
-    env = pc.all_state_variables_observation(lambda net: dict(KW(net), impl=impl))
-    assert env.simulator.impl == impl and not env._obs_fused
+@pytest.mark.parametrize("fuse", [True, False])
+def test_all_state_variables_observation_lane_group_families(impl, fuse):
+    """The same list observation through the lane-group kernels: gathered INSIDE the step kernel from the lanes that hold
+    the quantities (round 5: one LDS row per environment, no dump, no second launch) and, fuse=False, by the gather kernel
+    from the dump -- both against the golden transitions, and bit-equal to each other."""
+    env = pc.all_state_variables_observation(lambda net: dict(KW(net), impl=impl), fuse_observation=fuse)
+    assert env.simulator.impl == impl and env._obs_fused == fuse and env._need_full == (not fuse)
+
+
+@pytest.mark.parametrize("impl", ["radial", "mesh"])
+def test_fused_list_observation_of_a_30_bus_feeder_equals_the_gather_kernel(impl):
+    """config 4's network with a custom observation (anm_env.py:497-521, 562-592): 2 048 environments, host next_vars, 12 steps
+    with collapses; the fused gather of the lane-group kernel == dump + anm_gather_obs_f64, bit for bit, terminal rows zero."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs.anm_env import BatchedANMEnv
+
+    net = networks.synthetic_radial_network(30, 0)
+    spec = [("bus_v_magn", "all", "pu"), ("bus_v_ang", [3, 7, 29], "degree"), ("branch_s", "all", "MVA"), ("dev_p", "all", "MW"),
+            ("dev_q", [1, 5], "MVAr"), ("des_soc", "all", "MWh"), ("gen_p_max", "all", "MW"), ("bus_i_magn", [0, 12], "pu"),
+            ("branch_i_ang", [(0, 1)], "rad"), ("aux", "all")]  # fmt: skip
+    E_ = 2048
+
+    class Task(BatchedANMEnv):
+        def __init__(self, fuse):
+            super().__init__(net, spec, 2, 0.25, 0.995, 100, aux_bounds=np.array([[0, 50], [0, 1]]), num_envs=E_, device=DEV, impl=impl,
+                             fuse_observation=fuse, seed=5)
+
+        def next_vars(self, s):
+            return self._vars
+
+    a, b = Task(True), Task(False)
+    assert a._obs_fused and not b._obs_fused and a.simulator.impl == impl
+    m, base = a.simulator.model, a.simulator.baseMVA
+    g = torch.Generator(device="cpu").manual_seed(11)
+    U = lambda lo, hi: torch.as_tensor(lo) + (torch.as_tensor(hi) - torch.as_tensor(lo)) * torch.rand((E_, len(lo)), generator=g, dtype=torch.float64)
+    s0 = np.zeros((E_, a.state_N))
+    for env in (a, b):
+        env.check_actions = False
+        env.reset(options={"init_state": torch.as_tensor(s0)})
+    n_term = 0
+    for t in range(12):
+        scale = 1.0 + 0.35 * t   # heavier and heavier loads: collapses on the way
+        pl = U(m.dev_p_min[m.load_idx] * base * scale, 0 * m.dev_p_min[m.load_idx])
+        pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * base)
+        aux = torch.stack((torch.full((E_,), float(t)), torch.rand(E_, generator=g, dtype=torch.float64)), 1)
+        v = torch.cat((pl, pp, aux), 1).to(DEV)
+        act = U(a.action_space.low, a.action_space.high).to(DEV)
+        outs = []
+        for env in (a, b):
+            env._vars = v
+            o, r, term, _, _ = env.step(act)
+            outs.append((o.clone(), r.clone(), term.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), t
+        assert not bool(outs[0][0][outs[0][2]].any())
+        n_term = int(outs[0][2].sum())
+    assert 0 < n_term < E_
 
 
 def test_fused_list_observation_equals_the_gather_kernel_with_autoreset():
