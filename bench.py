@@ -264,6 +264,45 @@ def throughput_side_figure(dev, args, E=524288, n=60):
                      "note": "k_step_rows + k_step_stragglers + k_step_scatter per step; HIP events over %d steps" % n}}}
 
 
+def mixed_side_figure(dev, E=16384, n=40):
+    """Environments over DIFFERENT networks in one batch (gym_anm/envs/anm_env.py:79-156 builds one ANMEnv per network):
+    ANM6Easy, the 3-bus loop, a meshed 20-bus network and config 4's 30-bus feeder dealt at random to 16 384 environments,
+    series-mode tasks with autoreset, random agent; one launch per topology, each in its own kernel family, on its own
+    stream (MixedBatchedANMEnv) -- and the same launches one after the other on one stream."""
+    import numpy as np
+
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import MixedBatchedANMEnv
+    from gym_anm_amd.envs.anm6 import anm6easy_series
+    from gym_anm_amd.model import NetworkModel
+
+    def table(net, period, seed):
+        m = NetworkModel(net, 0.25, 100)
+        r, t = np.random.default_rng(seed), np.arange(period) / period
+        rows = [m.dev_p_min[k] * m.baseMVA * (0.25 + 0.3 * (1 + np.sin(2 * np.pi * (t + r.uniform())))) for k in m.load_idx]
+        rows += [m.dev_p_max[k] * m.baseMVA * (0.1 + 0.45 * (1 + np.sin(2 * np.pi * (t + r.uniform())))) for k in m.gen_idx]
+        return np.array(rows)
+
+    nets = [networks.anm6_network(), networks.three_bus_loop_network(gen_max=1.5), networks.synthetic_meshed_network(20, 3, 6),
+            networks.synthetic_radial_network(30, 0)]
+    series = [anm6easy_series(), table(nets[1], 24, 1), table(nets[2], 48, 2), table(nets[3], 96, 3)]
+    tasks = [dict(network=nw, series=s, delta_t=dt, costs_clipping=(1, 100)) for nw, s, dt in zip(nets, series, (0.25, 0.5, 0.25, 0.25))]
+    env_task = np.random.default_rng(5).integers(0, 4, E)
+    out = {}
+    for streams in (True, False):
+        env = MixedBatchedANMEnv(tasks, env_task, device=dev, seed=7, tol=1e-6, max_iter=100, autoreset=True, streams=streams)
+        env.check_actions = False
+        env.reset(seed=7)
+        g = torch.Generator(device=dev).manual_seed(1)
+        lo, hi = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
+        pool = [lo + (hi - lo) * torch.rand((E, env.A), generator=g, dtype=torch.float64, device=dev) for _ in range(4)]
+        wall, evs = _timed_env_steps(env, pool, n, dev)
+        out["streams" if streams else "one_stream"] = {"us_per_step": wall * 1e6, "us_per_step_events": evs * 1e6, "env_steps_per_s": E / wall}
+    out["families"] = dict(zip(("anm6", "3bus_loop", "mesh20", "case30"), env.impls))
+    out["envs_per_network"] = [int((env_task == k).sum()) for k in range(4)]
+    return {"mixed_topologies_16384": out}
+
+
 def mpc_side_figure(dev):
     """the batched MPC DC-OPF policy (gym_anm/agents/mpc.py), all environments' programs in one launch of
     k_mpc.  Algorithmic bytes per program: forecasts in, first-stage set-points + value + iteration count out."""
@@ -573,7 +612,7 @@ def main(argv=None, make_env=None, backend="nccl", device_type="cuda", script=No
         other.update(reduce_side_figure(comm, fig))
         if rank == 0 and world == 1:
             for f in (lambda: mesh_side_figure(dev), lambda: throughput_side_figure(dev, args),
-                      lambda: baseline_configs_side_figure(dev, args), lambda: mpc_side_figure(dev)):
+                      lambda: baseline_configs_side_figure(dev, args), lambda: mixed_side_figure(dev), lambda: mpc_side_figure(dev)):
                 try:
                     other.update(f())
                 except Exception as ex:

@@ -50,20 +50,31 @@ int fail_hip(hipError_t e, const char* where) {
 #define ANM_ROWS_WAVES 1  // min. waves per SIMD the step kernel is compiled for (register budget 512 / waves)
 #endif
 
-template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C0, TransitionIO io, SolverOpts so, int64_t n, ClassSel cs) {
+// VIEW: the launch serves the environments a batch view names (anm_model_bind_view); without one the view is a compile-time
+// identity and costs the kernels nothing
+template <class JT, bool VIEW = false>
+__global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C0, TransitionIO io, SolverOpts so, int64_t n, ClassSel cs, View v) {
   const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
   if (e >= n) return;
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
-  op_transition<Topo, JT>(C, io, so, e);
+  if constexpr (VIEW) op_transition<Topo, JT>(C, io, so, e, v);
+  else op_transition<Topo, JT>(C, io, so, e);
 }
 
-template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs) {
+template <class JT, bool VIEW = false>
+__global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs, View v) {
   const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
   if (e >= n) return;
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
-  op_reset<Topo, JT>(C, io, so, e);
+  if constexpr (VIEW) op_reset<Topo, JT>(C, io, so, e, v);
+  else op_reset<Topo, JT>(C, io, so, e);
+}
+
+// the step of the environments a batch view names (thread-per-environment family): see op_step_view
+template <class JT>
+__global__ __launch_bounds__(BLOCK) void k_step_view(cptr_t C, EnvIO io, SolverOpts so, int64_t n, View v) {
+  __shared__ double lds[Topo::TREE != 0 ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
+  op_step_view<Topo, JT>(C, io, so, n, v, lds);
 }
 
 // fast path of the step (series mode, K = 1, "state" observation): see op_step_rows
@@ -115,7 +126,7 @@ struct anm_model {
   int impl = ANM_IMPL_THREAD;   // which kernel family serves this model
   int impl_unbound = -1;        // the family to go back to when a per-environment class binding is lifted (-1: none pending)
   radial::View view{};          // anm_model_bind_view: the launches serve a sub-batch of a larger, padded batch
-  int impl_unviewed = -1;       // the family to go back to when the view is lifted
+  bool has_view = false;
   bool tpe_ok = false;          // the network has the topology this library was compiled for
   bool radial_ok = false;       // the network is a tree that fits one wavefront
   radial::Plan plan;            // per-lane tables of the lane-group kernel
@@ -223,7 +234,9 @@ size_t radial_obs_lds_bytes(const anm_model* m) {
   return size_t(64 / m->plan.d.G) * size_t(m->plan.d.FS + radial::KMAX) * sizeof(double);
 }
 
-int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io, SolverOpts so) {
+int launch_radial(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io_in, SolverOpts so) {
+  radial::IO io = io_in;
+  io.v = m->view;
   const int per_wave = 64 / m->plan.d.G;
   const unsigned grid = unsigned((n + per_wave - 1) / per_wave);
   // the model is the compiled tree: the specialised Newton loop; else (generic mode) the table-driven one
@@ -513,7 +526,7 @@ int anm_model_set_env(anm_model* m, const anm_env_config* cfg) {
 
 int anm_model_set_classes(anm_model* m, int32_t n_classes, const anm_network_desc* const* descs) {
   if (!m) return fail("anm_model_set_classes: null model");
-  if (n_classes > 1 && (m->view.index || m->view.w_state > 0))
+  if (n_classes > 1 && m->has_view)
     return fail("anm_model_set_classes: not while a batch view is bound (anm_model_bind_view)");
   if (n_classes < 1 || n_classes > 65536) return fail("anm_model_set_classes: n_classes must be in [1, 65536]");
   if (n_classes > 1 && !descs) return fail("anm_model_set_classes: null descriptions");
@@ -612,7 +625,7 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
     restore_impl();
     return 0;
   }
-  if (m->view.index || m->view.w_state > 0)   // (the same rule as anm_model_bind_view, from the other side: k_mesh looks a block's
+  if (m->has_view)   // (the same rule as anm_model_bind_view, from the other side: k_mesh looks a block's
     // class up by launch slot and an environment's by its index in the batch)
     return fail("anm_model_bind_env_classes: not while a batch view is bound (anm_model_bind_view)");
   if (num_envs <= 0) return fail("anm_model_bind_env_classes: num_envs must be positive");
@@ -649,7 +662,7 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
 
 int anm_model_bind_state_same(anm_model* m, uint8_t* state_same) {
   if (!m) return fail("anm_model_bind_state_same: null model");
-  if (state_same && (m->view.index || m->view.w_state > 0)) return fail("anm_model_bind_state_same: not while a batch view is bound");
+  if (state_same && m->has_view) return fail("anm_model_bind_state_same: not while a batch view is bound");
   m->d_state_same = state_same;
   return 0;
 }
@@ -670,31 +683,28 @@ int anm_model_bind_view(anm_model* m, const anm_batch_view* v) {
   if (!m) return fail("anm_model_bind_view: null model");
   if (!v) {
     m->view = radial::View{};
-    if (m->impl_unviewed >= 0) m->impl = m->impl_unviewed;
-    m->impl_unviewed = -1;
+    m->has_view = false;
     return 0;
   }
-  if (!m->mesh_ok) return fail("anm_model_bind_view: a view is served by the general lane-group kernel, which cannot take this network");
   if (m->d_env_class) return fail("anm_model_bind_view: not together with parameter classes (anm_model_bind_env_classes)");
   if (m->n_obs > 0) return fail("anm_model_bind_view: not together with a list-form observation (anm_model_set_obs): clear it first");
   if (m->d_state_same) return fail("anm_model_bind_view: not together with anm_model_bind_state_same (the flags are indexed by launch slot)");
-  const mesh::Dims& d = m->mplan.d;
+  anm_dims d;
+  anm_model_dims(m, &d);
   const int K = m->K;
+  const int n_set = d.n_gen + d.n_des;
   struct { int given, own; const char* what; } w[] = {
-      {v->w_load, d.NLOAD, "w_load"}, {v->w_gen, d.NGEN, "w_gen"}, {v->w_set, d.NSET, "w_set"}, {v->w_des, d.NDES, "w_des"},
-      {v->w_action, 2 * (d.NGEN + d.NDES), "w_action"}, {v->w_state, d.SDIM + K, "w_state"}, {v->w_exo, d.NLOAD + d.NGEN, "w_exo"},
-      {v->w_aux, K, "w_aux"}, {v->w_full, d.FS, "w_full"}};
+      {v->w_load, d.n_load, "w_load"}, {v->w_gen, d.n_gen, "w_gen"}, {v->w_set, n_set, "w_set"}, {v->w_des, d.n_des, "w_des"},
+      {v->w_action, 2 * n_set, "w_action"}, {v->w_state, d.state_base_dim + K, "w_state"}, {v->w_exo, d.n_load + d.n_gen, "w_exo"},
+      {v->w_aux, K, "w_aux"}, {v->w_full, d.full_dim, "w_full"}};
   for (auto& x : w)
     if (x.given != 0 && x.given < x.own) {
       g_err = std::string("anm_model_bind_view: ") + x.what + " is narrower than this network's own rows";
       return -1;
     }
   m->view = radial::View{v->env_index, v->w_load, v->w_gen, v->w_set, v->w_des, v->w_action, v->w_state, v->w_exo, v->w_aux, v->w_full};
-  if (m->impl != ANM_IMPL_MESH) {
-    m->impl_unviewed = m->impl;
-    m->impl = ANM_IMPL_MESH;
-  }
-  return 0;
+  m->has_view = true;
+  return 0;   // (every kernel family serves a view: the model stays in the family it is in)
 }
 
 int anm_step_ws_record_doubles(void) { return Rec<Topo>::SIZE; }
@@ -703,7 +713,7 @@ static unsigned magic_div(int d) { return d > 0 ? unsigned((0x100000000ull + uin
 
 int anm_model_obs_fusable(const anm_model* m) {
   if (!m) return 0;
-  if (m->view.index || m->view.w_state > 0) return 0;
+  if (m->has_view) return 0;
   if (m->impl == ANM_IMPL_THREAD) return (m->tpe_ok && GenLds<Topo>::FULL_OK) ? 1 : 0;
   if (m->impl == ANM_IMPL_RADIAL) return (m->radial_ok && radial_obs_lds_bytes(m) <= 48 * 1024) ? 1 : 0;
   if (m->impl == ANM_IMPL_MESH) return (m->mesh_ok && m->mplan.d.l_bw - m->mplan.d.l_blk >= m->mplan.d.FS + radial::KMAX) ? 1 : 0;
@@ -820,8 +830,6 @@ int anm_model_set_impl(anm_model* m, int32_t impl) {
   if (impl == ANM_IMPL_THREAD && m->class_per_env)
     return fail("anm_model_set_impl: the bound parameter classes change inside blocks of 64 environments: only a "
                 "lane-group kernel can serve them");
-  if (impl != ANM_IMPL_MESH && (m->view.index || m->view.w_state > 0))
-    return fail("anm_model_set_impl: a batch view is bound (anm_model_bind_view): only the general lane-group kernel serves it");
   if (impl != m->impl && m->n_obs > 0)
     return fail("anm_model_set_impl: a list-form observation is set (anm_model_set_obs), whose tables belong to the current "
                 "kernel family; clear it before switching and set it again afterwards");
@@ -863,10 +871,16 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
     return m->impl == ANM_IMPL_MESH ? launch_mesh(m, prec, n, s, rio, so) : launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
-  if (prec == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(k_transition<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
+  const bool viewed = m->has_view;
+  if (viewed) {
+    if (prec == ANM_SOLVE_F32)
+      hipLaunchKernelGGL((k_transition<float, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
+    else
+      hipLaunchKernelGGL((k_transition<double, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
+  } else if (prec == ANM_SOLVE_F32)
+    hipLaunchKernelGGL((k_transition<float, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
   else
-    hipLaunchKernelGGL(k_transition<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
+    hipLaunchKernelGGL((k_transition<double, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_transition");
   return 0;
@@ -911,10 +925,16 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
     return m->impl == ANM_IMPL_MESH ? launch_mesh(m, prec, n, s, rio, so) : launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
-  if (prec == ANM_SOLVE_F32)
-    hipLaunchKernelGGL(k_reset<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
+  const bool viewed = m->has_view;
+  if (viewed) {
+    if (prec == ANM_SOLVE_F32)
+      hipLaunchKernelGGL((k_reset<float, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
+    else
+      hipLaunchKernelGGL((k_reset<double, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
+  } else if (prec == ANM_SOLVE_F32)
+    hipLaunchKernelGGL((k_reset<float, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
   else
-    hipLaunchKernelGGL(k_reset<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false));
+    hipLaunchKernelGGL((k_reset<double, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_reset");
   return 0;
@@ -1017,6 +1037,21 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
     return m->impl == ANM_IMPL_MESH ? launch_mesh(m, prec, n, s, rio, so) : launch_radial(m, prec, n, s, rio, so);
   }
   cptr_t C = (cptr_t)m->d_const;
+  if (m->has_view) {
+    // a batch view: per-lane rows (the coalesced-row kernels need 64 consecutive environments)
+    if (io.K > 1) return fail("anm_step_f64: a batch view in the thread-per-environment family takes K <= 1 auxiliary variables (use the general lane-group family)");
+    if (io.n_obs > 0) return fail("anm_step_f64: a batch view and a list-form observation do not go together");
+    io.ws = nullptr;
+    io.state_same = nullptr;
+    io.aux_stride = m->view.w_aux;
+    if (prec == ANM_SOLVE_F32)
+      hipLaunchKernelGGL(k_step_view<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
+    else
+      hipLaunchKernelGGL(k_step_view<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
+    hipError_t ev = hipGetLastError();
+    if (ev != hipSuccess) return fail_hip(ev, "launch k_step_view");
+    return 0;
+  }
   if (io.aux_index && io.exo == nullptr && io.K == 1 && !io.full && io.n_obs == 0) {
     // fast path: series mode, "state" observation, nothing but the batch tensors
     if (prec == ANM_SOLVE_F32)

@@ -31,6 +31,14 @@ __device__ __forceinline__ cptr_t class_constants(cptr_t C, const ClassSel& cs, 
 }
 #endif
 
+// A launch may serve a SUB-batch of a larger batch (anm_model_bind_view): slot s of the launch is environment index[s] of
+// the batch arrays, whose rows are padded to common widths -- how one batch holds environments over networks of DIFFERENT
+// topologies, one launch per topology, each in its own kernel family
+struct View {
+  const int32_t* index;   // null: slot = environment
+  int w_load, w_gen, w_set, w_des, w_action, w_state, w_exo, w_aux, w_full;   // row strides (0: the network's own widths)
+};
+
 struct SolverOpts {
   double tol;
   int max_iter;
@@ -91,18 +99,23 @@ struct TransitionIO {
   const double* nr_start;  // [E, 2 (NB - 1)] or null (anm_model_bind_nr_start): initial guess (angles, magnitudes)
 };
 
+// (slot: position in the launch; with a view -- anm_model_bind_view -- the environment is index[slot] and the rows of the
+// batch arrays have the view's strides)
 template <class T, class JT>
-ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64_t e) {
+ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64_t slot, const View& v = View{}) {
+  const int64_t e = v.index ? int64_t(v.index[slot]) : slot;
+  const int WL = v.w_load > 0 ? v.w_load : T::NLOAD, WG = v.w_gen > 0 ? v.w_gen : T::NGEN, WS = v.w_set > 0 ? v.w_set : T::NSET;
+  const int WD = v.w_des > 0 ? v.w_des : T::NDES, WF = v.w_full > 0 ? v.w_full : FullState<T>::SIZE;
   EnvWork<T> w;
   double P_load[T::NLOAD > 0 ? T::NLOAD : 1], P_pot[T::NGEN > 0 ? T::NGEN : 1];
   double P_set[T::NSET > 0 ? T::NSET : 1], Q_set[T::NSET > 0 ? T::NSET : 1];
-  static_for<0, T::NLOAD>([&](auto I) { P_load[I] = io.p_load[e * T::NLOAD + I]; });
-  static_for<0, T::NGEN>([&](auto I) { P_pot[I] = io.p_pot[e * T::NGEN + I]; });
+  static_for<0, T::NLOAD>([&](auto I) { P_load[I] = io.p_load[e * WL + I]; });
+  static_for<0, T::NGEN>([&](auto I) { P_pot[I] = io.p_pot[e * WG + I]; });
   static_for<0, T::NSET>([&](auto I) {
-    P_set[I] = io.p_set[e * T::NSET + I];
-    Q_set[I] = io.q_set[e * T::NSET + I];
+    P_set[I] = io.p_set[e * WS + I];
+    Q_set[I] = io.q_set[e * WS + I];
   });
-  static_for<0, T::NDES>([&](auto I) { w.soc[I] = io.soc[e * T::NDES + I]; });
+  static_for<0, T::NDES>([&](auto I) { w.soc[I] = io.soc[e * WD + I]; });
   if (io.nr_start) {
     // the reference's solver from a given initial guess (v_guess of _newton_raphson_sparse, solve_load_flow.py:176)
     PFState<T> st;
@@ -120,14 +133,14 @@ ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64
   } else {
     transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
   }
-  static_for<0, T::NDES>([&](auto I) { io.soc[e * T::NDES + I] = w.soc[I]; });
+  static_for<0, T::NDES>([&](auto I) { io.soc[e * WD + I] = w.soc[I]; });
   io.reward[e] = w.reward;
   io.e_loss[e] = w.e_loss;
   io.penalty[e] = w.penalty;
   io.converged[e] = w.converged ? 1 : 0;
   if (io.nr_iters) io.nr_iters[e] = w.n_iter;
   if (io.nr_diff) io.nr_diff[e] = w.diff;
-  if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+  if (io.full) write_full_state<T>(w, io.full + e * WF);
 }
 
 struct EnvIO {
@@ -176,6 +189,7 @@ struct EnvIO {
   int mid_cap;              // ... by the first straggler launch (0: it runs every record to the end, one level)
   int32_t* ws_list2;        // records the first straggler launch did not finish (count: counter 2 of the header)
   double* nr_diff;          // [E] or null (anm_model_bind_nr_diff; reset only): ||F||inf of the final iterate
+  int aux_stride;           // row stride of aux_next (0: K; a batch view pads the rows)
 };
 
 // Split an init_state row (anm_env.py / simulator.py:248-268) into transition inputs.
@@ -270,34 +284,36 @@ ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32
 }
 
 template <class T, class JT, class S0>
-ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const S0& s0) {
-  const int S = T::SDIM + io.K;
+ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const S0& s0, const View& v = View{}) {
+  const int S = v.w_state > 0 ? v.w_state : T::SDIM + io.K;        // row stride of state / obs
+  const int WD = v.w_des > 0 ? v.w_des : T::NDES, WF = v.w_full > 0 ? v.w_full : FullState<T>::SIZE;
   EnvWork<T> w;
   double P_load[T::NLOAD > 0 ? T::NLOAD : 1], P_pot[T::NGEN > 0 ? T::NGEN : 1];
   double P_set[T::NSET > 0 ? T::NSET : 1], Q_set[T::NSET > 0 ? T::NSET : 1];
   inputs_from_init_state<T>(C, s0, w, P_load, P_pot, P_set, Q_set);
   transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
   RowPtrs rows{io.state + e * S, io.obs + e * S};
-  finish_reset<T, Layout<T>::KMAX, S0>(C, w, s0, io.K, io.soc + e * T::NDES, rows);
+  finish_reset<T, Layout<T>::KMAX, S0>(C, w, s0, io.K, io.soc + e * WD, rows);
   io.converged[e] = w.converged ? 1 : 0;
   io.terminated[e] = 0;
   if (io.timestep) io.timestep[e] = 0;
   if (io.nr_iters) io.nr_iters[e] = w.n_iter;
   if (io.nr_diff) io.nr_diff[e] = w.diff;
   if (io.aux_index && io.K == 1) io.aux_index[e] = int32_t(s0[T::SDIM]);
-  if (io.full) write_full_state<T>(w, io.full + e * FullState<T>::SIZE);
+  if (io.full) write_full_state<T>(w, io.full + e * WF);
 }
 
 template <class T, class JT>
-ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e) {
+ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t slot, const View& v = View{}) {
+  const int64_t e = v.index ? int64_t(v.index[slot]) : slot;
   if (io.mask && !io.mask[e]) return;
   if (io.init_state) {  // the row given by the caller
-    reset_from<T, JT>(C, io, so, e, io.init_state + e * (T::SDIM + io.K));
+    reset_from<T, JT>(C, io, so, e, io.init_state + e * (v.w_state > 0 ? v.w_state : T::SDIM + io.K), v);
   } else {              // device sampler (series mode, K = 1): same draws as the autoreset path, kept in registers
     double s0_drawn[T::SDIM + 1];
     sample_series_init_state<T>(C, io, e, uint32_t(io.reset_count[e]), s0_drawn);
     io.reset_count[e] += 1;
-    reset_from<T, JT>(C, io, so, e, s0_drawn);
+    reset_from<T, JT>(C, io, so, e, s0_drawn, v);
   }
 }
 
@@ -467,7 +483,7 @@ ANM_HD void step_end(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const 
       if (io.K > 0) {
         static_for<0, KCAP>([&](auto Kc) {  // unconditional stores, see finish_reset
           constexpr int k = Kc;
-          const double v = io.aux_next[e * io.K + (k < io.K ? k : 0)];
+          const double v = io.aux_next[e * (io.aux_stride > 0 ? io.aux_stride : io.K) + (k < io.K ? k : 0)];
           out.put_st(T::SDIM + k, v);
           out.put_ob(T::SDIM + k, fmin(fmax(v, C[L::OBS_LO + T::SDIM + k]), C[L::OBS_HI + T::SDIM + k]));
         });
@@ -654,6 +670,73 @@ __device__ __forceinline__ void epilogue_stores(const EnvIO& io, int64_t e0, int
   store_rows(io.state + e0 * S, out.state, out.write_state && !state_dup);
   store_rows(io.obs + e0 * S, out.obs, out.write_obs);
   ANM_PHASE(6);
+}
+
+// I/O layer 1b (GPU): the step of the environments a batch VIEW names (anm_model_bind_view: a sub-batch of a larger batch
+// whose rows are padded to common widths -- environments over different topologies in one batch, each topology stepped by
+// its own kernel family).  Slot s of the launch is environment index[s]; its rows are scattered over the batch, so the
+// loads and stores are per lane (the coalesced row blocks of layers 2 and 3 need 64 consecutive environments); the solve
+// is the same as theirs, the in-wave hand-over of diverging solves to lane groups included.  K <= 1, "state" observation.
+template <class T, class JT>
+__device__ void op_step_view(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n, const View& v, double* lds) {
+  typedef Dims<T> D;
+  constexpr int S1 = T::SDIM + 1;
+  const int lane = threadIdx.x;
+  const int64_t slot = int64_t(blockIdx.x) * 64 + lane;
+  const bool valid = slot < n;
+  const int64_t sc = valid ? slot : n - 1;
+  const int64_t e = v.index ? int64_t(v.index[sc]) : sc;
+  const int WA = v.w_action > 0 ? v.w_action : D::ADIM, WS = v.w_state > 0 ? v.w_state : T::SDIM + io.K;
+  const int WD = v.w_des > 0 ? v.w_des : T::NDES, WX = v.w_exo > 0 ? v.w_exo : D::NEXO, WF = v.w_full > 0 ? v.w_full : FullState<T>::SIZE;
+  const bool series = io.exo == nullptr;
+  StepIn<T> in;
+  StepOut<T, 1> out;
+  StepCtx<T> ctx;
+  PFState<T> st;
+  EnvWork<T> w;
+  in.was_term = io.terminated[e] != 0;
+  static_for<0, D::ADIM>([&](auto I) { in.action[I] = io.action[e * WA + I]; });
+  if (!series) static_for<0, D::NEXO>([&](auto I) { in.exo[I] = io.exo[e * WX + I]; });
+  static_for<0, T::NDES>([&](auto I) { in.soc[I] = io.soc[e * WD + I]; });
+  in.aux_prev = series ? io.state[e * WS + T::SDIM] : 0.0;
+  in.reset_count = (io.autoreset && io.reset_count) ? io.reset_count[e] : 0;
+  const int32_t ts_prev = io.timestep ? io.timestep[e] : 0;
+
+  step_begin<T, JT>(C, C, io, so, e, in, ctx, w, st, -1);
+  constexpr bool CAN_GROUP = T::TREE != 0;
+  const int handoff = (CAN_GROUP && so.handoff >= 0 && so.handoff < so.max_iter) ? so.handoff : -1;
+  pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, handoff >= 0 ? handoff : so.max_iter);
+  if constexpr (CAN_GROUP) {
+    if (handoff >= 0 && ANM_WAVE_ANY(st.active && valid))
+      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
+  }
+  step_end<T, 1>(C, io, so, e, ctx, w, st, out);
+  if (!valid) return;
+  // stores (store_step_scalars with the view's strides)
+  if (out.write_soc) static_for<0, T::NDES>([&](auto I) { io.soc[e * WD + I] = out.soc[I]; });
+  if (out.terminated >= 0) io.terminated[e] = uint8_t(out.terminated);
+  io.reward[e] = out.reward;
+  if (out.write_costs) {
+    io.e_loss[e] = out.e_loss;
+    io.penalty[e] = out.penalty;
+  }
+  if (io.nr_iters) io.nr_iters[e] = out.n_iter;
+  if (io.timestep) {
+    if (out.timestep_op == 1) io.timestep[e] = 0;
+    else if (out.timestep_op == 2) io.timestep[e] = ts_prev + 1;
+  }
+  if (out.inc_reset) io.reset_count[e] += 1;
+  const int SK = T::SDIM + io.K;   // (K <= 1)
+  double* state = io.state + e * WS;
+  double* obs = io.obs + e * WS;
+  static_for<0, S1>([&](auto Kc) {
+    constexpr int k = Kc;
+    if (k < SK) {
+      if (out.write_state) state[k] = out.state[k];
+      if (out.write_obs) obs[k] = out.obs[k];
+    }
+  });
+  if (io.full && out.write_state) write_full_state<T>(w, io.full + e * WF);
 }
 
 // I/O layer 2 (GPU, series mode, K = 1): one wavefront = 64 consecutive environments whose action /

@@ -222,13 +222,7 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
 
-// A launch may serve a SUB-batch of a larger batch (anm_model_bind_view; the general lane-group family): slot s of the
-// launch is environment index[s] of the batch arrays, whose rows are padded to common widths -- how one batch holds
-// environments over networks of DIFFERENT topologies, one launch per topology
-struct View {
-  const int32_t* index;   // null: slot = environment
-  int w_load, w_gen, w_set, w_des, w_action, w_state, w_exo, w_aux, w_full;   // row strides (0: the network's own widths)
-};
+using View = anm::View;   // (anm_env_ops.hpp)
 
 struct IO {
   int mode;  // 0 transition, 1 reset, 2 step
@@ -288,9 +282,19 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   const int l = t & (G - 1);
   const int gb = t - l;
   const int per_wave = 64 / G;
-  const int64_t e = int64_t(blockIdx.x) * per_wave + (t / G);
-  const bool env_ok = e < n_env;
-  const int64_t ee = env_ok ? e : 0;  // inactive groups compute on env 0 and never store
+  // slot of this launch -> environment: itself, or (a view is bound: the launch serves a SUB-batch of a larger batch whose
+  // rows are padded to common widths, anm_model_bind_view) the index the view names; the row strides of the batch arrays are
+  // the network's own widths unless the view gives others
+  const int64_t slot_e = int64_t(blockIdx.x) * per_wave + (t / G);
+  const bool env_ok = slot_e < n_env;
+  const int64_t ee = io.v.index ? int64_t(io.v.index[env_ok ? slot_e : 0]) : (env_ok ? slot_e : 0);  // inactive groups compute on another env and never store
+  const int64_t e = ee;
+  const int W_LOAD = io.v.w_load > 0 ? io.v.w_load : d.NLOAD, W_GEN = io.v.w_gen > 0 ? io.v.w_gen : d.NGEN;
+  const int W_SET = io.v.w_set > 0 ? io.v.w_set : d.NSET, W_DES = io.v.w_des > 0 ? io.v.w_des : d.NDES;
+  const int W_ACT = io.v.w_action > 0 ? io.v.w_action : 2 * (d.NGEN + d.NDES);
+  const int W_ST = io.v.w_state > 0 ? io.v.w_state : d.SDIM + io.e.K;
+  const int W_EXO = io.v.w_exo > 0 ? io.v.w_exo : d.NLOAD + d.NGEN, W_AUX = io.v.w_aux > 0 ? io.v.w_aux : io.e.K;
+  const int W_FS = io.v.w_full > 0 ? io.v.w_full : d.FS;
   auto RI = [&](int f) { return ri[f * G + l]; };
   auto RD = [&](int f) { return rd[d.off_lane + f * G + l]; };
   cptr_t C = (cptr_t)rd;
@@ -319,15 +323,15 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   double in_p = 0.0, in_q = 0.0, in_pot = 0.0, soc = 0.0, s0_q = 0.0;
   double soc_req = 0.0;     // reset: requested SoC (MWh slot)
   if (mode == 0) {
-    if (typ == DEV_LOAD) in_p = io.t.p_load[ee * d.NLOAD + slot];
+    if (typ == DEV_LOAD) in_p = io.t.p_load[ee * W_LOAD + slot];
     else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) {
-      in_pot = io.t.p_pot[ee * d.NGEN + slot];
-      in_p = io.t.p_set[ee * d.NSET + sset];
-      in_q = io.t.q_set[ee * d.NSET + sset];
+      in_pot = io.t.p_pot[ee * W_GEN + slot];
+      in_p = io.t.p_set[ee * W_SET + sset];
+      in_q = io.t.q_set[ee * W_SET + sset];
     } else if (typ == DEV_STORAGE) {
-      in_p = io.t.p_set[ee * d.NSET + sset];
-      in_q = io.t.q_set[ee * d.NSET + sset];
-      soc = io.t.soc[ee * d.NDES + slot];
+      in_p = io.t.p_set[ee * W_SET + sset];
+      in_q = io.t.q_set[ee * W_SET + sset];
+      soc = io.t.soc[ee * W_DES + slot];
     }
   } else {
     const bool was_term = (mode == 2) && io.e.terminated[ee] != 0;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     double s0_p = 0.0, s0_pm = 0.0;
     sampled = resetting && !(mode == 1 && io.e.init_state);
     if (mode == 1 && io.e.init_state) {
-      s0 = io.e.init_state + ee * S;
+      s0 = io.e.init_state + ee * W_ST;
       if (typ != DEV_NONE) { s0_p = s0[l]; s0_q = s0[d.ND + l]; }
       if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) s0_pm = s0[2 * d.ND + d.NDES + slot];
       if (typ == DEV_STORAGE) soc_req = s0[2 * d.ND + slot];
@@ -374,21 +378,21 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         soc = (s0_p <= 0.0) ? sd[SD_SOC_MIN] : sd[SD_SOC_MAX];  // simulator.py:273-278
       }
     } else if (!skip) {
-      const double* a = io.e.action + ee * (2 * (d.NGEN + d.NDES));
+      const double* a = io.e.action + ee * W_ACT;
       if (series) {
-        const double av = io.e.state[ee * S + d.SDIM];
+        const double av = io.e.state[ee * W_ST + d.SDIM];
         aux = int(fmod(av + 1.0, double(io.e.period)));
         if (typ == DEV_LOAD) in_p = io.e.series[slot * io.e.period + aux];
         else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.series[(d.NLOAD + slot) * io.e.period + aux];
       } else {
-        if (typ == DEV_LOAD) in_p = io.e.exo[ee * (d.NLOAD + d.NGEN) + slot];
-        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.exo[ee * (d.NLOAD + d.NGEN) + d.NLOAD + slot];
+        if (typ == DEV_LOAD) in_p = io.e.exo[ee * W_EXO + slot];
+        else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) in_pot = io.e.exo[ee * W_EXO + d.NLOAD + slot];
       }
       if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) { in_p = a[slot]; in_q = a[d.NGEN + slot]; }
       else if (typ == DEV_STORAGE) {
         in_p = a[2 * d.NGEN + slot];
         in_q = a[2 * d.NGEN + d.NDES + slot];
-        soc = io.e.soc[ee * d.NDES + slot];
+        soc = io.e.soc[ee * W_DES + slot];
       }
     }
   }
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   double* full = (mode == 0) ? io.t.full : io.e.full;
   auto write_full = [&]() {
     if (!full) return;
-    double* f = full + e * d.FS;
+    double* f = full + e * W_FS;
     if (isbus) {
       const int b = l + 1;
       f[d.f_bus_p + b] = bus_p; f[d.f_bus_q + b] = bus_q;
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   bool dump = false;
   do {
   if (mode == 0) {
-    if (typ == DEV_STORAGE) io.t.soc[e * d.NDES + slot] = soc;
+    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
     if (l == 0) {
       io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
       io.t.converged[e] = converged ? 1 : 0;
@@ -723,11 +727,11 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     break;
   }
 
-  double* state = io.e.state + e * S;
+  double* state = io.e.state + e * W_ST;
   // the observation: clip(state, Box) next to the state row, or (a list is set: anm_env.py:497-521, 562-592) n_obs entries
   // gathered from this environment's electrical state
   const bool list = mode == 2 && io.e.n_obs > 0;
-  const int OW = list ? io.e.n_obs : S;
+  const int OW = list ? io.e.n_obs : W_ST;
   double* obs = io.e.obs + e * OW;
   cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
   auto put = [&](int k, double v) {
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) row[d.f_gen_pmax + slot] = p_pot;
     // the aux variables sit behind the electrical state
     if (resetting || io.e.exo == nullptr) { if (l == 0) row[d.FS] = double(aux); }
-    else for (int k = l; k < K; k += G) row[d.FS + k] = io.e.aux_next[e * K + k];
+    else for (int k = l; k < K; k += G) row[d.FS + k] = io.e.aux_next[e * W_AUX + k];
     ANM_GROUP_SYNC();
     for (int k = l; k < OW; k += G) {
       const double v = row[io.e.obs_index[k]] * io.e.obs_scale[k];
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   if (resetting) {
     if (typ == DEV_STORAGE) {
       soc = soc_req / base;  // simulator.py:284-288
-      io.e.soc[e * d.NDES + slot] = soc;
+      io.e.soc[e * W_DES + slot] = soc;
     }
     if (mode == 2 && !converged) {
       // a redraw whose first power flow does not converge looks like the absorbing terminal state
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       if (sampled) {
         if (l == 0) { put(d.SDIM, double(aux)); io.e.reset_count[e] += 1; }
       } else {
-        const double* s0 = io.e.init_state + e * S;
+        const double* s0 = io.e.init_state + e * W_ST;
         for (int k = l; k < K; k += G) put(d.SDIM + k, s0[d.SDIM + k]);
       }
       if (l == 0) { io.e.converged[e] = converged ? 1 : 0; io.e.terminated[e] = 0; if (io.e.timestep) io.e.timestep[e] = 0; }
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     break;
   }
   // regular step
-  if (typ == DEV_STORAGE) io.e.soc[e * d.NDES + slot] = soc;
+  if (typ == DEV_STORAGE) io.e.soc[e * W_DES + slot] = soc;
   const bool term = !converged;
   if (!term) {
     if (typ != DEV_NONE) { put(l, dev_p * base); put(d.ND + l, dev_q * base); }
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (io.e.exo == nullptr) {
       if (l == 0) put(d.SDIM, double(aux));
     } else {
-      for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * K + k]);
+      for (int k = l; k < K; k += G) put(d.SDIM + k, io.e.aux_next[e * W_AUX + k]);
     }
   } else {
     for (int k = l; k < S; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }

@@ -1,0 +1,212 @@
+"""Environments over DIFFERENT networks in one batch, behind one Gymnasium-style surface.
+
+The reference builds one ``ANMEnv`` per network (``gym_anm/envs/anm_env.py:79-156``,
+``examples/custom_anm6.py:20``); a learner that trains over a family of grids holds a list of them.
+Here the environments of all those networks live in ONE batch of padded rows -- ``obs [E, W]``,
+``action [E, A]`` with ``W`` / ``A`` the widest network's widths -- and a step is one launch per
+TOPOLOGY, each told through a batch view (``anm_model_bind_view``) which rows are its own and each
+in the kernel family that suits its network (ANM6 on its thread-per-environment kernels, a 30-bus
+feeder on the tree kernel, a meshed network on the general lane-group kernel), the launches on
+separate HIP streams (they touch disjoint rows).  Nothing is gathered, copied or scattered around
+them.
+
+Scope: series-mode tasks (the exogenous variables are periodic tables indexed by one auxiliary
+time index, like ``ANM6Easy``: ``anm6_easy.py:54-132``), the ``"state"`` observation, device-side
+initial states and next-step autoreset (``anm_env.py:266-311`` with the counter-based sampler of
+``csrc/anm_device.hpp``).  Inside its row every environment uses the layout of its OWN network from
+column 0 (``dev_p, dev_q, des_soc, gen_p_max, aux``; the action ``[P_gen.., Q_gen.., P_des..,
+Q_des..]``); the padding of a row is never touched.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import errors as E
+from ..simulator import _stream_ptr
+from ..spaces import Box
+from .anm_env import BatchedANMEnv
+
+
+class _Task(BatchedANMEnv):
+    """One network of the mix as a one-environment ``BatchedANMEnv``: spec validation, the model with its task constants
+    (``anm_model_set_env``: observation Box, clipping, series), the spaces.  It is never stepped itself."""
+
+    def __init__(self, spec, device, seed, tol, max_iter, precision, impl):
+        series = np.ascontiguousarray(spec["series"], dtype=np.float64)
+        period = series.shape[1]
+        super().__init__(spec["network"], "state", 1, spec.get("delta_t", 0.25), spec.get("gamma", 0.995), spec.get("lamb", 100),
+                         aux_bounds=spec.get("aux_bounds", np.array([[0, period - 1]])), costs_clipping=spec.get("costs_clipping", (None, None)),
+                         seed=seed, num_envs=1, device=device, tol=tol, max_iter=max_iter, precision=precision, series=series, impl=impl,
+                         straggler_after=None)  # fmt: skip
+
+    def init_state(self):  # (host sampler of the one-environment object: unused)
+        raise NotImplementedError
+
+
+class MixedBatchedANMEnv:
+    """``tasks``: one dict per distinct network -- ``network`` (the reference's network dict), ``series``
+    (``[n_load + n_gen, period]`` MW: loads by device id, then the generators' potentials), optionally ``delta_t``,
+    ``gamma``, ``lamb``, ``aux_bounds``, ``costs_clipping``, ``impl``.  ``env_task[e]``: the task of environment ``e``,
+    in any order.
+
+    ``reset(seed=...)`` / ``step(action)`` follow ``gymnasium.vector`` semantics with next-step autoreset, like
+    ``BatchedANMEnv``.  ``observation_space`` / ``action_space`` are per-environment padded Boxes (``[E, W]`` bounds; the
+    padding columns are ``[0, 0]``); ``single_observation_spaces[k]`` / ``single_action_spaces[k]`` are those of task k."""
+
+    def __init__(self, tasks, env_task, device="cuda", seed=None, tol=1e-5, max_iter=100, precision="f64", autoreset=False,
+                 env_offset=0, streams=True):
+        env_task = np.asarray(env_task, dtype=np.int64)
+        if env_task.ndim != 1 or env_task.size == 0 or env_task.min() < 0 or env_task.max() >= len(tasks):
+            raise ValueError("env_task must be a 1-D array of indices into `tasks`")
+        self.num_envs = int(env_task.size)
+        self.env_task = env_task
+        self.autoreset = bool(autoreset)
+        self.env_offset = int(env_offset)
+        self.np_random = np.random.default_rng(seed)
+        self.rng_seed = int(self.np_random.integers(2**62)) if seed is None else int(seed)
+        self.tasks = [_Task(t, device, seed, tol, max_iter, precision, t.get("impl")) for t in tasks]
+        self.device = self.tasks[0].device
+        if self.device.type != "cuda":
+            raise E.HipExtensionError("MixedBatchedANMEnv steps through batch views of the gfx950 kernels: it needs a GPU device")
+        for t in self.tasks:  # the flags of anm_model_bind_state_same are indexed by launch slot: not with a view
+            with t.simulator._device_ctx():
+                t.simulator.backend.check(t.simulator.backend.lib.anm_model_bind_state_same(t.simulator._handle, None),
+                                          "anm_model_bind_state_same")
+        self.impls = [t.simulator.impl for t in self.tasks]
+        E_, dev = self.num_envs, self.device
+        self.state_N = [t.state_N for t in self.tasks]
+        self.action_N = [t.simulator.dims.action_dim for t in self.tasks]
+        self.W = max(self.state_N)
+        self.A = max(1, max(self.action_N))
+        self.W_des = max(1, max(t.simulator.N_des for t in self.tasks))
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.state = torch.zeros((E_, self.W), **f64)
+        self._obs = torch.zeros((E_, self.W), **f64)
+        self.soc = torch.zeros((E_, self.W_des), **f64)
+        self.reward, self.e_loss, self.penalty = (torch.zeros(E_, **f64) for _ in range(3))
+        self._term_u8 = torch.zeros(E_, dtype=torch.uint8, device=dev)
+        self.terminated = self._term_u8.view(torch.bool)
+        self._conv_u8 = torch.zeros(E_, dtype=torch.uint8, device=dev)
+        self.timestep = torch.zeros(E_, dtype=torch.int32, device=dev)
+        self.nr_iters = torch.zeros(E_, dtype=torch.int32, device=dev)
+        self._reset_count = torch.zeros(E_, dtype=torch.int32, device=dev)
+        self._truncated = torch.zeros(E_, dtype=torch.bool, device=dev)
+        # which rows belong to which task, and the views that tell the models
+        self.env_index, self._views = [], []
+        for k, t in enumerate(self.tasks):
+            idx = torch.as_tensor(np.nonzero(env_task == k)[0], dtype=torch.int32, device=dev)
+            self.env_index.append(idx)
+            v = _lib.BatchView(idx.data_ptr(), 0, 0, 0, self.W_des, self.A, self.W, 0, 0, 0)
+            self._views.append(v)
+            sim = t.simulator
+            with sim._device_ctx():
+                sim.backend.check(sim.backend.lib.anm_model_bind_view(sim._handle, C.byref(v)), "anm_model_bind_view")
+        # spaces: per environment, padded
+        lo, hi = np.zeros((E_, self.W)), np.zeros((E_, self.W))
+        alo, ahi = np.zeros((E_, self.A)), np.zeros((E_, self.A))
+        for k, t in enumerate(self.tasks):
+            rows = env_task == k
+            lo[rows, : self.state_N[k]], hi[rows, : self.state_N[k]] = t.observation_space.low, t.observation_space.high
+            alo[rows, : self.action_N[k]], ahi[rows, : self.action_N[k]] = t.action_space.low, t.action_space.high
+        self.observation_space = Box(low=lo, high=hi, dtype=np.float64)
+        self.action_space = Box(low=alo, high=ahi, dtype=np.float64)
+        self.single_observation_spaces = [t.observation_space for t in self.tasks]
+        self.single_action_spaces = [t.action_space for t in self.tasks]
+        self._act_low, self._act_high = torch.as_tensor(alo, **f64), torch.as_tensor(ahi, **f64)
+        self.check_actions = True
+        self._streams = [torch.cuda.Stream(device=dev) for _ in self.tasks] if (streams and len(self.tasks) > 1) else None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _fan_out(self, launch):
+        """``launch(k, stream_ptr)`` for every task with environments: on the tasks' own streams (forked from and joined
+        back into torch's current stream), or one after the other on the current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._streams is None:
+            for k in range(len(self.tasks)):
+                if self.env_index[k].numel():
+                    launch(k, _stream_ptr(self.device))
+            return
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        for k, s in enumerate(self._streams):
+            if not self.env_index[k].numel():
+                continue
+            s.wait_event(fork)
+            launch(k, C.c_void_p(s.cuda_stream))
+            done = torch.cuda.Event()
+            done.record(s)
+            cur.wait_event(done)
+
+    def _launch_reset(self, mask_u8):
+        def go(k, stream):
+            sim = self.tasks[k].simulator
+            with sim._device_ctx():
+                rc = sim.backend.lib.anm_reset_f64(
+                    sim._handle, int(self.env_index[k].numel()), None, mask_u8.data_ptr(), self.rng_seed, self.env_offset,
+                    self._reset_count.data_ptr(), self.soc.data_ptr(), self.state.data_ptr(), self._obs.data_ptr(),
+                    self._conv_u8.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(), self.nr_iters.data_ptr(), None, None,
+                    C.byref(sim.opts), stream)  # fmt: skip
+            sim.backend.check(rc, "anm_reset_f64")
+
+        self._fan_out(go)
+
+    def reset(self, *, seed=None, options=None):
+        """Initial states drawn on the device (``ANM6Easy.init_state`` generalised to any series-mode task, keyed by
+        ``(seed, env_offset + env, reset count)``); environments whose first power flow does not converge are redrawn, up
+        to the reference's 100 attempts (``anm_env.py:266-289``).  ``options={"mask": bool[E]}`` resets a subset."""
+        if seed is not None:
+            self.np_random = np.random.default_rng(seed)
+            self.rng_seed = int(seed)
+            self._reset_count.zero_()
+        mask = (options or {}).get("mask")
+        todo = (torch.ones(self.num_envs, dtype=torch.uint8, device=self.device) if mask is None
+                else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous())
+        touched = todo.bool()
+        for _ in range(100):
+            self._launch_reset(todo)
+            todo = todo * (1 - self._conv_u8)
+            if not bool(todo.any()):
+                break
+        else:
+            raise E.EnvInitializationError("No non-terminal state found out of 100 initial states for %d environments" % int(todo.sum()))
+        self.e_loss[touched] = 0.0
+        self.penalty[touched] = 0.0
+        self.reward[touched] = 0.0
+        return self._obs, {}
+
+    def step(self, action):
+        """``action [E, A]``: row ``e`` holds environment ``e``'s own action vector from column 0, the rest is ignored.
+        Returns ``(obs [E, W], reward [E], terminated [E], truncated [E], info)``: tensors the next call overwrites."""
+        if not (isinstance(action, torch.Tensor) and action.dtype == torch.float64 and action.device == self.device):
+            action = torch.as_tensor(action, dtype=torch.float64, device=self.device)
+        if action.shape != (self.num_envs, self.A):
+            raise AssertionError("Action %r (%s) invalid." % (tuple(action.shape), type(action)))
+        if self.check_actions:  # anm_env.py:356-357
+            ok = bool(((action >= self._act_low) & (action <= self._act_high)).all())
+            assert ok, "Action outside the action space of its environment."
+        action = action.contiguous()
+
+        def go(k, stream):
+            sim = self.tasks[k].simulator
+            with sim._device_ctx():
+                rc = sim.backend.lib.anm_step_f64(
+                    sim._handle, int(self.env_index[k].numel()), action.data_ptr(), None, None, self.soc.data_ptr(), self.state.data_ptr(),
+                    self._term_u8.data_ptr(), self.timestep.data_ptr(), self._obs.data_ptr(), self.reward.data_ptr(), self.e_loss.data_ptr(),
+                    self.penalty.data_ptr(), self.nr_iters.data_ptr(), None, 1 if self.autoreset else 0, self.rng_seed, self.env_offset,
+                    self._reset_count.data_ptr(), None, None, C.byref(sim.opts), stream)  # fmt: skip
+            sim.backend.check(rc, "anm_step_f64")
+
+        self._fan_out(go)
+        return self._obs, self.reward, self.terminated, self._truncated, {}
+
+    def task_rows(self, k):
+        """indices (int64 tensor) of the environments of task ``k``"""
+        return self.env_index[k].long()
+
+    def close(self):
+        pass

@@ -158,8 +158,10 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
  * anm_reset_f64 / anm_step_f64 take num_envs = the number of environments of the view: launch slot s works on
  * environment env_index[s] -- row env_index[s] of every per-environment array, the RNG key env_offset + env_index[s] --
  * with the row strides given here; inside a row the network's own layout starts at column 0 (state: dev_p, dev_q,
- * des_soc, gen_p_max, aux at column state_base_dim).  Served by the general lane-group family (the model switches to it;
- * a network it cannot take is refused); not together with parameter classes or a list-form observation.  NULL unbinds.
+ * des_soc, gen_p_max, aux at column state_base_dim).  Served by the kernel family the model is in (round 5: every family
+ * takes a view -- an ANM6 sub-batch keeps its thread-per-environment kernels, a feeder its tree kernel; the
+ * thread-per-environment step then reads and writes its rows per lane instead of as coalesced blocks, and takes K <= 1);
+ * not together with parameter classes, a list-form observation or anm_model_bind_state_same.  NULL unbinds.
  * One launch per topology; launches of different models on different streams may overlap (they touch disjoint rows). */
 typedef struct anm_batch_view {
   const int32_t* env_index; /* DEVICE int32 [n]: the environments of this view (caller-owned, alive while bound); NULL: 0..n-1 */
