@@ -407,12 +407,13 @@ class MixedBatchedSimulator:
     ``networks``: the distinct network dicts; ``env_network[e]``: which of them environment ``e`` lives on, in any order.
     Every per-environment array has ONE row per environment, padded to the widest network (``P_load [E, max n_load]``,
     ``full [E, max full_dim]`` ...); inside its row an environment uses the layout of its own network, from column 0
-    (``layout(k)`` gives it: ``full_offsets``, ``full_counts``, the device order).  ``transition`` is one launch of the
-    general lane-group kernel per topology, each told through a view (``anm_model_bind_view``) which rows are its own --
-    nothing is gathered, copied or scattered around the launches.
+    (``layout(k)`` gives it: ``full_offsets``, ``full_counts``, the device order).  ``transition`` is one launch per
+    topology, each in the kernel family that suits its network (``impl``: one family for all, e.g. ``"mesh"``; default: each
+    network's own default) and told through a view (``anm_model_bind_view``) which rows are its own -- nothing is gathered,
+    copied or scattered around the launches.
     """
 
-    def __init__(self, networks, env_network, delta_t, lamb, device="cuda", tol=1e-5, max_iter=100, precision="f64"):
+    def __init__(self, networks, env_network, delta_t, lamb, device="cuda", tol=1e-5, max_iter=100, precision="f64", impl=None):
         env_network = np.asarray(env_network, dtype=np.int64)
         if env_network.ndim != 1 or env_network.size == 0 or env_network.min() < 0 or env_network.max() >= len(networks):
             raise ValueError("env_network must be a 1-D array of indices into `networks`")
@@ -423,7 +424,7 @@ class MixedBatchedSimulator:
         for k, net in enumerate(networks):
             idx = np.nonzero(env_network == k)[0]
             sub = BatchedSimulator(net, delta_t, lamb, num_envs=max(1, idx.size), device=device, tol=tol, max_iter=max_iter,
-                                   precision=precision, impl="mesh")
+                                   precision=precision, impl=impl)
             self.subs.append(sub)
             self.env_index.append(torch.as_tensor(idx, dtype=torch.int32, device=sub.device))
         self.device = self.subs[0].device
