@@ -82,6 +82,51 @@ def cpu_baseline(budget_s=12.0, all_cores=True):
     return out
 
 
+def live_pmc(args, kernel="k_step_rows", timeout_s=150):
+    """HBM bytes and VALU instructions per launch of the headline kernel from the PMC counters, collected NOW: this
+    process spawns `rocprofv3 --kernel-trace --pmc <one counter group>` around a short headline-only run of this very
+    script and configuration -- separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE,
+    WRITE_SIZE in KiB; FETCH_SIZE doubled: the gfx950 correction for coalesced reads) -- and averages the kernel's rows.
+    Returns None when rocprofv3 is missing or a pass fails (the committed figure of an earlier run is attached then)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--headline-only", "--no-cpu-baseline", "--no-live-pmc", "--steps", "24", "--warmup", "6",
+            "--num-envs", str(args.num_envs), "--tol", repr(args.tol), "--max-iter", str(args.max_iter), "--precision", args.precision]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("valu", ["SQ_INSTS_VALU", "SQ_WAVES"])):
+            d = os.path.join(td, name)
+            try:
+                subprocess.run([rocprof, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--"] + base,
+                               cwd="/tmp", env=env, capture_output=True, timeout=timeout_s, check=True)
+                f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+            except Exception:
+                return None
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if kernel in r["Kernel_Name"]:
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if not all(c in acc and acc[c] for c in counters):
+                return None
+            for c in counters:
+                out[c] = sum(acc[c]) / len(acc[c])
+            out["launches_" + name] = len(acc[counters[0]])
+    fetch_b, write_b = out["FETCH_SIZE"] * 1024.0, out["WRITE_SIZE"] * 1024.0
+    return {"hbm_bytes_per_launch": 2.0 * fetch_b + write_b, "fetch_bytes_raw": fetch_b, "write_bytes_raw": write_b,
+            "valu_wave_insts_per_launch": out["SQ_INSTS_VALU"], "waves_per_launch": out["SQ_WAVES"],
+            "launches_averaged": out["launches_fetch"]}
+
+
 def transition_figure(dev, net, E, cap, n, load_scale=1.0, note=""):
     """Simulator.transition launches on a fixed batch of random inputs (the SoC is restored before every launch so that
     each launch does the same work), with the HBM roofline of the launch"""
@@ -373,6 +418,8 @@ def parse_args(argv=None):
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64", help="Jacobian/LU precision (F, x always fp64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 counter passes (roofline.traffic then "
+                    "carries the committed figure of an earlier run)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary figures (cap-20, case30) so that a rocprofv3 trace of this command holds "
                          "only launches of the headline configuration")
@@ -628,10 +675,20 @@ def main(argv=None, make_env=None, backend="nccl", device_type="cuda", script=No
         traffic_source = None
         valu = None
         try:
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pt = None
+            if gpu and world == 1 and not args.headline_only and not args.no_live_pmc:
+                pt = live_pmc(args)   # counters of THIS configuration on THIS box, collected by this run
+                if pt is not None:
+                    pt.update(num_envs=E, nr_max_iter=args.max_iter, precision=args.precision)
+                    src = ("live: rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, one group per pass) "
+                           "spawned by this run around a %d-launch headline-only run of the same configuration; FETCH_SIZE %.2f MB x2 "
+                           "(gfx950 correction) + WRITE_SIZE %.2f MB" % (pt["launches_averaged"], pt["fetch_bytes_raw"] / 1e6, pt["write_bytes_raw"] / 1e6))
+            if pt is None:
+                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                src = "profiles/pmc_traffic.json (%s): PMC passes of an earlier run of this configuration, not of this run" % pt.get("source", "?")
             if gpu and pt["num_envs"] == E and pt["nr_max_iter"] == args.max_iter and pt["precision"] == args.precision:
                 traffic = pt["hbm_bytes_per_launch"]
-                traffic_source = "profiles/pmc_traffic.json (%s): PMC passes of an earlier run of this configuration, not of this run" % pt.get("source", "?")
+                traffic_source = src
                 # what really bounds the kernel: fp64 VALU issue.  A wave64 fp64 instruction occupies its
                 # SIMD for 4 cycles, so the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 of them per s.
                 peak_issue = 256 * 4 * 2.4e9 / 4
