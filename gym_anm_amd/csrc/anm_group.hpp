@@ -406,7 +406,10 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       if (bigm == 0ull) {
         if (upd) {
           double sd_, cd_;
-          sincos_kernel<true>(dth, 0, sd_, cd_);
+          // (one-instruction Horner steps with the coefficients in vector registers -- see horner() -- where there is room: the
+          // LDS-hand-over variant, which serves the radial kernel's larger trees, sits at its 168-register budget for three
+          // wavefronts per SIMD and keeps the compiler's own form)
+          sincos_kernel<!LDSX>(dth, 0, sd_, cd_);
           vm = fma(-double(d1), fabs(vm), vm);
           const double c0 = cs, s0 = sn;
           cs = fma(c0, cd_, s0 * sd_);
@@ -415,7 +418,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       } else if (upd) {
         double sd_, cd_;
         if (fabs(dth) < 4.0e15) {
-          sincos_medium<true>(dth, sd_, cd_);
+          sincos_medium<!LDSX>(dth, sd_, cd_);
         } else {
           const SinCos r = sincos_huge(dth);
           sd_ = r.s;

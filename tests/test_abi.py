@@ -46,6 +46,11 @@ def test_no_cpu_fallback():
         BatchedSimulator(networks.anm6_network(), 0.25, 100, num_envs=4)
     with pytest.raises(errors.HipExtensionError):
         ANM6EasyVec(num_envs=4, device="cpu")
+    from gym_anm_amd.envs import MixedBatchedANMEnv
+    from gym_anm_amd.envs.anm6 import anm6easy_series
+
+    with pytest.raises(errors.HipExtensionError):   # the mixed-topology surface: no host path either
+        MixedBatchedANMEnv([dict(network=networks.anm6_network(), series=anm6easy_series())], [0, 0, 0, 0])
 
 
 def test_wrong_topology_is_rejected():
@@ -117,3 +122,46 @@ def test_stale_mpc_library_without_a_compiler_falls_back_to_a_size_class(monkeyp
     monkeypatch.setattr(codegen, "hipcc_path", lambda: None)
     be = _lib.load_mpc_for_topology(topo)
     assert be.size_class is not None and os.path.basename(be.path).startswith("libmpc_class_")
+
+
+def test_register_budgets_of_the_occupancy_critical_kernels():
+    """Occupancy is decided by the register count of a few kernels, and a change elsewhere in the shared templates can move it
+    silently (round 5: a sincos variant pushed config 4's tree kernel from 168 to 176 VGPRs = from three to two wavefronts per
+    SIMD, 77 -> 95 us, with every test green).  Read from the code objects of the built libraries."""
+    import subprocess
+    import tempfile
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+
+    def kernels(lib):
+        with tempfile.TemporaryDirectory() as td:
+            sec, co = os.path.join(td, "fat.bin"), os.path.join(td, "gfx950.co")
+            subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + sec, lib], check=True)
+            subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--input=" + sec, "--output=" + co], check=True)
+            txt = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+        out = {}
+        for blk in txt.split("- .agpr_count")[1:]:
+            name = subprocess.run(["c++filt", re.search(r"\.name:\s+(\S+)", blk).group(1)], capture_output=True, text=True).stdout.strip()
+            g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))  # noqa: E731
+            out[name] = (g("vgpr_count"), g("private_segment_fixed_size"))
+        return out
+
+    topo = codegen.stock_topologies()
+    budgets = {   # kernel substring -> (max VGPRs, max scratch bytes): wavefronts per SIMD = floor(512 / VGPRs)
+        "anm6": {"k_step_rows<double, false>": (256, 0), "k_step_stragglers<double, true>": (256, 0), "k_step_general<double>": (256, 0)},
+        "case30": {"k_radial<double, (anonymous namespace)::Topo, false>": (168, 0), "k_radial<double, void, false>": (168, 0),
+                   "k_mesh<double, false, false>": (256, 32)},   # (32 B: four doubles of the epilogue, outside the Newton loop)
+    }
+    for net, want in budgets.items():
+        lib = codegen.lib_path(codegen.topology_name(topo[net]))
+        if not os.path.exists(lib):
+            pytest.skip("library of %s not built here" % net)
+        have = kernels(lib)
+        for sub_, (vmax, smax) in want.items():
+            hits = [(n, v) for n, v in have.items() if sub_ in n]
+            assert hits, sub_
+            for n, (vg, sc) in hits:
+                assert vg <= vmax and sc <= smax, "%s: %d VGPRs, %d B scratch (budget %d / %d)" % (n[:90], vg, sc, vmax, smax)
