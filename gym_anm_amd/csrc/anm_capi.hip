@@ -196,19 +196,19 @@ ClassSel class_sel(const anm_model* m, bool radial) {
   return ClassSel{m->d_env_class, radial ? int(m->plan.hd.size()) : int(m->h_const.size()), 1, m->class_per_env ? 1 : 0};
 }
 
-template <bool WG>
+template <bool WG, int SW = 2>
 void launch_mesh_as(anm_model* m, int precision, unsigned grid, unsigned threads, size_t lds, hipStream_t s, const radial::IO& io,
                     SolverOpts so, int64_t n, const ClassSel& cs) {
   const mesh::Dims& d = m->mplan.d;
   if (cs.per_group) {
     if (precision == ANM_SOLVE_F32)
-      hipLaunchKernelGGL((mesh::k_mesh<float, true, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+      hipLaunchKernelGGL((mesh::k_mesh<float, true, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
     else
-      hipLaunchKernelGGL((mesh::k_mesh<double, true, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+      hipLaunchKernelGGL((mesh::k_mesh<double, true, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   } else if (precision == ANM_SOLVE_F32)
-    hipLaunchKernelGGL((mesh::k_mesh<float, false, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    hipLaunchKernelGGL((mesh::k_mesh<float, false, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   else
-    hipLaunchKernelGGL((mesh::k_mesh<double, false, WG>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    hipLaunchKernelGGL((mesh::k_mesh<double, false, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
 }
 
 int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io_in, SolverOpts so) {
@@ -221,6 +221,7 @@ int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const rad
   const size_t lds = mesh::lds_bytes(d, waves);
   const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1, m->class_per_env ? 1 : 0} : ClassSel{m->d_zero, 0, 0, 0};
   if (mesh::is_workgroup(d)) launch_mesh_as<true>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
+  else if (mesh::simd_waves(d) == 3) launch_mesh_as<false, 3>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
   else launch_mesh_as<false>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_mesh");
@@ -344,8 +345,10 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
         if (mesh::lds_bytes(m->mplan.d, mesh::waves_per_block(m->mplan.d)) > 64 * 1024) {
           // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, here: an
           // attribute call has no place in a launch path that may be under stream capture)
-          const void* fns[8] = {(const void*)mesh::k_mesh<float, false, false>, (const void*)mesh::k_mesh<double, false, false>,
+          const void* fns[12] = {(const void*)mesh::k_mesh<float, false, false>, (const void*)mesh::k_mesh<double, false, false>,
                                 (const void*)mesh::k_mesh<float, true, false>,  (const void*)mesh::k_mesh<double, true, false>,
+                                (const void*)mesh::k_mesh<float, false, false, 3>, (const void*)mesh::k_mesh<double, false, false, 3>,
+                                (const void*)mesh::k_mesh<float, true, false, 3>,  (const void*)mesh::k_mesh<double, true, false, 3>,
                                 (const void*)mesh::k_mesh<float, false, true>,  (const void*)mesh::k_mesh<double, false, true>,
                                 (const void*)mesh::k_mesh<float, true, true>,   (const void*)mesh::k_mesh<double, true, true>};
           for (const void* fn : fns)

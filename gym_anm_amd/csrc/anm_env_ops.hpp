@@ -753,6 +753,9 @@ __device__ void op_step_view(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
 // (Measured and left out, profiles/r05_c_*: the series table copied to LDS by every wavefront, so that the look-up by the time
 // index is no second, dependent trip to memory -- 524 288 environments 176.3 -> 180.7 us: the trip hides behind the first
 // scalar loads of the constants, the copy does not.)
+// (Measured and left out, profiles/r05_h_*: one throw-away scalar load per 64-byte line of the constant buffer while the wavefront
+// waits for its action rows, so that the dozen dependent batches of constant loads along the prologue hit the scalar cache --
+// headline kernel 87.03 -> 86.79 us over four same-box pairs, 524 288 environments unchanged: not worth 40 instructions.)
 template <class T, class JT, bool FULL>
 __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n, double* lds) {
   typedef Dims<T> D;

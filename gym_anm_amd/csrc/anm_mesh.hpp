@@ -122,23 +122,45 @@ inline size_t lds_bytes(const Dims& d, int waves) {
   return size_t(waves) * (64 / d.G) * d.lds_per_env * sizeof(double) + size_t(d.n_stage) * sizeof(int);
 }
 // wavefronts per workgroup (they share one copy of the tables): what puts most wavefronts on a compute unit -- its
-// 160 KB of LDS, and two wavefronts per SIMD (k_mesh holds more than 170 registers per lane).  On a tie the larger
+// 160 KB of LDS, and two or three wavefronts per SIMD (simd_waves).  On a tie the larger
 // workgroup for groups of 32 lanes and more (fewer copies of the tables to stage: the batch of the meshed 30-bus
 // network -4 %), the smaller one below: a workgroup gives its wavefront slots back when its LAST wavefront ends, and
 // with 8 environments per wavefront a fair share of the wavefronts carry a diverging solve to the iteration cap
 // (ANM6 through this family, 65 536 transitions: 358 us with one wavefront per workgroup, 445 us with four;
 // profiles/r04_m_mesh_step_program.txt)
-constexpr int MAX_WAVES_PER_CU = 8;
+inline size_t waves_on_cu(const Dims& d, int w, int cap) {
+  return lds_bytes(d, w) <= 160 * 1024 ? std::min<size_t>(size_t(cap), (160 * 1024 / lds_bytes(d, w)) * w) : 0;
+}
+// Wavefronts per SIMD the kernel is compiled for: k_mesh holds ~190 registers per lane (two wavefronts per SIMD); budgeted
+// for three (168 registers, ~110 bytes per lane more in scratch) it is the faster kernel where the LDS of the environments
+// lets a compute unit hold twelve wavefronts AND the batch is throughput-bound -- a meshed 20-bus network, 16 384
+// transitions: 166 -> 148 us.  Where LDS stops at eight to ten wavefronts the spills cost 1-2 % and buy nothing (meshed 30
+// buses: 549 -> 558 us at eight, 544 at nine, 613 at ten in two workgroups of five); and a batch that waits for one
+// diverging solve's hundred trips pays for them on every trip (ANM6 forced through this family, 8 environments per
+// wavefront, 65 536 transitions: 361 -> 373 us) -- so: groups of 16 lanes and more only (what reaches this family by
+// default).  profiles/r05_i_mesh_occupancy.txt
+inline int simd_waves(const Dims& d) {
+  if (is_workgroup(d)) return 2;
+  if (const char* ev = getenv("ANM_MESH_SIMD_WAVES")) {   // tuning experiments
+    const int v = atoi(ev);
+    if (v == 2 || v == 3) return v;
+  }
+  if (d.G < 16) return 2;
+  size_t best = 0;
+  for (int w = 1; w <= 4; w *= 2) best = std::max(best, waves_on_cu(d, w, 12));
+  return best >= 12 ? 3 : 2;
+}
 inline int waves_per_block(const Dims& d) {
   if (is_workgroup(d)) return d.G / 64;
   if (const char* ev = getenv("ANM_MESH_WAVES")) {   // tuning experiments
     const int w = atoi(ev);
     if ((w == 1 || w == 2 || w == 4) && lds_bytes(d, w) <= 160 * 1024) return w;
   }
+  const int cap = 4 * simd_waves(d);
   int best = 1;
   size_t best_waves = 0;
   for (int w = 1; w <= 4; w *= 2) {
-    const size_t per_cu = lds_bytes(d, w) <= 160 * 1024 ? std::min<size_t>(MAX_WAVES_PER_CU, (160 * 1024 / lds_bytes(d, w)) * w) : 0;
+    const size_t per_cu = waves_on_cu(d, w, cap);
     if (per_cu > best_waves || (per_cu == best_waves && d.G >= 32)) { best_waves = per_cu; best = w; }
   }
   return best;
@@ -587,11 +609,7 @@ inline bool build_plan_zone(const anm_network_desc& n, Plan& P, std::string& err
 }
 
 // wavefronts a compute unit holds of a plan (LDS, registers)
-inline size_t waves_per_cu(const Dims& d) {
-  const int w = waves_per_block(d);
-  const size_t blocks = (160 * 1024) / lds_bytes(d, w);
-  return std::min<size_t>(MAX_WAVES_PER_CU, blocks * w);
-}
+inline size_t waves_per_cu(const Dims& d) { return waves_on_cu(d, waves_per_block(d), 4 * simd_waves(d)); }
 
 // The plan of a network: the program with the fewest steps per Newton trip among
 //   * the zones "from level z on" (none, the last level, the last two ...; a search down the levels stops when five in a
@@ -634,9 +652,10 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     else ANM_WAVE_SYNC();                      \
   } while (0)
 
-template <class JT, bool PG = false, bool WG = false>   // PG: see k_radial; WG: the environment is the workgroup
-__global__ __launch_bounds__(WG ? 512 : 256) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,
-                                                          radial::IO io, SolverOpts so, int64_t n_env, ClassSel cls) {
+// PG: see k_radial; WG: the environment is the workgroup; SW: wavefronts per SIMD the registers are budgeted for (simd_waves)
+template <class JT, bool PG = false, bool WG = false, int SW = 2>
+__global__ __launch_bounds__(WG ? 512 : 256, SW) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,
+                                                              radial::IO io, SolverOpts so, int64_t n_env, ClassSel cls) {
   // a workgroup = 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet: a lane
   // group lies within one wavefront, whose LDS operations complete in program order (fences only).
   // WG: the workgroup (2 ... 8 wavefronts) is ONE environment; every place where lanes of an environment hand

@@ -183,3 +183,16 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
   *max_err = e;
   return 0;
 }
+
+// what decides how many wavefronts a compute unit holds of a plan: out[0..6] = group size, steps per trip, doubles of LDS per
+// environment, wavefronts per workgroup, LDS bytes per workgroup, wavefronts per compute unit, wavefronts per SIMD the kernel
+// variant is budgeted for
+extern "C" int mesh_plan_stats(const anm_network_desc* n, int64_t* out) {
+  mesh::Plan P;
+  std::string err;
+  if (!mesh::build_plan(*n, P, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return -1; }
+  const int w = mesh::waves_per_block(P.d);
+  out[0] = P.d.G; out[1] = P.d.n_steps; out[2] = P.d.lds_per_env; out[3] = w;
+  out[4] = int64_t(mesh::lds_bytes(P.d, w)); out[5] = int64_t(mesh::waves_per_cu(P.d)); out[6] = mesh::simd_waves(P.d);
+  return 0;
+}
