@@ -132,6 +132,7 @@ struct anm_model {
   radial::Plan plan;            // per-lane tables of the lane-group kernel
   bool mesh_ok = false;         // the general lane-group kernel can take the network
   mesh::Plan mplan;
+  mesh::Launch mlaunch{2, 1, true, 0, 0};
   int* d_mi = nullptr;
   double* d_md = nullptr;
   std::vector<std::vector<double>> x_md;      // general lane-group tables of each extra class
@@ -196,33 +197,42 @@ ClassSel class_sel(const anm_model* m, bool radial) {
   return ClassSel{m->d_env_class, radial ? int(m->plan.hd.size()) : int(m->h_const.size()), 1, m->class_per_env ? 1 : 0};
 }
 
-template <bool WG, int SW = 2>
+template <bool WG, int SW = 2, bool TL = !WG>
 void launch_mesh_as(anm_model* m, int precision, unsigned grid, unsigned threads, size_t lds, hipStream_t s, const radial::IO& io,
                     SolverOpts so, int64_t n, const ClassSel& cs) {
   const mesh::Dims& d = m->mplan.d;
   if (cs.per_group) {
     if (precision == ANM_SOLVE_F32)
-      hipLaunchKernelGGL((mesh::k_mesh<float, true, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+      hipLaunchKernelGGL((mesh::k_mesh<float, true, WG, SW, TL>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
     else
-      hipLaunchKernelGGL((mesh::k_mesh<double, true, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+      hipLaunchKernelGGL((mesh::k_mesh<double, true, WG, SW, TL>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   } else if (precision == ANM_SOLVE_F32)
-    hipLaunchKernelGGL((mesh::k_mesh<float, false, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    hipLaunchKernelGGL((mesh::k_mesh<float, false, WG, SW, TL>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
   else
-    hipLaunchKernelGGL((mesh::k_mesh<double, false, WG, SW>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+    hipLaunchKernelGGL((mesh::k_mesh<double, false, WG, SW, TL>), dim3(grid), dim3(threads), lds, s, d, m->d_mi, m->d_md, io, so, n, cs);
+}
+
+// the variants of k_mesh a launch may pick (mesh::Launch), as function pointers: for hipFuncSetAttribute
+template <bool WG, int SW, bool TL>
+void mesh_variants(std::vector<const void*>& out) {
+  out.push_back((const void*)mesh::k_mesh<float, false, WG, SW, TL>);
+  out.push_back((const void*)mesh::k_mesh<double, false, WG, SW, TL>);
+  out.push_back((const void*)mesh::k_mesh<float, true, WG, SW, TL>);
+  out.push_back((const void*)mesh::k_mesh<double, true, WG, SW, TL>);
 }
 
 int launch_mesh(anm_model* m, int precision, int64_t n, hipStream_t s, const radial::IO& io_in, SolverOpts so) {
   radial::IO io = io_in;
   io.v = m->view;
   const mesh::Dims& d = m->mplan.d;
-  const int waves = mesh::waves_per_block(d);
-  const int per_block = mesh::envs_per_block(d);
-  const unsigned grid = unsigned((n + per_block - 1) / per_block);
-  const size_t lds = mesh::lds_bytes(d, waves);
+  const mesh::Launch& L = m->mlaunch;   // (decided once, at anm_model_create)
+  const int per_block = mesh::envs_per_block(d, L);
+  const unsigned grid = unsigned((n + per_block - 1) / per_block), threads = unsigned(64 * L.waves);
   const ClassSel cs = m->d_env_class ? ClassSel{m->d_env_class, int(m->mplan.hd.size()), 1, m->class_per_env ? 1 : 0} : ClassSel{m->d_zero, 0, 0, 0};
-  if (mesh::is_workgroup(d)) launch_mesh_as<true>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
-  else if (mesh::simd_waves(d) == 3) launch_mesh_as<false, 3>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
-  else launch_mesh_as<false>(m, precision, grid, unsigned(64 * waves), lds, s, io, so, n, cs);
+  if (mesh::is_workgroup(d)) launch_mesh_as<true>(m, precision, grid, threads, L.lds, s, io, so, n, cs);
+  else if (!L.tables_in_lds) launch_mesh_as<false, 2, false>(m, precision, grid, threads, L.lds, s, io, so, n, cs);
+  else if (L.simd_waves == 3) launch_mesh_as<false, 3>(m, precision, grid, threads, L.lds, s, io, so, n, cs);
+  else launch_mesh_as<false>(m, precision, grid, threads, L.lds, s, io, so, n, cs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_mesh");
   return 0;
@@ -342,15 +352,12 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
       if (e1 == hipSuccess && e2 == hipSuccess &&
           hipMemcpy(m->d_mi, m->mplan.hi.data(), m->mplan.hi.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
         m->mesh_ok = true;
-        if (mesh::lds_bytes(m->mplan.d, mesh::waves_per_block(m->mplan.d)) > 64 * 1024) {
+        m->mlaunch = mesh::launch_of(m->mplan.d);
+        if (m->mlaunch.lds > 64 * 1024) {
           // above the default per-workgroup limit: ask for the compute unit's whole LDS (once, here: an
           // attribute call has no place in a launch path that may be under stream capture)
-          const void* fns[12] = {(const void*)mesh::k_mesh<float, false, false>, (const void*)mesh::k_mesh<double, false, false>,
-                                (const void*)mesh::k_mesh<float, true, false>,  (const void*)mesh::k_mesh<double, true, false>,
-                                (const void*)mesh::k_mesh<float, false, false, 3>, (const void*)mesh::k_mesh<double, false, false, 3>,
-                                (const void*)mesh::k_mesh<float, true, false, 3>,  (const void*)mesh::k_mesh<double, true, false, 3>,
-                                (const void*)mesh::k_mesh<float, false, true>,  (const void*)mesh::k_mesh<double, false, true>,
-                                (const void*)mesh::k_mesh<float, true, true>,   (const void*)mesh::k_mesh<double, true, true>};
+          std::vector<const void*> fns;
+          mesh_variants<false, 2, true>(fns); mesh_variants<false, 3, true>(fns); mesh_variants<false, 2, false>(fns); mesh_variants<true, 2, false>(fns);
           for (const void* fn : fns)
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) m->mesh_ok = false;
         }

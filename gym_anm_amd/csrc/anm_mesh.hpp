@@ -116,56 +116,83 @@ constexpr int MAX_GROUP = 512;   // (a 1024-lane workgroup would leave 128 regis
 constexpr int RED_DOUBLES = 64;
 inline bool is_workgroup(const Dims& d) { return d.G > 64; }
 
-// LDS of a workgroup of `waves` wavefronts: the environments' own areas + the staged tables (shared)
-inline size_t lds_bytes(const Dims& d, int waves) {
+// LDS of a workgroup of `waves` wavefronts: the environments' own areas + (tables: the staged tables, one copy)
+inline size_t lds_bytes(const Dims& d, int waves, bool tables) {
   if (is_workgroup(d)) return size_t(d.lds_per_env) * sizeof(double);
-  return size_t(waves) * (64 / d.G) * d.lds_per_env * sizeof(double) + size_t(d.n_stage) * sizeof(int);
+  return size_t(waves) * (64 / d.G) * d.lds_per_env * sizeof(double) + (tables ? size_t(d.n_stage) * sizeof(int) : 0);
 }
-// wavefronts per workgroup (they share one copy of the tables): what puts most wavefronts on a compute unit -- its
-// 160 KB of LDS, and two or three wavefronts per SIMD (simd_waves).  On a tie the larger
-// workgroup for groups of 32 lanes and more (fewer copies of the tables to stage: the batch of the meshed 30-bus
-// network -4 %), the smaller one below: a workgroup gives its wavefront slots back when its LAST wavefront ends, and
-// with 8 environments per wavefront a fair share of the wavefronts carry a diverging solve to the iteration cap
-// (ANM6 through this family, 65 536 transitions: 358 us with one wavefront per workgroup, 445 us with four;
-// profiles/r04_m_mesh_step_program.txt)
-inline size_t waves_on_cu(const Dims& d, int w, int cap) {
-  return lds_bytes(d, w) <= 160 * 1024 ? std::min<size_t>(size_t(cap), (160 * 1024 / lds_bytes(d, w)) * w) : 0;
+inline size_t waves_on_cu(const Dims& d, int w, int cap, bool tables) {
+  const size_t b = lds_bytes(d, w, tables);
+  return b <= 160 * 1024 ? std::min<size_t>(size_t(cap), (160 * 1024 / b) * w) : 0;
 }
-// Wavefronts per SIMD the kernel is compiled for: k_mesh holds ~190 registers per lane (two wavefronts per SIMD); budgeted
-// for three (168 registers, ~110 bytes per lane more in scratch) it is the faster kernel where the LDS of the environments
-// lets a compute unit hold twelve wavefronts AND the batch is throughput-bound -- a meshed 20-bus network, 16 384
-// transitions: 166 -> 148 us.  Where LDS stops at eight to ten wavefronts the spills cost 1-2 % and buy nothing (meshed 30
-// buses: 549 -> 558 us at eight, 544 at nine, 613 at ten in two workgroups of five); and a batch that waits for one
-// diverging solve's hundred trips pays for them on every trip (ANM6 forced through this family, 8 environments per
-// wavefront, 65 536 transitions: 361 -> 373 us) -- so: groups of 16 lanes and more only (what reaches this family by
-// default).  profiles/r05_i_mesh_occupancy.txt
-inline int simd_waves(const Dims& d) {
-  if (is_workgroup(d)) return 2;
-  if (const char* ev = getenv("ANM_MESH_SIMD_WAVES")) {   // tuning experiments
-    const int v = atoi(ev);
-    if (v == 2 || v == 3) return v;
-  }
-  if (d.G < 16) return 2;
+inline size_t most_waves_on_cu(const Dims& d, int cap, bool tables) {
   size_t best = 0;
-  for (int w = 1; w <= 4; w *= 2) best = std::max(best, waves_on_cu(d, w, 12));
-  return best >= 12 ? 3 : 2;
-}
-inline int waves_per_block(const Dims& d) {
-  if (is_workgroup(d)) return d.G / 64;
-  if (const char* ev = getenv("ANM_MESH_WAVES")) {   // tuning experiments
-    const int w = atoi(ev);
-    if ((w == 1 || w == 2 || w == 4) && lds_bytes(d, w) <= 160 * 1024) return w;
-  }
-  const int cap = 4 * simd_waves(d);
-  int best = 1;
-  size_t best_waves = 0;
-  for (int w = 1; w <= 4; w *= 2) {
-    const size_t per_cu = waves_on_cu(d, w, cap);
-    if (per_cu > best_waves || (per_cu == best_waves && d.G >= 32)) { best_waves = per_cu; best = w; }
-  }
+  for (int w = 1; w <= 4; w *= 2) best = std::max(best, waves_on_cu(d, w, cap, tables));
   return best;
 }
-inline int envs_per_block(const Dims& d) { return is_workgroup(d) ? 1 : waves_per_block(d) * (64 / d.G); }
+
+// How a plan is launched: which variant of k_mesh, in workgroups of how many wavefronts.
+//
+// simd_waves -- wavefronts per SIMD the kernel is compiled for.  k_mesh holds ~190 registers per lane (two wavefronts per
+//   SIMD); budgeted for three (168 registers, ~110 bytes per lane more in scratch) it is the faster kernel where the LDS of
+//   the environments lets a compute unit hold twelve wavefronts AND the batch is throughput-bound -- a meshed 20-bus
+//   network, 16 384 transitions: 166 -> 148 us.  Where LDS stops at eight to ten wavefronts the spills cost 1-2 % and buy
+//   nothing (meshed 30 buses: 549 -> 558 us at eight, 544 at nine, 613 at ten in two workgroups of five); and a batch that
+//   waits for one diverging solve's hundred trips pays for them on every trip (ANM6 forced through this family, 8
+//   environments per wavefront, 65 536 transitions: 361 -> 373 us) -- so: groups of 16 lanes and more only (what reaches
+//   this family by default).  profiles/r05_i_mesh_occupancy.txt
+// tables_in_lds -- the lists and the step program staged in LDS, one copy per workgroup (a 30-bus network: 5.5 KB), or read
+//   from global memory where they are.  Staged they are the faster tables (meshed 30 buses 547 us against 566, 20 buses 150
+//   against 153) -- unless the copy costs the compute unit wavefronts: a meshed 64-bus network has 29 KB of tables next to
+//   20 KB per environment, four wavefronts per compute unit with the copy and eight without: 8 192 transitions
+//   8.04 -> 5.45 ms.  profiles/r05_j_mesh_tables.txt
+// waves -- wavefronts per workgroup (they share the staged tables and otherwise never meet): what puts most wavefronts on
+//   a compute unit.  On a tie the larger workgroup for groups of 32 lanes and more (fewer copies of the tables to stage:
+//   the batch of the meshed 30-bus network -4 %), the smaller one below: a workgroup gives its wavefront slots back when
+//   its LAST wavefront ends, and with 8 environments per wavefront a fair share of the wavefronts carry a diverging solve
+//   to the iteration cap (ANM6 through this family, 65 536 transitions: 358 us with one wavefront per workgroup, 445 us
+//   with four; profiles/r04_m_mesh_step_program.txt)
+// Deterministic in the plan and the tuning switches ANM_MESH_SIMD_WAVES=2|3, ANM_MESH_TABLES=lds|global, ANM_MESH_WAVES=1|2|4.
+struct Launch {
+  int simd_waves, waves;
+  bool tables_in_lds;
+  size_t lds, waves_per_cu;
+};
+inline Launch launch_of(const Dims& d) {
+  Launch L{2, 1, false, 0, 0};
+  if (is_workgroup(d)) {
+    L.waves = d.G / 64;
+    L.lds = lds_bytes(d, L.waves, false);
+    L.waves_per_cu = std::min<size_t>(8, (160 * 1024 / L.lds) * L.waves);
+    return L;
+  }
+  L.tables_in_lds = true;
+  if (d.G >= 16 && most_waves_on_cu(d, 12, true) >= 12) L.simd_waves = 3;
+  if (const char* ev = getenv("ANM_MESH_SIMD_WAVES")) {
+    const int v = atoi(ev);
+    if (v == 2 || v == 3) L.simd_waves = v;
+  }
+  // (the variant that leaves the tables where they are exists for two wavefronts per SIMD: where three fit, LDS is no issue)
+  if (L.simd_waves == 2 && most_waves_on_cu(d, 8, false) > most_waves_on_cu(d, 8, true)) L.tables_in_lds = false;
+  if (const char* ev = getenv("ANM_MESH_TABLES")) {
+    if (std::string(ev) == "lds" && lds_bytes(d, 1, true) <= 160 * 1024) L.tables_in_lds = true;
+    if (std::string(ev) == "global") { L.tables_in_lds = false; L.simd_waves = 2; }
+  }
+  const int cap = 4 * L.simd_waves;
+  size_t best_waves = 0;
+  for (int w = 1; w <= 4; w *= 2) {
+    const size_t per_cu = waves_on_cu(d, w, cap, L.tables_in_lds);
+    if (per_cu > best_waves || (per_cu == best_waves && d.G >= 32)) { best_waves = per_cu; L.waves = w; }
+  }
+  if (const char* ev = getenv("ANM_MESH_WAVES")) {
+    const int w = atoi(ev);
+    if ((w == 1 || w == 2 || w == 4) && lds_bytes(d, w, L.tables_in_lds) <= 160 * 1024) L.waves = w;
+  }
+  L.lds = lds_bytes(d, L.waves, L.tables_in_lds);
+  L.waves_per_cu = waves_on_cu(d, L.waves, cap, L.tables_in_lds);
+  return L;
+}
+inline int envs_per_block(const Dims& d, const Launch& L) { return is_workgroup(d) ? 1 : L.waves * (64 / d.G); }
 
 inline bool fits(const anm_network_desc& n) {
   return n.n_bus >= 2 && n.n_bus - 1 <= MAX_GROUP && n.n_dev <= MAX_GROUP && n.n_branch <= MAX_GROUP * BR_SLOTS;
@@ -601,7 +628,7 @@ inline bool build_plan_zone(const anm_network_desc& n, Plan& P, std::string& err
   for (int k = 0; k < d.ND; ++k) pack_device(n, k, &P.hd[d.off_dev + k * SD_SIZE]);
 
   d.n_stage = int(P.hi.size()) - d.off_lists;   // what a workgroup stages in LDS: lists, fill ids, the program
-  if (lds_bytes(d, 1) > 160 * 1024) {
+  if (lds_bytes(d, 1, false) > 160 * 1024) {
     err = "network too large for the general lane-group kernel (LDS)";
     return false;
   }
@@ -609,7 +636,7 @@ inline bool build_plan_zone(const anm_network_desc& n, Plan& P, std::string& err
 }
 
 // wavefronts a compute unit holds of a plan (LDS, registers)
-inline size_t waves_per_cu(const Dims& d) { return waves_on_cu(d, waves_per_block(d), 4 * simd_waves(d)); }
+inline size_t waves_per_cu(const Dims& d) { return launch_of(d).waves_per_cu; }
 
 // The plan of a network: the program with the fewest steps per Newton trip among
 //   * the zones "from level z on" (none, the last level, the last two ...; a search down the levels stops when five in a
@@ -652,8 +679,9 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
     else ANM_WAVE_SYNC();                      \
   } while (0)
 
-// PG: see k_radial; WG: the environment is the workgroup; SW: wavefronts per SIMD the registers are budgeted for (simd_waves)
-template <class JT, bool PG = false, bool WG = false, int SW = 2>
+// PG: see k_radial; WG: the environment is the workgroup; SW: wavefronts per SIMD the registers are budgeted for; TL: the tables
+// are staged in LDS (Launch)
+template <class JT, bool PG = false, bool WG = false, int SW = 2, bool TL = !WG>
 __global__ __launch_bounds__(WG ? 512 : 256, SW) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,
                                                               radial::IO io, SolverOpts so, int64_t n_env, ClassSel cls) {
   // a workgroup = 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet: a lane
@@ -688,7 +716,7 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW) void k_mesh(Dims d, const int* 
   double* S = sh_dyn + grp * d.lds_per_env;                 // this environment's LDS
   double* RED = S + d.l_red;                                // WG: flags and partial sums of the wavefronts
   const int* tab;                                           // lists, fill ids, the program
-  if constexpr (WG) {
+  if constexpr (WG || !TL) {
     tab = ri + d.off_lists;
   } else {
     int* stage = reinterpret_cast<int*>(sh_dyn + per_block * d.lds_per_env);   // (shared by the workgroup)

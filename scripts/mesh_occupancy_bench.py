@@ -1,6 +1,6 @@
 """General lane-group kernel, wavefronts per compute unit: Simulator.transition launches of meshed networks (cap 100)
-under whatever ANM_MESH_SIMD_WAVES / ANM_MESH_WAVES / ANM_BUILD_TAG the environment names (ANM_IMPL=mesh puts ANM6 there).
-usage: python scripts/mesh_occupancy_bench.py [anm6 mesh12 mesh20 mesh30 mesh64 mesh200]"""
+under whatever ANM_MESH_SIMD_WAVES / ANM_MESH_TABLES / ANM_MESH_WAVES / ANM_BUILD_TAG the environment names (ANM_IMPL=mesh puts ANM6 there).
+usage: python scripts/mesh_occupancy_bench.py [anm6 mesh12 mesh20 mesh30 mesh50 mesh64 mesh200]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,7 @@ from gym_anm_amd import networks
 
 NETS = {"anm6": (networks.anm6_network, 65536, 1.0), "mesh12": (lambda: networks.synthetic_meshed_network(12, 3, 3), 32768, 1.0),
         "mesh20": (lambda: networks.synthetic_meshed_network(20, 3, 6), 16384, 1.0), "mesh30": (lambda: networks.synthetic_meshed_network(30, 6, 4), 16384, 1.0),
-        "mesh64": (lambda: networks.synthetic_meshed_network(64, 9, 20), 8192, 1.0), "mesh200": (lambda: networks.synthetic_meshed_network(200, 13, 30), 4096, 40.0 / 200)}
+        "mesh50": (lambda: networks.synthetic_meshed_network(50, 5, 10), 8192, 1.0), "mesh64": (lambda: networks.synthetic_meshed_network(64, 9, 20), 8192, 1.0), "mesh200": (lambda: networks.synthetic_meshed_network(200, 13, 30), 4096, 40.0 / 200)}
 dev = torch.device("cuda", 0)
 for name in (sys.argv[1:] or ["mesh20", "mesh30", "mesh64"]):
     mk, E, scale = NETS[name]

@@ -184,15 +184,15 @@ extern "C" int mesh_program_check(const anm_network_desc* n, uint64_t seed, doub
   return 0;
 }
 
-// what decides how many wavefronts a compute unit holds of a plan: out[0..6] = group size, steps per trip, doubles of LDS per
-// environment, wavefronts per workgroup, LDS bytes per workgroup, wavefronts per compute unit, wavefronts per SIMD the kernel
-// variant is budgeted for
+// how a plan is launched (mesh::Launch): out[0..7] = group size, steps per trip, doubles of LDS per environment, wavefronts per
+// workgroup, LDS bytes per workgroup, wavefronts per compute unit, wavefronts per SIMD the kernel variant is budgeted for,
+// tables staged in LDS (1) or read from global memory (0)
 extern "C" int mesh_plan_stats(const anm_network_desc* n, int64_t* out) {
   mesh::Plan P;
   std::string err;
   if (!mesh::build_plan(*n, P, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return -1; }
-  const int w = mesh::waves_per_block(P.d);
-  out[0] = P.d.G; out[1] = P.d.n_steps; out[2] = P.d.lds_per_env; out[3] = w;
-  out[4] = int64_t(mesh::lds_bytes(P.d, w)); out[5] = int64_t(mesh::waves_per_cu(P.d)); out[6] = mesh::simd_waves(P.d);
+  const mesh::Launch L = mesh::launch_of(P.d);
+  out[0] = P.d.G; out[1] = P.d.n_steps; out[2] = P.d.lds_per_env; out[3] = L.waves;
+  out[4] = int64_t(L.lds); out[5] = int64_t(L.waves_per_cu); out[6] = L.simd_waves; out[7] = L.tables_in_lds ? 1 : 0;
   return 0;
 }

@@ -588,6 +588,44 @@ def test_mesh_fused_levels_schedule_equals_the_default(monkeypatch, n_bus, seed,
     assert torch.equal(sims[0].full[conv], sims[1].full[conv]) and torch.equal(sims[0].reward[conv], sims[1].reward[conv])
 
 
+@pytest.mark.parametrize("n_bus,seed,n_chords,switch", [(20, 3, 6, ("ANM_MESH_SIMD_WAVES", "2", "3")), (14, 5, 3, ("ANM_MESH_SIMD_WAVES", "2", "3")),
+                                                        (64, 9, 20, ("ANM_MESH_TABLES", "lds", "global")), (30, 6, 4, ("ANM_MESH_TABLES", "lds", "global"))])
+def test_mesh_launch_variants_are_bit_identical(monkeypatch, n_bus, seed, n_chords, switch):
+    """The variants of the general lane-group kernel a plan may be launched with (mesh::Launch, read when the model is
+    created): registers budgeted for two or three wavefronts per SIMD, tables staged in LDS or read from global memory.
+    Same operations on the same operands in the same order: bit-identical outputs, diverging solves included."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    net = networks.synthetic_meshed_network(n_bus, seed, n_chords)
+    M = 512
+    sims = []
+    for value in switch[1:]:
+        monkeypatch.setenv(switch[0], value)
+        sims.append(BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl="mesh"))
+    monkeypatch.delenv(switch[0])
+    model, rng = sims[0].model, np.random.default_rng(seed)
+    b, f = model.baseMVA, min(1.0, 40.0 / n_bus)
+
+    def U(lo, hi, scale=1.0):
+        lo, hi = np.asarray(lo, float) * scale, np.asarray(hi, float) * scale
+        return lo + (hi - lo) * rng.uniform(size=(M, lo.size))
+
+    pl = U(model.dev_p_min[model.load_idx], 0 * model.dev_p_min[model.load_idx], 0.6 * b * f)
+    pp = U(0 * model.dev_p_max[model.gen_idx], model.dev_p_max[model.gen_idx], b)
+    ps = U(model.dev_p_min[model.setp_idx], model.dev_p_max[model.setp_idx], 1.2 * b * f)
+    qs = U(model.dev_q_min[model.setp_idx], model.dev_q_max[model.setp_idx], 1.2 * b * f)
+    soc = U(model.dev_soc_min[model.des_idx], model.dev_soc_max[model.des_idx])
+    pl[-4:] *= 40.0 / f
+    for sim in sims:
+        sim.soc.copy_(torch.as_tensor(soc))
+        sim.transition(pl, pp, ps, qs)
+    assert int(sims[0].pfe_converged.sum()) >= M // 2
+    bits = lambda a: a.view(torch.int64) if a.dtype == torch.float64 else a   # (NaN == NaN as bit patterns)
+    for name in ("pfe_converged", "nr_iters", "full", "reward", "soc"):
+        assert torch.equal(bits(getattr(sims[0], name)), bits(getattr(sims[1], name))), name
+
+
 def test_environment_over_a_network_larger_than_a_wavefront():
     env = pc.large_network_env(KW)
     assert env.simulator.lanes_per_env == 256
