@@ -70,9 +70,12 @@ __global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts
   else op_reset<Topo, JT>(C, io, so, e);
 }
 
-// the step of the environments a batch view names (thread-per-environment family): see op_step_view
-template <class JT>
-__global__ __launch_bounds__(BLOCK) void k_step_view(cptr_t C, EnvIO io, SolverOpts so, int64_t n, View v) {
+// the step of the environments a batch view names (thread-per-environment family): see op_step_view.
+// SW: wavefronts per SIMD the registers are budgeted for -- 1: 288 registers; 2: 256 + 80 bytes of scratch, the faster
+// kernel once the batch gives every SIMD more than two wavefronts (two ANM6 models, 524 288 environments: 385 -> 315 us;
+// 131 072: 219 -> 223; 16 384, where the step waits for one diverging solve: 124 -> 139.  profiles/r05_k_view_step.txt)
+template <class JT, int SW>
+__global__ __launch_bounds__(BLOCK, SW) void k_step_view(cptr_t C, EnvIO io, SolverOpts so, int64_t n, View v) {
   __shared__ double lds[Topo::TREE != 0 ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
   op_step_view<Topo, JT>(C, io, so, n, v, lds);
 }
@@ -127,6 +130,7 @@ struct anm_model {
   int impl_unbound = -1;        // the family to go back to when a per-environment class binding is lifted (-1: none pending)
   radial::View view{};          // anm_model_bind_view: the launches serve a sub-batch of a larger, padded batch
   bool has_view = false;
+  int view_waves = 0;   // k_step_view variant: 0 = by batch size; 1 | 2 (ANM_VIEW_WAVES, read at anm_model_create: tuning, tests)
   bool tpe_ok = false;          // the network has the topology this library was compiled for
   bool radial_ok = false;       // the network is a tree that fits one wavefront
   radial::Plan plan;            // per-lane tables of the lane-group kernel
@@ -370,6 +374,10 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
         if (ev && std::string(ev) == "mesh") m->impl = ANM_IMPL_MESH;
       }
     }
+  }
+  if (const char* ev = getenv("ANM_VIEW_WAVES")) {
+    const int v = atoi(ev);
+    if (v == 1 || v == 2) m->view_waves = v;
   }
   if (!m->tpe_ok && !m->radial_ok && !m->mesh_ok) {
     // neither the compiled topology nor a network the generic lane-group kernels can take
@@ -1054,10 +1062,14 @@ static int launch_step(anm_model* m, const EnvIO& io_in, int64_t n, const anm_so
     io.ws = nullptr;
     io.state_same = nullptr;
     io.aux_stride = m->view.w_aux;
-    if (prec == ANM_SOLVE_F32)
-      hipLaunchKernelGGL(k_step_view<float>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
-    else
-      hipLaunchKernelGGL(k_step_view<double>, dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
+    const bool dense = m->view_waves ? m->view_waves == 2 : n > int64_t(2) * 64 * 4 * 256;   // more than two wavefronts per SIMD of the chip
+    if (prec == ANM_SOLVE_F32) {
+      if (dense) hipLaunchKernelGGL((k_step_view<float, 2>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
+      else hipLaunchKernelGGL((k_step_view<float, 1>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
+    } else {
+      if (dense) hipLaunchKernelGGL((k_step_view<double, 2>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
+      else hipLaunchKernelGGL((k_step_view<double, 1>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, m->view);
+    }
     hipError_t ev = hipGetLastError();
     if (ev != hipSuccess) return fail_hip(ev, "launch k_step_view");
     return 0;

@@ -146,3 +146,35 @@ def test_mixed_batch_equals_each_network_on_its_own():
         o2, r2, t2, _, _ = own.step(a[rows][:, :6].contiguous())
         assert torch.equal(obs[rows][:, :18], o2) and torch.equal(r[rows], r2) and torch.equal(term[rows], t2), t
         assert torch.equal(env.nr_iters[rows], own.simulator.nr_iters)
+
+
+def test_view_step_variants_are_bit_identical(monkeypatch):
+    """k_step_view exists budgeted for one and for two wavefronts per SIMD (the launch picks by batch size; ANM_VIEW_WAVES, read
+    when the model is created, forces one): the same arithmetic -- states, observations, rewards, flags equal bit for bit
+    over 30 autoresetting steps of two ANM6 models in one batch, terminations and diverging solves included"""
+    import copy
+
+    net_b = copy.deepcopy(networks.anm6_network())
+    net_b["branch"][:, 5] *= 1.1
+    tasks = [dict(network=networks.anm6_network(), series=anm6easy_series(), costs_clipping=(1, 100)),
+             dict(network=net_b, series=anm6easy_series(), costs_clipping=(1, 100))]
+    E_ = 8192
+    envs = []
+    for v in ("1", "2"):
+        monkeypatch.setenv("ANM_VIEW_WAVES", v)
+        envs.append(MixedBatchedANMEnv(tasks, np.arange(E_) % 2, device=DEV, seed=4, tol=1e-6, autoreset=True))
+    monkeypatch.delenv("ANM_VIEW_WAVES")
+    lo, hi = envs[0]._act_low, envs[0]._act_high
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for env in envs:
+        env.check_actions = False
+        env.reset(seed=4)
+    n_term = 0
+    for t in range(30):
+        a = lo + (hi - lo) * torch.rand(lo.shape, generator=gen, dtype=torch.float64, device=DEV)
+        outs = [env.step(a) for env in envs]
+        n_term += int(outs[0][2].sum())
+        for x, y in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(x, y), t
+        assert torch.equal(envs[0].state, envs[1].state) and torch.equal(envs[0].nr_iters, envs[1].nr_iters)
+    assert n_term > 20
