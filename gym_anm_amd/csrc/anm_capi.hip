@@ -52,22 +52,27 @@ int fail_hip(hipError_t e, const char* where) {
 
 // VIEW: the launch serves the environments a batch view names (anm_model_bind_view); without one the view is a compile-time
 // identity and costs the kernels nothing
-template <class JT, bool VIEW = false>
+// START: the launch honours anm_model_bind_nr_start (an instantiation of its own, always with VIEW: see op_transition)
+template <class JT, bool VIEW = false, bool START = false>
 __global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C0, TransitionIO io, SolverOpts so, int64_t n, ClassSel cs, View v) {
-  const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
-  if (e >= n) return;
+  __shared__ double lds[Topo::TREE != 0 ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
+  const int64_t e0 = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
+  const bool valid = e0 < n;
+  const int64_t e = valid ? e0 : n - 1;
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
-  if constexpr (VIEW) op_transition<Topo, JT>(C, io, so, e, v);
-  else op_transition<Topo, JT>(C, io, so, e);
+  if constexpr (VIEW) op_transition<Topo, JT, START>(C, io, so, e, v, valid, lds);
+  else op_transition<Topo, JT>(C, io, so, e, View{}, valid, lds);
 }
 
 template <class JT, bool VIEW = false>
 __global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs, View v) {
-  const int64_t e = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
-  if (e >= n) return;
+  __shared__ double lds[Topo::TREE != 0 ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
+  const int64_t e0 = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
+  const bool valid = e0 < n;
+  const int64_t e = valid ? e0 : n - 1;
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
-  if constexpr (VIEW) op_reset<Topo, JT>(C, io, so, e, v);
-  else op_reset<Topo, JT>(C, io, so, e);
+  if constexpr (VIEW) op_reset<Topo, JT>(C, io, so, e, v, valid, lds);
+  else op_reset<Topo, JT>(C, io, so, e, View{}, valid, lds);
 }
 
 // the step of the environments a batch view names (thread-per-environment family): see op_step_view.
@@ -890,7 +895,13 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   }
   cptr_t C = (cptr_t)m->d_const;
   const bool viewed = m->has_view;
-  if (viewed) {
+  if (io.nr_start) {
+    if (prec == ANM_SOLVE_F32)
+      hipLaunchKernelGGL((k_transition<float, true, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
+    else
+      hipLaunchKernelGGL((k_transition<double, true, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
+  } else if (viewed) {
+
     if (prec == ANM_SOLVE_F32)
       hipLaunchKernelGGL((k_transition<float, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
     else

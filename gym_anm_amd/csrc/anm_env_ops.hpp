@@ -101,8 +101,13 @@ struct TransitionIO {
 
 // (slot: position in the launch; with a view -- anm_model_bind_view -- the environment is index[slot] and the rows of the
 // batch arrays have the view's strides)
-template <class T, class JT>
-ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64_t slot, const View& v = View{}) {
+template <class T, class JT, bool START = false>
+ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64_t slot, const View& v = View{}, bool valid = true,
+                          double* lds = nullptr) {
+  // valid / lds (GPU): `slot` is clamped for the lanes beyond the batch (they compute along and store nothing), and a tree
+  // topology hands the solves still running after so.handoff iterations over to lane groups inside the wavefront, like the
+  // step kernels (group::continue_in_groups, collective: hence no early return) -- 65 536 ANM6 transitions 242 -> ~100 us:
+  // the launch waits for its diverging solves, and a lane group's trip is a quarter of a thread's
   const int64_t e = v.index ? int64_t(v.index[slot]) : slot;
   const int WL = v.w_load > 0 ? v.w_load : T::NLOAD, WG = v.w_gen > 0 ? v.w_gen : T::NGEN, WS = v.w_set > 0 ? v.w_set : T::NSET;
   const int WD = v.w_des > 0 ? v.w_des : T::NDES, WF = v.w_full > 0 ? v.w_full : FullState<T>::SIZE;
@@ -116,7 +121,7 @@ ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64
     Q_set[I] = io.q_set[e * WS + I];
   });
   static_for<0, T::NDES>([&](auto I) { w.soc[I] = io.soc[e * WD + I]; });
-  if (io.nr_start) {
+  if (START && io.nr_start) {
     // the reference's solver from a given initial guess (v_guess of _newton_raphson_sparse, solve_load_flow.py:176)
     PFState<T> st;
     transition_begin<T, JT>(C, C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, -1);
@@ -131,8 +136,21 @@ ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64
     pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, so.max_iter);
     transition_end<T>(C, w, st, so.tol);
   } else {
-    transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
+    PFState<T> st;
+    int cap = so.max_iter;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (T::TREE != 0)
+      if (lds && so.handoff >= 0 && so.handoff < so.max_iter) cap = so.handoff;
+#endif
+    transition_begin<T, JT>(C, C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, cap);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (T::TREE != 0)
+      if (cap < so.max_iter && ANM_WAVE_ANY(st.active && valid))
+        group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
+#endif
+    transition_end<T>(C, w, st, so.tol);
   }
+  if (!valid) return;
   static_for<0, T::NDES>([&](auto I) { io.soc[e * WD + I] = w.soc[I]; });
   io.reward[e] = w.reward;
   io.e_loss[e] = w.e_loss;
@@ -284,14 +302,30 @@ ANM_HD int sample_series_init_state(cptr_t C, const EnvIO& io, int64_t e, uint32
 }
 
 template <class T, class JT, class S0>
-ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const S0& s0, const View& v = View{}) {
+ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, const S0& s0, const View& v = View{}, bool act = true,
+                       double* lds = nullptr) {   // act / lds: see op_transition (lanes with !act compute along and store nothing)
   const int S = v.w_state > 0 ? v.w_state : T::SDIM + io.K;        // row stride of state / obs
   const int WD = v.w_des > 0 ? v.w_des : T::NDES, WF = v.w_full > 0 ? v.w_full : FullState<T>::SIZE;
   EnvWork<T> w;
   double P_load[T::NLOAD > 0 ? T::NLOAD : 1], P_pot[T::NGEN > 0 ? T::NGEN : 1];
   double P_set[T::NSET > 0 ? T::NSET : 1], Q_set[T::NSET > 0 ? T::NSET : 1];
   inputs_from_init_state<T>(C, s0, w, P_load, P_pot, P_set, Q_set);
-  transition<T, JT>(C, w, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter);
+  {
+    PFState<T> st;
+    int cap = so.max_iter;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (T::TREE != 0)
+      if (lds && so.handoff >= 0 && so.handoff < so.max_iter) cap = so.handoff;
+#endif
+    transition_begin<T, JT>(C, C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, cap);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (T::TREE != 0)
+      if (cap < so.max_iter && ANM_WAVE_ANY(st.active && act))
+        group::continue_in_groups<T, JT>(C, w, st, st.active && act, so.tol, so.max_iter, lds);
+#endif
+    transition_end<T>(C, w, st, so.tol);
+  }
+  if (!act) return;
   RowPtrs rows{io.state + e * S, io.obs + e * S};
   finish_reset<T, Layout<T>::KMAX, S0>(C, w, s0, io.K, io.soc + e * WD, rows);
   io.converged[e] = w.converged ? 1 : 0;
@@ -304,16 +338,17 @@ ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, cons
 }
 
 template <class T, class JT>
-ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t slot, const View& v = View{}) {
+ANM_HD void op_reset(cptr_t C, const EnvIO& io, SolverOpts so, int64_t slot, const View& v = View{}, bool valid = true, double* lds = nullptr) {
   const int64_t e = v.index ? int64_t(v.index[slot]) : slot;
-  if (io.mask && !io.mask[e]) return;
+  const bool act = valid && !(io.mask && !io.mask[e]);
+  if (!ANM_WAVE_ANY(act)) return;   // (wavefront-uniform: the hand-over to lane groups inside reset_from is collective)
   if (io.init_state) {  // the row given by the caller
-    reset_from<T, JT>(C, io, so, e, io.init_state + e * (v.w_state > 0 ? v.w_state : T::SDIM + io.K), v);
+    reset_from<T, JT>(C, io, so, e, io.init_state + e * (v.w_state > 0 ? v.w_state : T::SDIM + io.K), v, act, lds);
   } else {              // device sampler (series mode, K = 1): same draws as the autoreset path, kept in registers
     double s0_drawn[T::SDIM + 1];
     sample_series_init_state<T>(C, io, e, uint32_t(io.reset_count[e]), s0_drawn);
-    io.reset_count[e] += 1;
-    reset_from<T, JT>(C, io, so, e, s0_drawn, v);
+    if (act) io.reset_count[e] += 1;
+    reset_from<T, JT>(C, io, so, e, s0_drawn, v, act, lds);
   }
 }
 

@@ -142,8 +142,8 @@ int anm_transition_f64(anm_model* m, int64_t n, const double* p_load, const doub
   int prec;
   SolverOpts so = solver(opts, prec);
   for (int64_t e = 0; e < n; ++e) {
-    if (prec == ANM_SOLVE_F32) op_transition<Topo, float>(m->c.data(), io, so, e);
-    else op_transition<Topo, double>(m->c.data(), io, so, e);
+    if (prec == ANM_SOLVE_F32) op_transition<Topo, float, true>(m->c.data(), io, so, e);
+    else op_transition<Topo, double, true>(m->c.data(), io, so, e);
   }
   return 0;
 }
