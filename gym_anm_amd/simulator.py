@@ -158,6 +158,7 @@ class BatchedSimulator:
         self.state_bounds = m.state_bounds()
         self.state = None
         self.pfe_converged = None
+        self._arg_ids = None
 
         self.backend = _backend if _backend is not None else _lib.load_for_topology(m.topology(), impl)
         self.device = torch.device(device)
@@ -308,6 +309,9 @@ class BatchedSimulator:
     def _as_batch(self, x, ids, name):
         """dict {dev_id: scalar | tensor[E]} or tensor [E, n] -> contiguous float64 [E, n] on device."""
         n = len(ids)
+        if (isinstance(x, torch.Tensor) and x.dtype == torch.float64 and x.device == self.device and x.shape == (self.num_envs, n)
+                and x.is_contiguous()):
+            return x   # (what a training loop hands over: no torch call on the way to the launch)
         if isinstance(x, dict):
             cols = []
             for i in ids:
@@ -329,12 +333,14 @@ class BatchedSimulator:
         ``tensor[num_envs]``) or ``[num_envs, n]`` tensors ordered by ascending device id.
         Returns ``(state, reward, e_loss, penalty, pfe_converged)`` with per-environment tensors.
         """
-        m = self.model
-        ids = m.dev_ids
-        pl = self._as_batch(P_load, [ids[k] for k in m.load_idx], "P_load")
-        pp = self._as_batch(P_potential, [ids[k] for k in m.gen_idx], "P_potential")
-        ps = self._as_batch(P_set_points, [ids[k] for k in m.setp_idx], "P_set_points")
-        qs = self._as_batch(Q_set_points, [ids[k] for k in m.setp_idx], "Q_set_points")
+        if self._arg_ids is None:
+            m = self.model
+            self._arg_ids = tuple([m.dev_ids[k] for k in idx] for idx in (m.load_idx, m.gen_idx, m.setp_idx))
+        ids_load, ids_gen, ids_set = self._arg_ids
+        pl = self._as_batch(P_load, ids_load, "P_load")
+        pp = self._as_batch(P_potential, ids_gen, "P_potential")
+        ps = self._as_batch(P_set_points, ids_set, "P_set_points")
+        qs = self._as_batch(Q_set_points, ids_set, "Q_set_points")
         with self._device_ctx():
             rc = self.backend.lib.anm_transition_f64(
                 self._handle, self.num_envs, pl.data_ptr(), pp.data_ptr(), ps.data_ptr(), qs.data_ptr(),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): bash scripts/r05_profile.sh <stage> [what...]
 # kernel traces + PMC passes (one counter group per pass, kernel-trace only); summaries land in
-# gpurun_out/r05_<stage>_*.txt ready to be copied to profiles/.  what: head mpc thr c30 wg (default: head mpc thr c30)
+# gpurun_out/r05_<stage>_*.txt ready to be copied to profiles/.  what: head mpc thr c30 wg trn (default: head mpc thr c30)
 stage=$1; shift
 what="${@:-head mpc thr c30}"
 R=$GRAFT_REPO_ROOT
@@ -46,6 +46,10 @@ thr)
       ANM_PMC_KERNEL=$k python $R/scripts/pmc_summary.py $out/pmc_thr$E "throughput regime: ANM6Easy $E envs on one GPU, two-launch step; kernel $k"
     done > $R/gpurun_out/r05_${stage}_pmc_throughput_$E.txt
   done
+  ;;
+trn)
+  CMD="python $R/scripts/mesh_occupancy_bench.py anm6"
+  trace transition_anm6 "command: scripts/mesh_occupancy_bench.py anm6 (Simulator.transition, 65 536 ANM6 transitions per launch of k_transition, dump on)" $CMD
   ;;
 wg)
   for NB in 30 200; do

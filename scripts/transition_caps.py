@@ -1,0 +1,45 @@
+"""Simulator.transition (thread family, ANM6, 65 536 transitions, uniformly random inputs) by iteration cap: the slope is the cost
+of one more trip of the diverging solves.  usage: python scripts/transition_caps.py [E [cap ...]]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gym_anm_amd import networks
+from gym_anm_amd.simulator import BatchedSimulator
+
+dev = torch.device("cuda", 0)
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+for cap in ([int(a) for a in sys.argv[2:]] or (6, 8, 20, 50, 100)):
+    sim = BatchedSimulator(networks.anm6_network(), 0.25, 100, num_envs=E, device=dev, tol=1e-6, max_iter=cap)
+    m, b = sim.model, sim.model.baseMVA
+    g = torch.Generator(device=dev).manual_seed(0)
+    U = lambda lo, hi: (torch.as_tensor(lo, device=dev) + (torch.as_tensor(hi, device=dev) - torch.as_tensor(lo, device=dev))
+                        * torch.rand((E, len(lo)), generator=g, dtype=torch.float64, device=dev))
+    pl = U(m.dev_p_min[m.load_idx] * b, 0 * m.dev_p_min[m.load_idx]); pp = U(0 * m.dev_p_max[m.gen_idx], m.dev_p_max[m.gen_idx] * b)
+    ps = U(m.dev_p_min[m.setp_idx] * b, m.dev_p_max[m.setp_idx] * b); qs = U(m.dev_q_min[m.setp_idx] * b, m.dev_q_max[m.setp_idx] * b)
+    soc = U(m.dev_soc_min[m.des_idx], m.dev_soc_max[m.des_idx])
+    for _ in range(3):
+        sim.soc.copy_(soc); sim.transition(pl, pp, ps, qs)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tot = 0.0
+    for _ in range(20):
+        sim.soc.copy_(soc); torch.cuda.synchronize()
+        ev0.record(); sim.transition(pl, pp, ps, qs); ev1.record(); torch.cuda.synchronize()
+        tot += ev0.elapsed_time(ev1)
+    # the same launch without the electrical-state dump (the C entry point takes full = NULL): what the dump costs
+    import ctypes as C
+    from gym_anm_amd.simulator import _stream_ptr
+    def raw(full_ptr):
+        with sim._device_ctx():
+            return sim.backend.lib.anm_transition_f64(sim._handle, E, pl.data_ptr(), pp.data_ptr(), ps.data_ptr(), qs.data_ptr(), sim.soc.data_ptr(),
+                                                      full_ptr, sim.reward.data_ptr(), sim.e_loss.data_ptr(), sim.penalty.data_ptr(),
+                                                      sim._conv_u8.data_ptr(), sim.nr_iters.data_ptr(), C.byref(sim.opts), _stream_ptr(sim.device))
+    res = []
+    for ptr in (sim.full.data_ptr(), None):
+        t2 = 0.0
+        for _ in range(20):
+            sim.soc.copy_(soc); torch.cuda.synchronize()
+            ev0.record(); raw(ptr); ev1.record(); torch.cuda.synchronize()
+            t2 += ev0.elapsed_time(ev1)
+        res.append(t2 / 20 * 1e3)
+    print("E %d cap %3d: %.1f us per launch (events around Simulator.transition); kernel alone %.1f us with the dump (%d doubles per transition), %.1f us without"
+          % (E, cap, tot / 20 * 1e3, res[0], sim.full_dim, res[1]), flush=True)
