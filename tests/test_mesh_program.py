@@ -28,7 +28,17 @@ def checker():
                        check=True, capture_output=True)
     h = C.CDLL(lib)
     h.mesh_program_check.argtypes = [C.POINTER(_lib.NetworkDesc), C.c_uint64, C.POINTER(C.c_double)] + [C.POINTER(C.c_int32)] * 3
+    h.mesh_plan_stats.argtypes = [C.POINTER(_lib.NetworkDesc), C.POINTER(C.c_int64)]
     return h
+
+
+def _launch(checker, net):
+    """mesh::launch_of of the network's plan: (group, steps, LDS doubles per environment, wavefronts per workgroup, LDS bytes per
+    workgroup, wavefronts per compute unit, wavefronts per SIMD of the kernel variant, tables staged in LDS)"""
+    desc, keep = _lib.network_desc(NetworkModel(net, 0.25, 100))
+    out = (C.c_int64 * 8)()
+    assert checker.mesh_plan_stats(C.byref(desc), out) == 0
+    return tuple(out)
 
 
 def _check(checker, net, seed):
@@ -94,3 +104,30 @@ def test_structured_topologies(checker, shape):
     for seed in range(3):
         steps, levels, group = _check(checker, net, 100 + seed)
         assert steps <= 3 * levels + 6
+
+
+def test_launch_variant_by_plan(checker, monkeypatch):
+    """mesh::launch_of: the kernel variant budgeted for three wavefronts per SIMD where the LDS of a compute unit holds twelve
+    wavefronts of the plan (groups of >= 16 lanes), the tables left in global memory where their LDS copy costs wavefronts, two
+    wavefronts per SIMD and staged tables otherwise -- and never more LDS than a compute unit has (measured choices:
+    profiles/r05_i_mesh_occupancy.txt, r05_j_mesh_tables.txt)"""
+    for var in ("ANM_MESH_SIMD_WAVES", "ANM_MESH_TABLES", "ANM_MESH_WAVES"):
+        monkeypatch.delenv(var, raising=False)
+    want = {"anm6": (networks.anm6_network(), 2, 1), "mesh20": (networks.synthetic_meshed_network(20, 3, 6), 3, 1),
+            "mesh30": (networks.synthetic_meshed_network(30, 6, 4), 2, 1), "case30": (networks.synthetic_radial_network(30, 0), 2, 1),
+            "mesh64": (networks.synthetic_meshed_network(64, 9, 20), 2, 0), "mesh200": (networks.synthetic_meshed_network(200, 13, 30), 2, 0)}
+    for name, (net, simd_waves, tables) in want.items():
+        g, steps, lds_env, waves, lds_block, per_cu, sw, tl = _launch(checker, net)
+        assert (sw, tl) == (simd_waves, tables), name
+        assert lds_block <= 160 * 1024 and 1 <= waves <= 4 and per_cu >= waves and per_cu <= 4 * sw, name
+        if sw == 3:
+            assert per_cu == 12 and g >= 16, name
+    # the switches override the choice (read when a model is created)
+    monkeypatch.setenv("ANM_MESH_SIMD_WAVES", "2")
+    assert _launch(checker, want["mesh20"][0])[6] == 2
+    monkeypatch.delenv("ANM_MESH_SIMD_WAVES")
+    monkeypatch.setenv("ANM_MESH_TABLES", "global")
+    g, steps, lds_env, waves, lds_block, per_cu, sw, tl = _launch(checker, want["mesh20"][0])
+    assert (sw, tl) == (2, 0)
+    monkeypatch.setenv("ANM_MESH_TABLES", "lds")
+    assert _launch(checker, want["mesh64"][0])[7] == 1
