@@ -404,7 +404,7 @@ class BatchedANMEnv(GymEnv):
         access: rows the kernel did not write because they equal the observation are taken from it."""
         if self._state_same is None:
             return self._state_buf
-        return torch.where(self._state_same.bool().unsqueeze(1), self._state_obs, self._state_buf)
+        return torch.where(self._state_same.view(torch.bool).unsqueeze(1), self._state_obs, self._state_buf)
 
     @property
     def terminated(self):
@@ -441,11 +441,11 @@ class BatchedANMEnv(GymEnv):
         self._after_step = False
         # convergence per environment: the environments this reset touched report the reset's power flow, the others
         # keep what their last step left (not terminated <=> converged, anm_env.py:421)
-        conv = self._conv_u8.bool()
+        conv = torch.ne(self._conv_u8, 0)
         if mask_u8 is None:
             self._conv_bool = conv
         else:
-            self._conv_bool = torch.where(mask_u8.bool(), conv, self.pfe_converged)
+            self._conv_bool = torch.where(mask_u8.ne(0), conv, self.pfe_converged)
         self._conv_stale = False
         if self._need_full_reset or self._need_full:
             sim.state = StateView(sim, sim.full)
@@ -492,9 +492,9 @@ class BatchedANMEnv(GymEnv):
                 )
         if given is not None:
             # an explicit initial state that does not converge leaves that environment terminated
-            sel = todo.bool()
+            sel = todo.ne(0)
             self._term_u8[sel] = 1
-        touched = mask_u8.bool() if mask_u8 is not None else slice(None)
+        touched = mask_u8.ne(0) if mask_u8 is not None else slice(None)
         self.e_loss[touched] = 0.0
         self.penalty[touched] = 0.0
         obs = self.observation(self.state)
@@ -516,7 +516,7 @@ class BatchedANMEnv(GymEnv):
             todo = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
         else:
             todo = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
-        touched = todo.bool()
+        touched = todo.ne(0)
         for attempt in range(100):
             self._launch_reset(None, todo)
             todo = todo * (1 - self._conv_u8)

@@ -166,7 +166,7 @@ class MixedBatchedANMEnv:
         mask = (options or {}).get("mask")
         todo = (torch.ones(self.num_envs, dtype=torch.uint8, device=self.device) if mask is None
                 else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous())
-        touched = todo.bool()
+        touched = todo.ne(0)
         for _ in range(100):
             self._launch_reset(todo)
             todo = todo * (1 - self._conv_u8)

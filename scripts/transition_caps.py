@@ -41,5 +41,11 @@ for cap in ([int(a) for a in sys.argv[2:]] or (6, 8, 20, 50, 100)):
             ev0.record(); raw(ptr); ev1.record(); torch.cuda.synchronize()
             t2 += ev0.elapsed_time(ev1)
         res.append(t2 / 20 * 1e3)
+    tot2 = 0.0   # the Python call once more, AFTER the others: the first loop of a process runs at lower clocks
+    for _ in range(20):
+        sim.soc.copy_(soc); torch.cuda.synchronize()
+        ev0.record(); sim.transition(pl, pp, ps, qs); ev1.record(); torch.cuda.synchronize()
+        tot2 += ev0.elapsed_time(ev1)
+    print("E %d cap %3d: Simulator.transition again, after the others: %.1f us" % (E, cap, tot2 / 20 * 1e3))
     print("E %d cap %3d: %.1f us per launch (events around Simulator.transition); kernel alone %.1f us with the dump (%d doubles per transition), %.1f us without"
           % (E, cap, tot / 20 * 1e3, res[0], sim.full_dim, res[1]), flush=True)
