@@ -32,6 +32,21 @@ from ..spaces import Box
 from .anm_env import BatchedANMEnv
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    """Three side streams per device, made ONCE per process and shared by every mixed batch.  A device serves its streams from
+    four hardware queues (ROCm's default), handed out in creation order: with the current stream that is one queue per launch
+    of a four-topology step.  Streams made per object land on queues already in use as soon as a process builds a few objects,
+    and two launches on one queue run one after the other (measured: the same batch 164 us per step with the first three
+    streams of the process, 220-250 us with later ones, 236-246 us on one stream; profiles/r05_n_mixed_streams.txt)."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
+    return _SIDE_STREAMS[key]
+
+
 class _Task(BatchedANMEnv):
     """One network of the mix as a one-environment ``BatchedANMEnv``: spec validation, the model with its task constants
     (``anm_model_set_env``: observation Box, clipping, series), the spaces.  It is never stepped itself."""
@@ -119,38 +134,55 @@ class MixedBatchedANMEnv:
         self.single_action_spaces = [t.action_space for t in self.tasks]
         self._act_low, self._act_high = torch.as_tensor(alo, **f64), torch.as_tensor(ahi, **f64)
         self.check_actions = True
-        self._streams = [torch.cuda.Stream(device=dev) for _ in self.tasks] if (streams and len(self.tasks) > 1) else None
+        self._live = [k for k in range(len(self.tasks)) if self.env_index[k].numel()]
+        self._streams = _side_streams(dev)[: len(self.tasks) - 1] if (streams and len(self.tasks) > 1) else None
+        if self._streams is not None:
+            self._stream_ptrs = [C.c_void_p(s.cuda_stream) for s in self._streams]
+            self._fork, self._done = torch.cuda.Event(), [torch.cuda.Event() for _ in self._streams]
+        self._step_calls = None
 
     # ------------------------------------------------------------------------------------------------------------
     def _fan_out(self, launch):
-        """``launch(k, stream_ptr)`` for every task with environments: on the tasks' own streams (forked from and joined
-        back into torch's current stream), or one after the other on the current stream."""
+        """``launch(k, stream_ptr)`` for every task with environments: spread over torch's current stream and the side streams
+        (forked from and joined back into the current stream), or one after the other on the current stream.
+        (Host time matters here: four launches with their events took longer to ISSUE than the longest kernel runs -- the
+        events and stream handles are made once, the device context is entered once per call.)"""
         cur = torch.cuda.current_stream(self.device)
-        if self._streams is None:
-            for k in range(len(self.tasks)):
-                if self.env_index[k].numel():
-                    launch(k, _stream_ptr(self.device))
-            return
-        fork = torch.cuda.Event()
-        fork.record(cur)
-        for k, s in enumerate(self._streams):
-            if not self.env_index[k].numel():
-                continue
-            s.wait_event(fork)
-            launch(k, C.c_void_p(s.cuda_stream))
-            done = torch.cuda.Event()
-            done.record(s)
-            cur.wait_event(done)
+        live = self._live
+        with torch.cuda.device(self.device):
+            if self._streams is None or len(live) < 2:
+                ptr = _stream_ptr(self.device)
+                for k in live:
+                    launch(k, ptr)
+                return
+            # Task j of the live ones -> slot j mod (side streams + 1); slot 0 is the current stream itself.  No more than three
+            # side streams: a device serves its streams from four hardware queues (ROCm's default), and two streams that share a
+            # queue run their kernels one after the other.
+            n_slots = len(self._streams) + 1
+            self._fork.record(cur)
+            for i, s in enumerate(self._streams):
+                mine = live[i + 1 :: n_slots]
+                if not mine:
+                    continue
+                s.wait_event(self._fork)
+                for k in mine:
+                    launch(k, self._stream_ptrs[i])
+                self._done[i].record(s)
+            ptr = _stream_ptr(self.device)
+            for k in live[0::n_slots]:
+                launch(k, ptr)
+            for i in range(len(self._streams)):
+                if live[i + 1 :: n_slots]:
+                    cur.wait_event(self._done[i])
 
     def _launch_reset(self, mask_u8):
         def go(k, stream):
             sim = self.tasks[k].simulator
-            with sim._device_ctx():
-                rc = sim.backend.lib.anm_reset_f64(
-                    sim._handle, int(self.env_index[k].numel()), None, mask_u8.data_ptr(), self.rng_seed, self.env_offset,
-                    self._reset_count.data_ptr(), self.soc.data_ptr(), self.state.data_ptr(), self._obs.data_ptr(),
-                    self._conv_u8.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(), self.nr_iters.data_ptr(), None, None,
-                    C.byref(sim.opts), stream)  # fmt: skip
+            rc = sim.backend.lib.anm_reset_f64(
+                sim._handle, int(self.env_index[k].numel()), None, mask_u8.data_ptr(), self.rng_seed, self.env_offset,
+                self._reset_count.data_ptr(), self.soc.data_ptr(), self.state.data_ptr(), self._obs.data_ptr(),
+                self._conv_u8.data_ptr(), self._term_u8.data_ptr(), self.timestep.data_ptr(), self.nr_iters.data_ptr(), None, None,
+                C.byref(sim.opts), stream)  # fmt: skip
             sim.backend.check(rc, "anm_reset_f64")
 
         self._fan_out(go)
@@ -191,15 +223,23 @@ class MixedBatchedANMEnv:
             assert ok, "Action outside the action space of its environment."
         action = action.contiguous()
 
-        def go(k, stream):
-            sim = self.tasks[k].simulator
-            with sim._device_ctx():
-                rc = sim.backend.lib.anm_step_f64(
-                    sim._handle, int(self.env_index[k].numel()), action.data_ptr(), None, None, self.soc.data_ptr(), self.state.data_ptr(),
+        if self._step_calls is None:   # everything but the action pointer, the seed and the stream is the same at every step
+            self._step_calls = []
+            for k, t in enumerate(self.tasks):
+                sim = t.simulator
+                self._step_calls.append((sim, sim.backend.lib.anm_step_f64, [
+                    sim._handle, int(self.env_index[k].numel()), 0, None, None, self.soc.data_ptr(), self.state.data_ptr(),
                     self._term_u8.data_ptr(), self.timestep.data_ptr(), self._obs.data_ptr(), self.reward.data_ptr(), self.e_loss.data_ptr(),
-                    self.penalty.data_ptr(), self.nr_iters.data_ptr(), None, 1 if self.autoreset else 0, self.rng_seed, self.env_offset,
-                    self._reset_count.data_ptr(), None, None, C.byref(sim.opts), stream)  # fmt: skip
-            sim.backend.check(rc, "anm_step_f64")
+                    self.penalty.data_ptr(), self.nr_iters.data_ptr(), None, 1 if self.autoreset else 0, 0, self.env_offset,
+                    self._reset_count.data_ptr(), None, None, C.byref(sim.opts), None]))  # fmt: skip
+        a_ptr, seed, auto = action.data_ptr(), self.rng_seed, 1 if self.autoreset else 0
+
+        def go(k, stream):
+            sim, fn, args = self._step_calls[k]
+            args[2], args[15], args[16], args[22] = a_ptr, auto, seed, stream
+            rc = fn(*args)
+            if rc != 0:
+                sim.backend.check(rc, "anm_step_f64")
 
         self._fan_out(go)
         return self._obs, self.reward, self.terminated, self._truncated, {}
