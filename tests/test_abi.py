@@ -169,3 +169,21 @@ def test_register_budgets_of_the_occupancy_critical_kernels():
             assert hits, sub_
             for n, (vg, sc) in hits:
                 assert vg <= vmax and sc <= smax, "%s: %d VGPRs, %d B scratch (budget %d / %d)" % (n[:90], vg, sc, vmax, smax)
+
+
+def test_mixed_batch_slot_plan():
+    """envs/mixed.py: plan_slots -- which launches of a mixed step share a stream, from the time each takes alone (a fork / join
+    pair costs ~20 us per side stream): the longest alone on the current stream, the others packed behind each other as long
+    as they stay inside it, never more slots than hardware queues"""
+    from gym_anm_amd.envs.mixed import plan_slots
+
+    assert plan_slots([87, 72, 48, 37]) == [[0], [1], [2, 3]]
+    assert plan_slots([87.0, 87.0]) == [[0], [1]]
+    assert plan_slots([500, 480, 470, 30, 20, 10]) == [[0, 5], [1, 4], [2, 3]]
+    slots = plan_slots([50, 40, 30, 20, 10], max_slots=2)
+    assert len(slots) == 2 and sorted(i for s in slots for i in s) == [0, 1, 2, 3, 4] and slots[0][0] == 0
+    assert plan_slots([10]) == [[0]] and plan_slots([]) == [[]]
+    for n in range(1, 9):   # every launch exactly once, at most four slots, slot 0 starts with the longest
+        d = [((7 * i) % 11 + 1) * 10.0 for i in range(n)]
+        slots = plan_slots(d)
+        assert len(slots) <= 4 and sorted(i for s in slots for i in s) == list(range(n)) and d[slots[0][0]] == max(d)
