@@ -95,7 +95,9 @@ class MixedBatchedANMEnv:
     in any order.
 
     ``reset(seed=...)`` / ``step(action)`` follow ``gymnasium.vector`` semantics with next-step autoreset, like
-    ``BatchedANMEnv``.  ``observation_space`` / ``action_space`` are per-environment padded Boxes (``[E, W]`` bounds; the
+    ``BatchedANMEnv``.  With ``streams=True`` the first two steps of an object's life run the launches one after the other and
+    time them (one synchronize each; ``launch_us`` keeps the result), from the third step on the launches are packed into
+    streams by ``plan_slots`` -- capture a step into a HIP graph only after that.  ``observation_space`` / ``action_space`` are per-environment padded Boxes (``[E, W]`` bounds; the
     padding columns are ``[0, 0]``); ``single_observation_spaces[k]`` / ``single_action_spaces[k]`` are those of task k."""
 
     def __init__(self, tasks, env_task, device="cuda", seed=None, tol=1e-5, max_iter=100, precision="f64", autoreset=False,
