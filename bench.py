@@ -459,6 +459,24 @@ def self_launch(n, script=None, argv=None):
     return subprocess.call(cmd, env=env)
 
 
+def preflight_devices(n, visible):
+    """`--gpus n` against the devices this process can see: None when it fits, else the one line to exit with BEFORE any rank
+    is spawned (a rank that cannot set its device would leave the others waiting in the rendezvous)"""
+    if n <= visible:
+        return None
+    return ("bench.py: --gpus %d but only %d GPU%s visible here (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the set): "
+            "nothing started" % (n, visible, " is" if visible == 1 else "s are"))
+
+
+def rendezvous_timeout_s():
+    """how long a rank waits for the others in init_process_group before it gives up with a message instead of hanging
+    (ANM_BENCH_RDZV_TIMEOUT seconds; default 180: a fresh box can take two minutes over its first `import torch`)"""
+    try:
+        return max(1.0, float(os.environ.get("ANM_BENCH_RDZV_TIMEOUT", "180")))
+    except ValueError:
+        return 180.0
+
+
 def shard(args, world, rank):
     """environments of this rank, global index of its first one, scaling mode"""
     if args.global_envs:
@@ -477,9 +495,17 @@ class Comm:
         if world > 1 or launched:
             import torch.distributed as dist
 
+            import datetime
+
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             kw = {"device_id": device} if device.type == "cuda" else {}
-            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            t_out = rendezvous_timeout_s()
+            try:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=t_out), **kw)
+            except Exception as ex:  # a peer that never arrived (it could not set its device, or was never started)
+                raise SystemExit("bench.py rank %d/%d: the rendezvous on %s:%s did not complete within %.0f s (%s: %s) -- a peer "
+                                 "rank is missing; nothing was measured" % (rank, world, os.environ.get("MASTER_ADDR"),
+                                                                            os.environ.get("MASTER_PORT"), t_out, type(ex).__name__, str(ex)[:200]))
             self.dist = dist
             # the communicator really spans `world` ranks: one all-reduce of ones must come back as the world size
             self.ranks_seen = int(round(self.reduce([1.0], "sum")[0]))
@@ -538,16 +564,30 @@ def main(argv=None, make_env=None, backend="nccl", device_type="cuda", script=No
     the benchmark itself never does (no flag selects them)."""
     args = parse_args(argv)
     rank, local_rank, world, launched = rank_info()
+    gpu = device_type == "cuda"
     if not launched and args.gpus > 1:
         # typed as `python bench.py --gpus N`: start one rank per GPU and let rank 0 print the line
+        if gpu:
+            msg = preflight_devices(args.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+            if msg:
+                raise SystemExit(msg)
         raise SystemExit(self_launch(args.gpus, script, argv))
     if world != args.gpus:
         args.gpus = world
-    gpu = device_type == "cuda"
     if gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the simulator has no CPU path")
     if gpu:
-        torch.cuda.set_device(local_rank)
+        # a rank without a device of its own leaves with one line; its peers then time out of the rendezvous (Comm) instead
+        # of waiting for it for ever (under torch.distributed.run the agent ends them at once)
+        n_vis = torch.cuda.device_count()
+        if local_rank >= n_vis:
+            raise SystemExit("bench.py rank %d: LOCAL_RANK %d but %d GPU%s visible to this process; this rank leaves before the "
+                             "rendezvous" % (rank, local_rank, n_vis, " is" if n_vis == 1 else "s are"))
+        try:
+            torch.cuda.set_device(local_rank)
+        except Exception as ex:
+            raise SystemExit("bench.py rank %d: torch.cuda.set_device(%d) failed (%s); this rank leaves before the rendezvous"
+                             % (rank, local_rank, str(ex)[:200]))
     dev = torch.device("cuda", local_rank) if gpu else torch.device("cpu")
     comm = Comm(backend, rank, world, dev, launched)
     rccl_ranks = comm.ranks_seen

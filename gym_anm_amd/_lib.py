@@ -103,6 +103,7 @@ ABI = {
     "anm_transition_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 11 + [C.POINTER(SolverOpts), _P]),
     "anm_reset_f64": (C.c_int, [C.c_void_p, C.c_int64, _P, _P, C.c_uint64, C.c_uint64] + [_P] * 10
                       + [C.POINTER(SolverOpts), _P]),
+    "anm_sample_init_state_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "anm_step_f64": (C.c_int, [C.c_void_p, C.c_int64] + [_P] * 13 + [C.c_int32, C.c_uint64, C.c_uint64, _P, _P,
                                                                       C.POINTER(StepWs), C.POINTER(SolverOpts), _P]),
     "anm_model_set_classes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(NetworkDesc))]),

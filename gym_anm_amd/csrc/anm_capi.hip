@@ -1,11 +1,13 @@
 // anm_capi.hip -- gfx950 kernels + the C ABI of include/anm_mi355x.h for ONE network topology
 // (the descriptor header is injected with -DANM_TOPO_HEADER=...; see gym_anm_amd/codegen.py).
 //
-// Launch shape: one thread per environment, 64-thread workgroups (one wavefront each) so that a
-// divergent Newton-Raphson straggler only ever holds back the 63 other environments of its own
-// wave and workgroups spread round-robin over the 8 XCDs; no LDS, no inter-workgroup traffic.
-// HBM traffic per environment step is the action row in and the obs/reward rows out (~250 B for
-// ANM6Easy); the network constants are wave-uniform scalar loads that stay in the scalar cache.
+// Launch shapes: 64-thread workgroups = one wavefront each (the general family: up to 512 lanes per environment above 65
+// buses), so that a diverging Newton-Raphson solve only ever holds back the other environments of its own wavefront and
+// workgroups spread round-robin over the 8 XCDs; no inter-workgroup traffic.  Thread family: one thread per environment,
+// LDS for the coalesced row transposes and the in-wave hand-over slots; lane-group families: one environment per group of
+// lanes, hand-overs and Jacobian blocks in LDS.  HBM traffic per environment step is the action row in and the obs /
+// reward rows out (~250 B for ANM6Easy); the network constants are wave-uniform scalar loads that stay in the scalar cache
+// (thread family) or per-lane tables (lane groups).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -128,6 +130,53 @@ __global__ void k_gather_obs(int64_t n, int full_dim, const double* __restrict__
   }
 }
 
+// ANM6Easy.init_state (anm6_easy.py:25-52) for any series-mode task, the draws alone: one thread per environment, table-driven
+// (tab[d] = type, slot, q_min, q_max, soc_min, soc_max of device d), the very expressions of the samplers inside the reset /
+// step kernels (sample_series_init_state, anm_radial.hpp, anm_mesh.hpp) -- tests/test_gpu_sampler.py holds them to it bit for
+// bit.  raw (nullable): the Philox words behind the row, blocks 0 .. n_blocks - 1 of key (seed, env_offset + e, epoch).
+__global__ void k_sample_init_state(int64_t n, int nd, int nload, int ngen, int ndes, const double* __restrict__ tab,
+                                    const double* __restrict__ series, int period, uint64_t seed, uint64_t env_offset,
+                                    const int32_t* __restrict__ reset_count, double* __restrict__ out, uint32_t* __restrict__ raw,
+                                    int n_blocks) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int W = 2 * nd + ndes + ngen + 1;
+  const uint32_t epoch = reset_count ? uint32_t(reset_count[e]) : 0u;
+  uint32_t r[4];
+  Philox::generate(seed, env_offset + uint64_t(e), epoch, 0u, r);
+  const int aux = int((uint64_t(r[0]) * uint64_t(period)) >> 32);
+  double* s0 = out + e * W;
+  for (int k = 0; k < W; ++k) s0[k] = 0.0;
+  s0[W - 1] = double(aux);
+  for (int d = 0; d < nd; ++d) {
+    const double* t = tab + 6 * d;
+    const int typ = int(t[0]), slot = int(t[1]);
+    if (typ == DEV_LOAD) {
+      s0[d] = series[slot * period + aux];
+    } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE || typ == DEV_STORAGE) {
+      const bool des = typ == DEV_STORAGE;
+      const int u = des ? ngen + slot : slot;
+      uint32_t q[4];
+      Philox::generate(seed, env_offset + uint64_t(e), epoch, 1u + u / 2, q);
+      const double uu = Philox::u01(q[2 * (u % 2)], q[2 * (u % 2) + 1]);
+      if (des) {
+        s0[2 * nd + slot] = t[4] + (t[5] - t[4]) * uu;
+      } else {
+        const double pm = series[(nload + slot) * period + aux];
+        s0[d] = pm;
+        s0[2 * nd + ndes + slot] = pm;
+        s0[nd + d] = t[2] + (t[3] - t[2]) * uu;
+      }
+    }
+  }
+  if (raw)
+    for (int b = 0; b < n_blocks; ++b) {
+      uint32_t q[4];
+      Philox::generate(seed, env_offset + uint64_t(e), epoch, uint32_t(b), q);
+      for (int k = 0; k < 4; ++k) raw[(e * n_blocks + b) * 4 + k] = q[k];
+    }
+}
+
 }  // namespace
 
 struct anm_model {
@@ -169,6 +218,8 @@ struct anm_model {
   double* d_nr_diff = nullptr;                // caller's device array [num_envs] (anm_model_bind_nr_diff)
   const double* d_nr_start = nullptr;         // caller's device array [num_envs, 2 (n_bus - 1)] (anm_model_bind_nr_start)
   int32_t* d_zero = nullptr;                  // one zero: the class of every environment when no classes are bound
+  double* d_samp = nullptr;                   // [n_dev][6] sampler table (anm_sample_init_state_f64)
+  int s_nd = 0, s_nload = 0, s_ngen = 0, s_ndes = 0;
   std::vector<cplx> ybus;
 };
 
@@ -410,6 +461,23 @@ int anm_model_create(const anm_network_desc* desc, anm_model** out) {
   int rc = upload_const(m);
   if (rc == 0 && (hipMalloc(&m->d_zero, sizeof(int32_t)) != hipSuccess || hipMemset(m->d_zero, 0, sizeof(int32_t)) != hipSuccess))
     rc = fail("hipMalloc(class selector)");
+  if (rc == 0) {   // table of the stand-alone sampler (class 0)
+    std::vector<double> tab(size_t(6) * desc->n_dev, 0.0);
+    m->s_nd = desc->n_dev;
+    for (int k = 0; k < desc->n_dev; ++k) {
+      const int t = desc->dev_type[k];
+      int slot = -1;
+      if (t == DEV_LOAD) slot = m->s_nload++;
+      else if (t == DEV_CLASSICAL || t == DEV_RENEWABLE) slot = m->s_ngen++;
+      else if (t == DEV_STORAGE) slot = m->s_ndes++;
+      double* o = &tab[6 * size_t(k)];
+      o[0] = t; o[1] = slot; o[2] = desc->dev_qmin[k]; o[3] = desc->dev_qmax[k];
+      o[4] = t == DEV_STORAGE ? desc->dev_soc_min[k] : 0.0; o[5] = t == DEV_STORAGE ? desc->dev_soc_max[k] : 0.0;
+    }
+    if (hipMalloc(&m->d_samp, tab.size() * sizeof(double) + 8) != hipSuccess ||
+        hipMemcpy(m->d_samp, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail("hipMalloc(sampler table)");
+  }
   if (rc) {
     anm_model_destroy(m);
     return rc;
@@ -427,6 +495,7 @@ void anm_model_destroy(anm_model* m) {
   if (m->d_mi) hipFree(m->d_mi);
   if (m->d_md) hipFree(m->d_md);
   if (m->d_zero) hipFree(m->d_zero);
+  if (m->d_samp) hipFree(m->d_samp);
   if (m->d_obs_index) hipFree(m->d_obs_index);
   if (m->d_obs_tab) hipFree(m->d_obs_tab);
   delete m;
@@ -642,7 +711,19 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
     if (m->impl_unbound >= 0) m->impl = m->impl_unbound;
     m->impl_unbound = -1;
   };
+  // Lifting a binding (or rebinding in aligned blocks) takes the model back to the family the binding displaced.  A
+  // list-form observation set meanwhile has the tables of the lane-group family it was set in (identity layout, no row
+  // stride): the thread-per-environment kernels would gather from overlapping LDS rows.  Refused, like the forward
+  // direction below and anm_model_set_impl.
+  auto restore_refused = [&]() {
+    return m->n_obs > 0 && m->impl_unbound >= 0 && m->impl_unbound != m->impl;
+  };
+  const char* const restore_msg =
+      "anm_model_bind_env_classes: lifting this binding moves the model back to the kernel family it displaced, and the "
+      "list-form observation that is set (anm_model_set_obs) has the tables of the current family: clear it first "
+      "(n_obs = 0) and set it again afterwards";
   if (!env_class) {
+    if (restore_refused()) return fail(restore_msg);
     m->d_env_class = nullptr;
     m->class_per_env = false;
     restore_impl();
@@ -673,6 +754,7 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
     return fail("anm_model_bind_env_classes: classes that change inside blocks of 64 environments move the model to a lane-group "
                 "kernel, and the list-form observation that is set (anm_model_set_obs) has the tables of the thread-per-environment "
                 "kernel: clear it first (n_obs = 0) and set it again after binding, or bind the classes in aligned blocks of 64");
+  if (blocks && restore_refused()) return fail(restore_msg);
   m->class_per_env = !blocks;
   m->d_env_class = env_class;
   if (blocks) restore_impl();
@@ -775,7 +857,8 @@ int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const d
     std::vector<int32_t> idx(2 * size_t(n_obs));
     for (int k = 0; k < n_obs; ++k) {
       const int i = index[k];
-      if (i < 0 || i >= FS + radial::KMAX) return fail("anm_model_set_obs: index out of range");
+      // (the aux slots behind the electrical state: only the K of the task are written, anm_model_set_env)
+      if (i < 0 || i >= FS + (m->env_set ? m->K : radial::KMAX)) return fail("anm_model_set_obs: index out of range");
       if (i < FS) {
         unsigned c = 0;
         while (c + 1 < FC_COUNT && base[c + 1] <= i) ++c;
@@ -802,7 +885,7 @@ int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const d
   unsigned need = 0;
   for (int k = 0; k < n_obs; ++k) {
     const int i = index[k];
-    if (i < 0 || i >= FS + Layout<Topo>::KMAX) return fail("anm_model_set_obs: index out of range");
+    if (i < 0 || i >= FS + (m->env_set ? m->K : Layout<Topo>::KMAX)) return fail("anm_model_set_obs: index out of range");
     if (i < FS) {
       unsigned c = 0;
       while (c + 1 < FC_COUNT && full_class_base<Topo>(c + 1) <= i) ++c;
@@ -966,6 +1049,22 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
     hipLaunchKernelGGL((k_reset<double, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, C, io, so, n, class_sel(m, false), m->view);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "launch k_reset");
+  return 0;
+}
+
+int anm_sample_init_state_f64(anm_model* m, int64_t n, uint64_t rng_seed, uint64_t env_offset, const int32_t* reset_count,
+                              double* init_state, uint32_t* raw, void* stream) {
+  if (!m || !init_state) return fail("anm_sample_init_state_f64: null argument");
+  if (!m->env_set || m->period <= 0 || m->K != 1 || !m->d_series)
+    return fail("anm_sample_init_state_f64: the model needs a series-mode task (anm_model_set_env with series, K = 1)");
+  if (m->d_env_class) return fail("anm_sample_init_state_f64: not while parameter classes are bound (the table is class 0's)");
+  if (n <= 0) return 0;
+  const int n_blocks = 1 + (m->s_ngen + m->s_ndes + 1) / 2;
+  hipLaunchKernelGGL(k_sample_init_state, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                     m->s_nd, m->s_nload, m->s_ngen, m->s_ndes, m->d_samp, m->d_series, m->period, rng_seed, env_offset,
+                     reset_count, init_state, raw, n_blocks);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "launch k_sample_init_state");
   return 0;
 }
 

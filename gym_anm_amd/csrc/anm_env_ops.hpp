@@ -317,7 +317,9 @@ ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, cons
     if constexpr (T::TREE != 0)
       if (lds && so.handoff >= 0 && so.handoff < so.max_iter) cap = so.handoff;
 #endif
-    transition_begin<T, JT>(C, C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, cap);
+    // (a lane that stores nothing -- masked out of a partial reset, or beyond the batch -- evaluates F once and iterates
+    // no further: a redraw round of ANMEnv.reset must not wait for 63 solves nobody asked for)
+    transition_begin<T, JT>(C, C, w, st, P_load, P_pot, P_set, Q_set, so.tol, so.max_iter, act ? cap : 0);
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (T::TREE != 0)
       if (cap < so.max_iter && ANM_WAVE_ANY(st.active && act))

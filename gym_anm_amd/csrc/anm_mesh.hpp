@@ -682,7 +682,10 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 // PG: see k_radial; WG: the environment is the workgroup; SW: wavefronts per SIMD the registers are budgeted for; TL: the tables
 // are staged in LDS (Launch)
 template <class JT, bool PG = false, bool WG = false, int SW = 2, bool TL = !WG>
-__global__ __launch_bounds__(WG ? 512 : 256, SW) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,
+#ifndef ANM_MESH_MINWAVES2
+#define ANM_MESH_MINWAVES2 2   // tuning switch: the waves-per-SIMD hint of the SW = 2 variants (1: none, what round 4 compiled)
+#endif
+__global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,
                                                               radial::IO io, SolverOpts so, int64_t n_env, ClassSel cls) {
   // a workgroup = 1, 2 or 4 wavefronts that share one LDS copy of the tables and otherwise never meet: a lane
   // group lies within one wavefront, whose LDS operations complete in program order (fences only).

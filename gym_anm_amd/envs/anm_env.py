@@ -530,6 +530,29 @@ class BatchedANMEnv(GymEnv):
         self.penalty[touched] = 0.0
         return self.observation(self.state), {}
 
+    def sample_init_state(self, raw=False):
+        """The initial states ``reset(options={"sampler": "device"})`` / the autoreset would draw NOW for every
+        environment -- ``ANM6Easy.init_state`` (anm6_easy.py:25-52) generalised to the series-mode task, keyed by
+        ``(seed, env_offset + env, reset_count[env])`` -- without resetting anything: ``[num_envs, state_N]`` in the
+        layout ``reset(options={"init_state": ...})`` takes.  ``raw=True``: also the Philox words behind each row
+        (``int64 [num_envs, blocks, 4]`` holding uint32 values; anm_sample_init_state_f64)."""
+        if self._series is None:
+            raise E.EnvInitializationError("the device sampler needs a series-mode task")
+        sim = self.simulator
+        out = torch.zeros((self.num_envs, self.state_N), dtype=torch.float64, device=self.device)
+        words = None
+        if raw:
+            n_blocks = 1 + (sim.N_non_slack_gen + sim.N_des + 1) // 2
+            words = torch.zeros((self.num_envs, n_blocks, 4), dtype=torch.int32, device=self.device)
+        with sim._device_ctx():
+            rc = sim.backend.lib.anm_sample_init_state_f64(
+                sim._handle, self.num_envs, self.rng_seed, self.env_offset, self._reset_count_ptr, out.data_ptr(),
+                None if words is None else words.data_ptr(), _stream_ptr(self.device))
+        sim.backend.check(rc, "anm_sample_init_state_f64")
+        if raw:
+            return out, words.to(torch.int64) & 0xFFFFFFFF
+        return out
+
     # ---- step (anm_env.py:333-453) -----------------------------------------------------------------------------
     def _step_call(self, action_ptr, exo_ptr, aux_ptr):
         """One anm_step_f64 launch on torch's current stream (all buffer pointers are persistent)."""

@@ -170,6 +170,27 @@ int anm_reset_f64(anm_model* m, int64_t n, const double* init_state, const uint8
   return 0;
 }
 
+int anm_sample_init_state_f64(anm_model* m, int64_t n, uint64_t rng_seed, uint64_t env_offset, const int32_t* reset_count,
+                              double* init_state, uint32_t* raw, void*) {
+  if (!m->env_set || m->period <= 0 || m->K != 1) return fail("anm_sample_init_state_f64: the model needs a series-mode task");
+  EnvIO io{};
+  io.K = 1; io.series = m->series.data(); io.period = m->period; io.rng_seed = rng_seed; io.env_offset = env_offset;
+  const int n_blocks = 1 + (Topo::NGEN + Topo::NDES + 1) / 2;
+  for (int64_t e = 0; e < n; ++e) {
+    const uint32_t epoch = reset_count ? uint32_t(reset_count[e]) : 0u;
+    double s0[Topo::SDIM + 1];
+    sample_series_init_state<Topo>(m->c.data(), io, e, epoch, s0);
+    for (int k = 0; k <= Topo::SDIM; ++k) init_state[e * (Topo::SDIM + 1) + k] = s0[k];
+    if (raw)
+      for (int b = 0; b < n_blocks; ++b) {
+        uint32_t q[4];
+        Philox::generate(rng_seed, env_offset + uint64_t(e), epoch, uint32_t(b), q);
+        for (int k = 0; k < 4; ++k) raw[(e * n_blocks + b) * 4 + k] = q[k];
+      }
+  }
+  return 0;
+}
+
 int anm_step_f64(anm_model* m, int64_t n, const double* action, const double* exo, const double* aux_next,
                  double* soc, double* state, uint8_t* terminated, int32_t* timestep, double* obs, double* reward,
                  double* e_loss, double* penalty, int32_t* nr_iters, double* full, int32_t autoreset,

@@ -113,3 +113,37 @@ def test_bench_typed_with_gpus_2_starts_its_own_two_ranks():
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["scaling"] == "strong" and out["config"]["num_envs_per_gpu"] == 256 and out["config"]["global_num_envs"] == 512
+
+
+def test_more_gpus_asked_than_visible_exits_with_one_line_before_spawning():
+    """VERDICT r5 #8: `bench.py --gpus N` with fewer than N visible devices must say so and start nothing"""
+    assert bench.preflight_devices(1, 1) is None and bench.preflight_devices(8, 8) is None
+    assert "--gpus 2 but only 1 GPU is visible" in bench.preflight_devices(2, 1)
+    assert "--gpus 8 but only 0 GPUs are visible" in bench.preflight_devices(8, 0)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+        pytest.skip("a box with 64 GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=280)
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    err = [ln for ln in res.stderr.splitlines() if ln.strip()]
+    assert len(err) == 1 and "--gpus 64 but only" in err[0] and "nothing started" in err[0], res.stderr[-2000:]
+
+
+@pytest.mark.timeout(300)
+def test_a_missing_peer_does_not_hang_the_rendezvous():
+    """one rank of two whose peer never arrives (it could not set its device): init_process_group gives up after
+    ANM_BENCH_RDZV_TIMEOUT and the rank leaves with a message, it does not wait for ever"""
+    import time
+
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               ANM_BENCH_RDZV_TIMEOUT="4")
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(HERE, "bench_double.py"), "--gpus", "2", "--num-envs", "64", "--steps", "1",
+                          "--warmup", "0", "--headline-only", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=240)
+    assert res.returncode != 0
+    assert "did not complete within 4 s" in res.stderr and "a peer rank is missing" in res.stderr, res.stderr[-2000:]
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 200
