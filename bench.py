@@ -181,6 +181,50 @@ def case30_side_figure(dev, E=16384, n=20):
     return out
 
 
+def case30_envstep_figure(dev, args, E=16384, n=100):
+    """BASELINE.json config 4 on the metric's own terms (VERDICT r5 #1b): env-steps of `BatchedANMEnv.step` over the synthetic
+    30-bus radial feeder -- a series-mode task (daily tables for its loads and generators), the "state" observation, uniform
+    random actions in the action Box, in-kernel autoreset -- one launch of the tree kernel per step, with SURVEY 8(d)'s
+    algorithmic bytes per env-step: 8 (A + O + 2 (n_des + K) + 3) + 2 = 658 B for this feeder (A = 16, O = 51, n_des = 5,
+    K = 1).  The reference's cap (100) and a cap of 20."""
+    import numpy as np
+
+    from gym_anm_amd import networks
+    from gym_anm_amd.envs import BatchedANMEnv
+    from gym_anm_amd.model import NetworkModel
+
+    net = networks.synthetic_radial_network(30, 0)
+    m = NetworkModel(net, 0.25, 100)
+    period = 96
+    r, t = np.random.default_rng(3), np.arange(period) / period
+    rows = [m.dev_p_min[k] * m.baseMVA * (0.25 + 0.3 * (1 + np.sin(2 * np.pi * (t + r.uniform())))) for k in m.load_idx]
+    rows += [m.dev_p_max[k] * m.baseMVA * (0.1 + 0.45 * (1 + np.sin(2 * np.pi * (t + r.uniform())))) for k in m.gen_idx]
+    series = np.array(rows)
+    out = {}
+    for cap in (100, 20):
+        env = BatchedANMEnv(net, "state", 1, 0.25, 0.995, 100, aux_bounds=np.array([[0, period - 1]]), costs_clipping=(1, 100), seed=11,
+                            num_envs=E, device=dev, tol=args.tol, max_iter=cap, autoreset=True, series=series)
+        env.check_actions = False
+        env.reset(seed=11, options={"sampler": "device"})
+        gen = torch.Generator(device=dev).manual_seed(23)
+        lo, hi = torch.as_tensor(env.action_space.low, device=dev), torch.as_tensor(env.action_space.high, device=dev)
+        A = int(lo.numel())
+        pool = [lo + (hi - lo) * torch.rand((E, A), generator=gen, dtype=torch.float64, device=dev) for _ in range(8)]
+        wall, evs = _timed_env_steps(env, pool, n, dev)
+        nbytes = algorithmic_bytes_per_env_step(A, env.state_N, m.N_des, 1)
+        term = float(env.terminated.double().mean())
+        out["case30_envstep_16384" + ("" if cap == 100 else "_cap%d" % cap)] = {
+            "env_steps_per_s": E / wall, "us_per_step": wall * 1e6, "us_per_step_events": evs * 1e6, "impl": env.simulator.impl,
+            "lanes_per_env": env.simulator.lanes_per_env, "nr_tol": args.tol, "nr_max_iter": cap,
+            "mean_nr_iters": float(env.simulator.nr_iters.double().mean()), "collapsed_per_step": term,
+            "roofline": {"bound": "hbm", "achieved": nbytes * E / evs / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": nbytes * E / evs / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_env_step": nbytes,
+                         "note": "k_radial (mode: step), one launch per step; HIP events over %d steps; SURVEY 8(d)'s formula with "
+                                 "A = %d, O = %d, n_des = %d, K = 1" % (n, A, env.state_N, m.N_des)}}
+        del env
+    return out
+
+
 def mesh_side_figure(dev, E=16384, n=20):
     """the general lane-group family: a meshed 30-bus network inside a wavefront, a meshed 200-bus network as one
     workgroup of 256 lanes per environment (loads scaled with 40 / n_bus: the synthetic feeders carry the same load
@@ -698,7 +742,7 @@ def main(argv=None, make_env=None, backend="nccl", device_type="cuda", script=No
                    for c in (100, 20)}
         other.update(reduce_side_figure(comm, fig))
         if rank == 0 and world == 1:
-            for f in (lambda: mesh_side_figure(dev), lambda: throughput_side_figure(dev, args),
+            for f in (lambda: case30_envstep_figure(dev, args), lambda: mesh_side_figure(dev), lambda: throughput_side_figure(dev, args),
                       lambda: baseline_configs_side_figure(dev, args), lambda: mixed_side_figure(dev), lambda: mpc_side_figure(dev)):
                 try:
                     other.update(f())

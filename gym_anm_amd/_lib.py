@@ -53,7 +53,7 @@ class StepWs(C.Structure):
 
 class BatchView(C.Structure):
     _fields_ = [("env_index", C.c_void_p)] + [(k, C.c_int32) for k in ["w_load", "w_gen", "w_set", "w_des", "w_action", "w_state",
-                                                                      "w_exo", "w_aux", "w_full"]]  # fmt: skip
+                                                                      "w_exo", "w_aux", "w_full", "w_obs"]]  # fmt: skip
 
 
 class MpcDims(C.Structure):

@@ -311,6 +311,99 @@ def _dpp_plan_for_group(G, n_bus, parent, ch, maxch, buses, roots, tt):
                       plan={k: encode(v) for k, v in plan.items()})
 
 
+def hybrid_plan(n_bus, tt):
+    """Lane layout + per-level tables of the HYBRID hand-overs of the lane-group Newton trip (csrc/anm_group.hpp), for trees
+    that have no all-DPP layout (dpp_plan: a random feeder with up to five children per bus).
+
+    The elimination goes by height: a bus of height h folds the Schur complements its children published, inverts its pivot,
+    publishes its own.  Two observations cut what that costs through LDS:
+
+    * every bus of height h >= 1 has a child of height exactly h - 1 -- the one its own elimination waits for.  The buses are
+      laid out along these HEAVY edges (vertical paths top -> heavy child -> ..., consecutive lanes, never across a 16-lane
+      DPP row): the heavy child's six values then arrive by `row_shl:1` moves, no LDS round trip on the longest chain;
+    * a LIGHT child of height k < h - 1 has published long before level h: its parent folds it at level k + 1 (while it has
+      nothing else to do), so a level reads as many slots as some bus has light children of height EXACTLY h - 1 -- for the
+      30-bus feeder 2 + 1 + 1 + 2 instead of 3 + 4 + 3 + 5 -- and the level of a bus with many children no longer pays
+      for all of them at once.
+
+    Returns None when the tree is a chain-free corner case the layout cannot place (no padding lane left)."""
+    parent, height, maxch = tt["PARENT"], tt["HEIGHT"], tt["MAXCH"]
+    G, maxh = tt["GRP"], tt["MAXH"]
+    ch = [[c for c in tt["CH"][b * maxch:(b + 1) * maxch] if c > 0] for b in range(n_bus)]
+    ch[0] = []
+    size = [1] * n_bus
+    for b in sorted(range(1, n_bus), key=lambda b: height[b]):
+        for c in ch[b]:
+            size[b] += size[c]
+    # heavy child: height h - 1, largest subtree among those (ties: lowest bus)
+    heavy = [0] * n_bus
+    for b in range(1, n_bus):
+        cands = [c for c in ch[b] if height[c] == height[b] - 1]
+        if cands:
+            heavy[b] = max(cands, key=lambda c: (size[c], -c))
+    is_heavy = [False] * n_bus
+    for b in range(1, n_bus):
+        if heavy[b]:
+            is_heavy[heavy[b]] = True
+    paths = []
+    for b in range(1, n_bus):
+        if not is_heavy[b]:
+            p = [b]
+            while heavy[p[-1]]:
+                p.append(heavy[p[-1]])
+            paths.append(p)
+    # pack the paths into the 16-lane DPP rows of the group (first fit, longest first); a path that fits nowhere is cut (the
+    # child at the cut becomes a light child)
+    n_rows = max(1, G // 16)
+    row_len = min(G, 16)
+    rows = [[] for _ in range(n_rows)]
+    free = [row_len] * n_rows
+    todo = sorted(paths, key=lambda p: (-len(p), p[0]))
+    while todo:
+        p = todo.pop(0)
+        fit = [r for r in range(n_rows) if free[r] >= len(p)]
+        if fit:
+            r = fit[0]
+            rows[r].append(p)
+            free[r] -= len(p)
+            continue
+        r = max(range(n_rows), key=lambda r: free[r])
+        if free[r] == 0:
+            return None
+        k = free[r]
+        head, tail = p[:k], p[k:]
+        heavy[head[-1]] = 0
+        is_heavy[tail[0]] = False
+        rows[r].append(head)
+        free[r] = 0
+        todo.append(tail)
+        todo.sort(key=lambda p: (-len(p), p[0]))
+    if sum(free) < 1:
+        return None   # the hand-overs through LDS need one padding lane (the neutral slot)
+    pos, lane_bus = [0] * n_bus, [0] * G
+    for r in range(n_rows):
+        lane = r * row_len
+        for p in rows[r]:
+            for b in p:
+                pos[b] = lane
+                lane_bus[lane] = b
+                lane += 1
+    # light children by level: LCH[h][b] = the children of b folded at level h (height h - 1, not its DPP child)
+    lch = [[[] for _ in range(n_bus)] for _ in range(maxh + 1)]
+    for b in range(1, n_bus):
+        for c in ch[b]:
+            if c != heavy[b]:
+                lch[height[c] + 1][b].append(c)
+    nlh = [max([len(x) for x in lch[h]] + [0]) for h in range(maxh + 1)]
+    maxl = max(nlh + [1])
+    flat = []
+    for h in range(maxh + 1):
+        for b in range(n_bus):
+            flat += lch[h][b] + [-1] * (maxl - len(lch[h][b]))
+    return dict(POS=pos, LANE_BUS=lane_bus, HEAVY=heavy, NLH=nlh, MAXL=maxl, LCH=flat,
+                ALL_HEAVY=int(all(heavy[b] for b in range(1, n_bus) if height[b] >= 1)))
+
+
 def _arr(name, values, typ="int"):
     vals = list(values)
     body = ", ".join(str(int(v)) for v in vals) if vals else "0"
@@ -392,10 +485,24 @@ def emit_header(topo, name=None) -> str:
             _arr("T_NCH", tt["NCH"]), _arr("T_CH", tt["CH"]), _arr("T_NCH_H", tt["NCH_H"]),
             _arr("T_ZBB", tt["ZBB"]), _arr("T_ZBP", tt["ZBP"]), _arr("T_ZPB", tt["ZPB"]),
         ]  # fmt: skip
-        if dp is None:  # hand-overs by ds_bpermute_b32, bus b in lane b - 1
+        hy = None if (dp is not None or os.environ.get("ANM_NO_HYBRID")) else hybrid_plan(n_bus, tt)  # ANM_NO_HYBRID: tuning switch
+        if hy is not None:
+            lines += [
+                "  // hybrid hand-overs (codegen.hybrid_plan): buses laid out along their heavy edges (DPP row_shl:1 from the child of",
+                "  // height h - 1), light children through LDS slots, folded at the level right after their own",
+                "  static constexpr int T_HYB = 1, T_MAXL = %d, T_ALL_HEAVY = %d;" % (hy["MAXL"], hy["ALL_HEAVY"]),
+                _arr("T_HEAVY", hy["HEAVY"]), _arr("T_NLH", hy["NLH"]), _arr("T_LCH", hy["LCH"]),
+            ]
+        else:
+            lines += ["  static constexpr int T_HYB = 0, T_MAXL = 1, T_ALL_HEAVY = 0;", _arr("T_HEAVY", [0]), _arr("T_NLH", [0] * (tt["MAXH"] + 1)),
+                      _arr("T_LCH", [0])]
+        if dp is None:  # hand-overs by ds_bpermute_b32 / LDS slots, bus b in lane b - 1 (or the hybrid layout)
             lane_bus = [b if b < n_bus else 0 for b in range(1, tt["GRP"] + 1)]
+            pos = [0] + list(range(n_bus - 1))
+            if hy is not None:
+                lane_bus, pos = hy["LANE_BUS"], hy["POS"]
             lines += ["  static constexpr int T_DPP = 0;", _arr("T_LANE_BUS", lane_bus),
-                      _arr("T_POS", [0] + list(range(n_bus - 1)))]
+                      _arr("T_POS", pos)]
             lines += ["  static constexpr int T_PAR_N = 0;", _arr("T_PAR_CTRL", [0, 0]), _arr("T_PAR_BANK", [0, 0]),
                       _arr("T_PAR_FULL", [0, 0]),
                       _arr("T_CH_N", [0] * tt["MAXCH"]), _arr("T_CH_CTRL", [0] * (2 * tt["MAXCH"])),

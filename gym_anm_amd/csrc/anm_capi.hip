@@ -57,6 +57,7 @@ int fail_hip(hipError_t e, const char* where) {
 // START: the launch honours anm_model_bind_nr_start (an instantiation of its own, always with VIEW: see op_transition)
 template <class JT, bool VIEW = false, bool START = false>
 __global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C0, TransitionIO io, SolverOpts so, int64_t n, ClassSel cs, View v) {
+#ifndef ANM_DEV_LANE_GROUPS_ONLY   // (tuning builds of the lane-group kernels alone: minutes less to compile)
   __shared__ double lds[Topo::TREE != 0 ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
   const int64_t e0 = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
   const bool valid = e0 < n;
@@ -64,10 +65,12 @@ __global__ __launch_bounds__(BLOCK) void k_transition(cptr_t C0, TransitionIO io
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   if constexpr (VIEW) op_transition<Topo, JT, START>(C, io, so, e, v, valid, lds);
   else op_transition<Topo, JT>(C, io, so, e, View{}, valid, lds);
+#endif
 }
 
 template <class JT, bool VIEW = false>
 __global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs, View v) {
+#ifndef ANM_DEV_LANE_GROUPS_ONLY   // (tuning builds of the lane-group kernels alone: minutes less to compile)
   __shared__ double lds[Topo::TREE != 0 ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
   const int64_t e0 = int64_t(blockIdx.x) * BLOCK + threadIdx.x;
   const bool valid = e0 < n;
@@ -75,6 +78,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   if constexpr (VIEW) op_reset<Topo, JT>(C, io, so, e, v, valid, lds);
   else op_reset<Topo, JT>(C, io, so, e, View{}, valid, lds);
+#endif
 }
 
 // the step of the environments a batch view names (thread-per-environment family): see op_step_view.
@@ -83,30 +87,38 @@ __global__ __launch_bounds__(BLOCK) void k_reset(cptr_t C0, EnvIO io, SolverOpts
 // 131 072: 219 -> 223; 16 384, where the step waits for one diverging solve: 124 -> 139.  profiles/r05_k_view_step.txt)
 template <class JT, int SW>
 __global__ __launch_bounds__(BLOCK, SW) void k_step_view(cptr_t C, EnvIO io, SolverOpts so, int64_t n, View v) {
+#ifndef ANM_DEV_LANE_GROUPS_ONLY   // (tuning builds of the lane-group kernels alone: minutes less to compile)
   __shared__ double lds[Topo::TREE != 0 ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
   op_step_view<Topo, JT>(C, io, so, n, v, lds);
+#endif
 }
 
 // fast path of the step (series mode, K = 1, "state" observation): see op_step_rows
 template <class JT, bool FULL>
 __global__ __launch_bounds__(BLOCK, ANM_ROWS_WAVES) void k_step_rows(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs) {
+#ifndef ANM_DEV_LANE_GROUPS_ONLY   // (tuning builds of the lane-group kernels alone: minutes less to compile)
   __shared__ double lds[64 * (Topo::SDIM + 2)];
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   op_step_rows<Topo, JT, FULL>(C, io, so, n, lds);
+#endif
 }
 
 // general step (host next_vars, K != 1, list-form observations, `full` dump): see op_step_general
 template <class JT>
 __global__ __launch_bounds__(BLOCK) void k_step_general(cptr_t C0, EnvIO io, SolverOpts so, int64_t n, ClassSel cs) {
+#ifndef ANM_DEV_LANE_GROUPS_ONLY   // (tuning builds of the lane-group kernels alone: minutes less to compile)
   extern __shared__ double lds_dyn[];
   const cptr_t C = class_constants(C0, cs, int64_t(blockIdx.x) * BLOCK);
   op_step_general<Topo, JT>(C, io, so, n, lds_dyn);
+#endif
 }
 
 template <class JT, bool GROUPS>
 __global__ __launch_bounds__(BLOCK) void k_step_stragglers(cptr_t C, EnvIO io, SolverOpts so, int level) {
+#ifndef ANM_DEV_LANE_GROUPS_ONLY   // (tuning builds of the lane-group kernels alone: minutes less to compile)
   __shared__ double lds[GROUPS ? group::Shape<Topo>::NG * group::Slot<Topo>::SIZE : 1];
   op_step_stragglers<Topo, JT, GROUPS>(C, io, so, lds, level);
+#endif
 }
 
 __global__ void k_step_scatter(EnvIO io) { op_step_scatter<Topo>(io); }
@@ -792,7 +804,10 @@ int anm_model_bind_view(anm_model* m, const anm_batch_view* v) {
     return 0;
   }
   if (m->d_env_class) return fail("anm_model_bind_view: not together with parameter classes (anm_model_bind_env_classes)");
-  if (m->n_obs > 0) return fail("anm_model_bind_view: not together with a list-form observation (anm_model_set_obs): clear it first");
+  if (m->n_obs > 0 && m->impl == ANM_IMPL_THREAD)
+    return fail("anm_model_bind_view: the thread-per-environment family gathers no list-form observation through a view "
+                "(anm_model_set_obs): clear it, or move the model to a lane-group family first (anm_model_set_impl)");
+  if (m->n_obs > 0 && v->w_obs != 0 && v->w_obs < m->n_obs) return fail("anm_model_bind_view: w_obs is narrower than the observation list");
   if (m->d_state_same) return fail("anm_model_bind_view: not together with anm_model_bind_state_same (the flags are indexed by launch slot)");
   anm_dims d;
   anm_model_dims(m, &d);
@@ -807,7 +822,7 @@ int anm_model_bind_view(anm_model* m, const anm_batch_view* v) {
       g_err = std::string("anm_model_bind_view: ") + x.what + " is narrower than this network's own rows";
       return -1;
     }
-  m->view = radial::View{v->env_index, v->w_load, v->w_gen, v->w_set, v->w_des, v->w_action, v->w_state, v->w_exo, v->w_aux, v->w_full};
+  m->view = radial::View{v->env_index, v->w_load, v->w_gen, v->w_set, v->w_des, v->w_action, v->w_state, v->w_exo, v->w_aux, v->w_full, v->w_obs};
   m->has_view = true;
   return 0;   // (every kernel family serves a view: the model stays in the family it is in)
 }
@@ -818,7 +833,7 @@ static unsigned magic_div(int d) { return d > 0 ? unsigned((0x100000000ull + uin
 
 int anm_model_obs_fusable(const anm_model* m) {
   if (!m) return 0;
-  if (m->has_view) return 0;
+  if (m->has_view && m->impl == ANM_IMPL_THREAD) return 0;   // (its step through a view moves rows per lane: no LDS rows to gather from)
   if (m->impl == ANM_IMPL_THREAD) return (m->tpe_ok && GenLds<Topo>::FULL_OK) ? 1 : 0;
   if (m->impl == ANM_IMPL_RADIAL) return (m->radial_ok && radial_obs_lds_bytes(m) <= 48 * 1024) ? 1 : 0;
   if (m->impl == ANM_IMPL_MESH) return (m->mesh_ok && m->mplan.d.l_bw - m->mplan.d.l_blk >= m->mplan.d.FS + radial::KMAX) ? 1 : 0;
@@ -836,6 +851,7 @@ int anm_model_set_obs(anm_model* m, int32_t n_obs, const int32_t* index, const d
     return fail("anm_model_set_obs: this model cannot gather inside the step kernel (use anm_gather_obs_f64)");
   if (!index || !scale || !low || !high) return fail("anm_model_set_obs: null argument");
   if (n_obs > 4096) return fail("anm_model_set_obs: more than 4096 observation entries");
+  if (m->has_view && m->view.w_obs != 0 && m->view.w_obs < n_obs) return fail("anm_model_set_obs: the bound view's w_obs is narrower than the list");
   if (m->impl != ANM_IMPL_THREAD) {
     // lane-group families: the identity layout of `full` (runtime offsets of the network), the classes the list reads
     const bool rad = m->impl == ANM_IMPL_RADIAL;

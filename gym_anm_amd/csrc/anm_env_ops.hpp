@@ -37,6 +37,7 @@ __device__ __forceinline__ cptr_t class_constants(cptr_t C, const ClassSel& cs, 
 struct View {
   const int32_t* index;   // null: slot = environment
   int w_load, w_gen, w_set, w_des, w_action, w_state, w_exo, w_aux, w_full;   // row strides (0: the network's own widths)
+  int w_obs;              // ... of the rows of a list-form observation (0: n_obs)
 };
 
 struct SolverOpts {

@@ -195,6 +195,14 @@ struct LaneView {
   }
 };
 
+// hybrid hand-overs: position of level h's first light-child slot in the packed list (sum of T_NLH below h)
+template <class T>
+constexpr int hyb_slot_base(int h) {
+  int n = 0;
+  for (int k = 0; k < h && k <= T::T_MAXH; ++k) n += T::T_NLH[k];
+  return n;
+}
+
 // The Newton-Raphson loop of every lane group of the wavefront, from the iterate (vm, cs, sn) each bus lane
 // holds, `it` iterations already done.  gvalid (uniform per group): the group holds a solve.  Every lane of
 // the wavefront must call.  On return: the final iterate, `it`, and the group's verdict in tb / tn
@@ -227,6 +235,36 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
     xS[3 * wl] = double2{0.0, 0.0}; xS[3 * wl + 1] = double2{0.0, 0.0}; xS[3 * wl + 2] = double2{0.0, 0.0};
     ANM_WAVE_SYNC();
   }
+  // Hybrid hand-overs of the elimination (codegen.hybrid_plan; LDS variant only): the buses lie along their heavy edges, so
+  // the child a bus's own elimination waits for -- the one of height h - 1 -- sits in the next lane and its six values
+  // arrive by DPP (row_shl:1, no LDS round trip on the longest chain); every other child is folded through its LDS slot at
+  // the level right after its own, by a parent that has nothing else to do then.  lq[h][j]: slot index (3 x lane) of the
+  // j-th light child this lane's bus folds at level h (no such child: a padding lane's slot, zeros).
+  constexpr bool HYB = LDSX && T::T_HYB != 0;
+  // (the lanes of the children are per-lane constants of the whole loop: packed four to a register -- a byte each, one
+  // v_bfe_u32 to take one out -- or they cost the kernel its third wavefront per SIMD: 170 registers instead of <= 168)
+  constexpr int NLQ = HYB ? hyb_slot_base<T>(T::T_MAXH + 1) : 0;
+  [[maybe_unused]] unsigned lqp[HYB ? (NLQ + 3) / 4 + 1 : 1] = {0u};
+  [[maybe_unused]] unsigned clp[HYB ? (T::T_MAXCH + 3) / 4 : 1] = {0u};
+  [[maybe_unused]] bool dpp_child = false;   // this lane's bus has its heavy child in the next lane
+  if constexpr (HYB) {
+    constexpr int PAD = first_padding_lane<T>();
+    const int gb0 = wl - (wl & (T::GRP - 1));
+    const int bb = T::T_LANE_BUS[wl & (T::GRP - 1)];
+    static_for<1, T::T_MAXH + 1>([&](auto H) {
+      static_for<0, T::T_NLH[H]>([&](auto J) {
+        constexpr int q = hyb_slot_base<T>(H) + J;
+        const int c = bb > 0 ? T::T_LCH[(H * T::NB + bb) * T::T_MAXL + J] : -1;
+        lqp[q / 4] |= unsigned(gb0 + (c > 0 ? T::T_POS[c] : PAD)) << (8 * (q % 4));
+      });
+    });
+    static_for<0, T::T_MAXCH>([&](auto Cc) { clp[Cc / 4] |= unsigned(cl[Cc]) << (8 * (Cc % 4)); });
+    dpp_child = bb > 0 && T::T_HEAVY[bb] > 0;
+  }
+  [[maybe_unused]] auto child_lane = [&](auto Cc) -> int {   // lane of the Cc-th child (W sums)
+    if constexpr (HYB) return int(__builtin_amdgcn_ubfe(clp[Cc / 4], 8u * (Cc % 4), 8u));
+    else return cl[Cc];
+  };
   const int height = V.height, depth = V.depth, nch = V.nch;
   const double ybb_r = V.ybb_r, ybb_i = V.ybb_i, ybp_r = V.ybp_r, ybp_i = V.ybp_i, ypb_r = V.ypb_r, ypb_i = V.ypb_i;
   const unsigned long long gmask = V.gmask;
@@ -274,7 +312,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       static_for<0, T::T_MAXCH>([&](auto Cc) {
         double cr, ci;
         if constexpr (LDSX) {
-          const double2 cw = xW[cl[Cc]];
+          const double2 cw = xW[child_lane(Cc)];
           cr = cw.x; ci = cw.y;
         } else {
           cr = X.template from_child<Cc>(wpb_r); ci = X.template from_child<Cc>(wpb_i);
@@ -317,6 +355,60 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       // ---- elimination by height: a bus folds the Schur complements and reduced right-hand sides its
       // children published (registers Sc / Lr of the child lanes; 0 on padding lanes), inverts its pivot
       // and publishes its own
+      if constexpr (HYB) {
+        static_for<0, T::T_MAXH + 1>([&](auto H) {
+          constexpr int h = H;
+          if constexpr (h > 0) {
+            constexpr int NL = T::T_NLH[h];
+            // light children of height h - 1 (published at the end of the previous level), folded by every bus that has some --
+            // whatever its own height: all NL slots fetched together, then folded
+            if constexpr (NL > 0) {
+              if (height >= h) {
+#ifndef ANM_HYB_FETCH
+#define ANM_HYB_FETCH 1   // light-child slots fetched together before they are folded (2: 170 registers, the third wavefront per SIMD lost)
+#endif
+                static_for<0, (NL + ANM_HYB_FETCH - 1) / ANM_HYB_FETCH>([&](auto R) {
+                  constexpr int Q0 = R * ANM_HYB_FETCH;
+                  constexpr int NF = (NL - Q0) < ANM_HYB_FETCH ? (NL - Q0) : ANM_HYB_FETCH;
+                  double2 qv[NF][3];
+                  static_for<0, NF>([&](auto Q) {
+                    constexpr int q = hyb_slot_base<T>(h) + Q0 + Q;
+                    const int cq = 3 * int(__builtin_amdgcn_ubfe(lqp[q / 4], 8u * (q % 4), 8u));
+                    qv[Q][0] = xS[cq]; qv[Q][1] = xS[cq + 1]; qv[Q][2] = xS[cq + 2];
+                  });
+                  static_for<0, NF>([&](auto Q) {
+                    Dg.a -= JT(qv[Q][0].x); Dg.b -= JT(qv[Q][0].y); Dg.c -= JT(qv[Q][1].x); Dg.d -= JT(qv[Q][1].y);
+                    r0 -= JT(qv[Q][2].x); r1 -= JT(qv[Q][2].y);
+                  });
+                });
+              }
+            }
+            // the heavy child's publication: registers of the next lane (every lane executes the moves; only the buses of
+            // this height, whose next lane IS their child of height h - 1, use what arrives)
+            constexpr int SHL1 = 0x101;   // row_shl:1 -- lane i reads lane i + 1 of its 16-lane row
+            const JT ha = dpp_move<SHL1, 0xF, 1, true>(JT(0), Sc.a), hb = dpp_move<SHL1, 0xF, 1, true>(JT(0), Sc.b);
+            const JT hc = dpp_move<SHL1, 0xF, 1, true>(JT(0), Sc.c), hd = dpp_move<SHL1, 0xF, 1, true>(JT(0), Sc.d);
+            const JT h0 = dpp_move<SHL1, 0xF, 1, true>(JT(0), Lr0), h1 = dpp_move<SHL1, 0xF, 1, true>(JT(0), Lr1);
+            if (height == h && (T::T_ALL_HEAVY != 0 || dpp_child)) {
+              Dg.a -= ha; Dg.b -= hb; Dg.c -= hc; Dg.d -= hd;
+              r0 -= h0; r1 -= h1;
+            }
+          }
+          if (height == h) {
+            Dg = blk_inv_fast(Dg);
+            if constexpr (h < T::T_MAXH) {
+              const Blk<JT> Lk = blk_mul(Jpb, Dg);
+              Sc = blk_mul(Lk, Jbp);
+              Lr0 = fm(Lk.a, r0, Lk.b * r1);
+              Lr1 = fm(Lk.c, r0, Lk.d * r1);
+              xS[3 * wl] = double2{double(Sc.a), double(Sc.b)};
+              xS[3 * wl + 1] = double2{double(Sc.c), double(Sc.d)};
+              xS[3 * wl + 2] = double2{double(Lr0), double(Lr1)};
+            }
+          }
+          if constexpr (h < T::T_MAXH) ANM_WAVE_SYNC();
+        });
+      } else
       static_for<0, T::T_MAXH + 1>([&](auto H) {
         constexpr int h = H;
         constexpr int NC = T::T_NCH_H[h];

@@ -683,7 +683,10 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 // are staged in LDS (Launch)
 template <class JT, bool PG = false, bool WG = false, int SW = 2, bool TL = !WG>
 #ifndef ANM_MESH_MINWAVES2
-#define ANM_MESH_MINWAVES2 2   // tuning switch: the waves-per-SIMD hint of the SW = 2 variants (1: none, what round 4 compiled)
+// The SW = 2 variants carry NO waves-per-SIMD hint (1): the compiler gives them 192 registers = two wavefronts per SIMD
+// either way, but with the hint its schedule of the trip is slower -- meshed 30 buses, 16 384 transitions: 546 -> 534 us, same
+// box, three rounds each (profiles/r06_b_mesh_regression.txt: the regression the driver saw between rounds 4 and 5).
+#define ANM_MESH_MINWAVES2 1
 #endif
 __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,
                                                               radial::IO io, SolverOpts so, int64_t n_env, ClassSel cls) {
@@ -1278,23 +1281,16 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) 
     if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) f[d.f_gen_pmax + slot] = p_pot;
   };
 
-  if (mode == 0) {
-    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
-    if (l == 0) {
-      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
-      io.t.converged[e] = converged ? 1 : 0;
-      if (io.t.nr_iters) io.t.nr_iters[e] = it;
-      if (nr_diff) nr_diff[e] = fdiff;
-    }
-    write_full();
-    return;
-  }
-
+  // (one call site each for the list-form observation and for the dump: their |z| / arg z code exists once, not once per
+  // mode and branch -- the branches only decide: lo_mode 0 none, 1 zeros, 2 gather; dump)
+  int lo_mode = 0;
+  bool dump = false;
   double* state = io.e.state + e * W_ST;
   // the observation: clip(state, Box) next to the state row, or (a list is set: anm_env.py:497-521, 562-592; see
   // anm_radial.hpp) n_obs entries gathered from this environment's electrical state
   const bool list = mode == 2 && io.e.n_obs > 0;
-  const int OW = list ? io.e.n_obs : W_ST;
+  const int ON = list ? io.e.n_obs : W_ST;                                  // entries of an observation row
+  const int OW = list ? (io.v.w_obs > 0 ? io.v.w_obs : io.e.n_obs) : W_ST;   // its stride (a view pads the rows)
   double* obs = io.e.obs + e * OW;
   cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
   auto put = [&](int k, double v) {
@@ -1304,7 +1300,7 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) 
   auto list_obs = [&](bool zero) {
     if (!list) return;
     if (zero) {   // terminal / absorbing: the observation is 0 (anm_env.py:365-367, 442-446)
-      for (int k = l; k < OW; k += G) obs[k] = 0.0;
+      for (int k = l; k < ON; k += G) obs[k] = 0.0;
       return;
     }
     // the row lives where the Jacobian blocks were (l_blk ... l_bw: free once the solve is over; anm_model_set_obs has
@@ -1339,18 +1335,30 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) 
     if (resetting || io.e.exo == nullptr) { if (l == 0) row[d.FS] = double(aux); }
     else for (int k = l; k < K; k += G) row[d.FS + k] = io.e.aux_next[e * W_AUX + k];
     ANM_MESH_SYNC();
-    for (int k = l; k < OW; k += G) {
+    for (int k = l; k < ON; k += G) {
       const double v = row[io.e.obs_index[k]] * io.e.obs_scale[k];
       obs[k] = fmin(fmax(v, io.e.obs_lo[k]), io.e.obs_hi[k]);
     }
   };
+  do {
+  if (mode == 0) {
+    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
+    if (l == 0) {
+      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
+      io.t.converged[e] = converged ? 1 : 0;
+      if (io.t.nr_iters) io.t.nr_iters[e] = it;
+      if (nr_diff) nr_diff[e] = fdiff;
+    }
+    dump = true;
+    break;
+  }
   if (skip) {
     if (mode == 2) {  // absorbing terminal state
-      if (list) list_obs(true);
+      if (list) lo_mode = 1;
       else for (int k = l; k < SD_; k += G) obs[k] = 0.0;
       if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
     }
-    return;
+    break;
   }
   if (l == 0 && io.e.nr_iters) io.e.nr_iters[e] = it;
   if (resetting) {
@@ -1382,10 +1390,10 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) 
         if (io.e.timestep) io.e.timestep[e] = 0;
         io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
       }
-      list_obs(!converged);
+      lo_mode = converged ? 2 : 1;
     }
-    write_full();
-    return;
+    dump = true;
+    break;
   }
   if (typ == DEV_STORAGE) io.e.soc[e * W_DES + slot] = soc;
   const bool term = !converged;
@@ -1401,7 +1409,7 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) 
   } else {
     for (int k = l; k < SD_; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }
   }
-  list_obs(term);
+  lo_mode = term ? 1 : 2;
   if (l == 0) {
     const double c1 = rd[SF_C1], c2 = rd[SF_C2];
     io.e.terminated[e] = term ? 1 : 0;
@@ -1415,7 +1423,11 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) 
     }
     if (io.e.timestep) io.e.timestep[e] += 1;
   }
-  write_full();
+  dump = true;
+  } while (false);
+  // (lo_mode and dump are uniform over the lanes of an environment: list_obs synchronises them)
+  if (list && lo_mode != 0) list_obs(lo_mode == 1);
+  if (dump) write_full();
 }
 #endif  // __HIPCC__
 

@@ -712,26 +712,16 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) f[d.f_gen_pmax + slot] = p_pot;
   };
 
-  // (one call site for the dump: its |z| / arg z code exists once, not once per mode)
+  // (one call site for the dump and for the list-form observation: their |z| / arg z code exists once, not once per mode
+  // and branch; lo_mode: 0 none, 1 zeros, 2 gather -- uniform over the lanes of an environment, like `dump`)
   bool dump = false;
-  do {
-  if (mode == 0) {
-    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
-    if (l == 0) {
-      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
-      io.t.converged[e] = converged ? 1 : 0;
-      if (io.t.nr_iters) io.t.nr_iters[e] = it;
-      if (nr_diff) nr_diff[e] = fdiff;
-    }
-    dump = true;
-    break;
-  }
-
+  int lo_mode = 0;
   double* state = io.e.state + e * W_ST;
   // the observation: clip(state, Box) next to the state row, or (a list is set: anm_env.py:497-521, 562-592) n_obs entries
   // gathered from this environment's electrical state
   const bool list = mode == 2 && io.e.n_obs > 0;
-  const int OW = list ? io.e.n_obs : W_ST;
+  const int ON = list ? io.e.n_obs : W_ST;                                  // entries of an observation row
+  const int OW = list ? (io.v.w_obs > 0 ? io.v.w_obs : io.e.n_obs) : W_ST;   // its stride (a view pads the rows)
   double* obs = io.e.obs + e * OW;
   cptr_t lo = C + d.off_obs_lo, hi = C + d.off_obs_hi;
   auto put = [&](int k, double v) {
@@ -743,7 +733,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   auto list_obs = [&](bool zero) {
     if (!list) return;
     if (zero) {   // terminal / absorbing: the observation is 0 (anm_env.py:365-367, 442-446)
-      for (int k = l; k < OW; k += G) obs[k] = 0.0;
+      for (int k = l; k < ON; k += G) obs[k] = 0.0;
       return;
     }
     double* row = sh_obs_rows + (t / G) * (d.FS + KMAX);
@@ -775,14 +765,26 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (resetting || io.e.exo == nullptr) { if (l == 0) row[d.FS] = double(aux); }
     else for (int k = l; k < K; k += G) row[d.FS + k] = io.e.aux_next[e * W_AUX + k];
     ANM_GROUP_SYNC();
-    for (int k = l; k < OW; k += G) {
+    for (int k = l; k < ON; k += G) {
       const double v = row[io.e.obs_index[k]] * io.e.obs_scale[k];
       obs[k] = fmin(fmax(v, io.e.obs_lo[k]), io.e.obs_hi[k]);
     }
   };
+  do {
+  if (mode == 0) {
+    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
+    if (l == 0) {
+      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
+      io.t.converged[e] = converged ? 1 : 0;
+      if (io.t.nr_iters) io.t.nr_iters[e] = it;
+      if (nr_diff) nr_diff[e] = fdiff;
+    }
+    dump = true;
+    break;
+  }
   if (skip) {
     if (mode == 2) {  // absorbing terminal state
-      if (list) list_obs(true);
+      if (list) lo_mode = 1;
       else for (int k = l; k < S; k += G) obs[k] = 0.0;
       if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
     }
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         if (io.e.timestep) io.e.timestep[e] = 0;
         io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
       }
-      list_obs(!converged);
+      lo_mode = converged ? 2 : 1;
     }
     dump = true;
     break;
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   } else {
     for (int k = l; k < S; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }
   }
-  list_obs(term);
+  lo_mode = term ? 1 : 2;
   if (l == 0) {
     const double c1 = rd[SF_C1], c2 = rd[SF_C2];
     io.e.terminated[e] = term ? 1 : 0;
@@ -856,6 +858,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   }
   dump = true;
   } while (false);
+  if (list && lo_mode != 0) list_obs(lo_mode == 1);
   if (dump) write_full();
   ANM_PHASE(5);
 }

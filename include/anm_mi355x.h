@@ -161,15 +161,19 @@ int anm_model_bind_env_classes(anm_model* m, const int32_t* env_class, int64_t n
  * anm_reset_f64 / anm_step_f64 take num_envs = the number of environments of the view: launch slot s works on
  * environment env_index[s] -- row env_index[s] of every per-environment array, the RNG key env_offset + env_index[s] --
  * with the row strides given here; inside a row the network's own layout starts at column 0 (state: dev_p, dev_q,
- * des_soc, gen_p_max, aux at column state_base_dim).  Served by the kernel family the model is in (round 5: every family
+ * des_soc, gen_p_max, aux at column state_base_dim).  Served by the kernel family the model is in (every family
  * takes a view -- an ANM6 sub-batch keeps its thread-per-environment kernels, a feeder its tree kernel; the
- * thread-per-environment step then reads and writes its rows per lane instead of as coalesced blocks, and takes K <= 1);
- * not together with parameter classes, a list-form observation or anm_model_bind_state_same.  NULL unbinds.
+ * thread-per-environment step then reads and writes its rows per lane instead of as coalesced blocks, takes K <= 1 and
+ * the "state" observation only; the lane-group families take host next_vars with any K and list-form observations
+ * through a view as without one);
+ * not together with parameter classes or anm_model_bind_state_same.  NULL unbinds.
  * One launch per topology; launches of different models on different streams may overlap (they touch disjoint rows). */
 typedef struct anm_batch_view {
   const int32_t* env_index; /* DEVICE int32 [n]: the environments of this view (caller-owned, alive while bound); NULL: 0..n-1 */
   int32_t w_load, w_gen, w_set, w_des;   /* row strides of p_load / p_pot / p_set, q_set / soc (0: the network's own width) */
   int32_t w_action, w_state, w_exo, w_aux, w_full; /* ... of action / state, obs, init_state / exo / aux_next / full */
+  int32_t w_obs; /* ... of the rows of a LIST-form observation (anm_model_set_obs; 0: n_obs); the "state" observation's rows
+                    have the stride of the state rows (w_state) */
 } anm_batch_view;
 int anm_model_bind_view(anm_model* m, const anm_batch_view* view);
 
@@ -320,8 +324,8 @@ int anm_gather_obs_f64(int64_t num_envs, int32_t full_dim, const double* full, i
  * runs.  index/scale/low/high are HOST arrays of n_obs entries (copied).  n_obs = 0 restores the "state"
  * observation obs = clip(state).  anm_model_obs_fusable: 1 when the model supports this under its current kernel family
  * (thread per environment: its electrical-state rows fit in LDS; lane groups: one row of FS + 8 doubles per environment
- * in LDS -- 48 KB per wavefront at most in the radial kernel, in place of the Jacobian blocks in the general one; not with a
- * batch view), else use `full` + anm_gather_obs_f64.  The tables belong to the family that is current when the list is set:
+ * in LDS -- 48 KB per wavefront at most in the radial kernel, in place of the Jacobian blocks in the general one; the
+ * thread-per-environment family not through a batch view), else use `full` + anm_gather_obs_f64.  The tables belong to the family that is current when the list is set:
  * anm_model_set_impl and a class binding that would change the family are refused while a list is set (clear it, switch, set it
  * again).  anm_reset_f64 is not affected. */
 int anm_model_obs_fusable(const anm_model* m);

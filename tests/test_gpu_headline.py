@@ -352,6 +352,41 @@ def test_parameter_classes_inside_a_block_of_64_move_the_model_to_a_lane_group_f
         BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.two_bus_network()])
 
 
+def test_lifting_a_class_binding_is_refused_while_a_list_observation_of_the_other_family_is_set():
+    """bind per-environment classes (thread -> lane-group family), set a list-form observation there (identity
+    tables, no row stride), unbind: the model would be back on the thread-per-environment kernels with tables they cannot
+    read (overlapping LDS rows, silently wrong observations).  Both ways back -- unbind, rebind in aligned blocks -- are
+    refused until the list is cleared."""
+    import ctypes as C
+
+    from gym_anm_amd import _lib, networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    base = networks.anm6_network()
+    ev = np.zeros(128, dtype=np.int32)
+    ev[70:] = 1
+    sim = BatchedSimulator(base, 0.25, 100, num_envs=128, device=DEV, variants=[networks.perturbed_network(base, 1)], env_variant=ev)
+    lib, h = sim.backend.lib, sim._handle
+    assert sim.impl == "radial"
+    cfg = _lib.EnvConfig(K=1, gamma=0.995, clip_e_loss=1.0, clip_penalty=100.0, obs_low=None, obs_high=None, series=None, period=0)
+    assert lib.anm_model_set_env(h, C.byref(cfg)) == 0
+    idx = np.array([2, 3, sim.full_dim], dtype=np.int32)
+    one, lo, hi = np.ones(3), -np.ones(3) * 1e9, np.ones(3) * 1e9
+    args = (_lib.as_c(idx, np.int32)[1], _lib.as_c(one, np.float64)[1], _lib.as_c(lo, np.float64)[1], _lib.as_c(hi, np.float64)[1])
+    assert lib.anm_model_set_obs(h, 3, *args) == 0
+    # an aux index beyond the task's K is refused (it would gather LDS nobody wrote)
+    bad = np.array([2, 3, sim.full_dim + 1], dtype=np.int32)
+    assert lib.anm_model_set_obs(h, 3, _lib.as_c(bad, np.int32)[1], *args[1:]) != 0 and b"out of range" in lib.anm_last_error()
+    assert lib.anm_model_set_obs(h, 3, *args) == 0
+    assert lib.anm_model_bind_env_classes(h, None, 0) != 0 and b"clear it first" in lib.anm_last_error()
+    aligned = torch.as_tensor(np.repeat([0, 1], 64).astype(np.int32), device=DEV)
+    assert lib.anm_model_bind_env_classes(h, aligned.data_ptr(), 128) != 0 and b"clear it first" in lib.anm_last_error()
+    assert lib.anm_model_get_impl(h) == 1                      # nothing moved
+    assert lib.anm_model_set_obs(h, 0, None, None, None, None) == 0
+    assert lib.anm_model_bind_env_classes(h, None, 0) == 0 and lib.anm_model_get_impl(h) == 0
+    assert lib.anm_model_set_obs(h, 3, *args) == 0             # set again: now with the thread family's tables
+
+
 # ---------------------------------------------------------------------------------------------------
 # the general lane-group family ("mesh"): any topology, block-sparse Jacobian in LDS
 # ---------------------------------------------------------------------------------------------------
