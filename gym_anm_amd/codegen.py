@@ -404,6 +404,55 @@ def hybrid_plan(n_bus, tt):
                 ALL_HEAVY=int(all(heavy[b] for b in range(1, n_bus) if height[b] >= 1)))
 
 
+def lane_pack(n_bus, tt, lane_bus, pos, hy):
+    """What a lane of a group needs to know about its place in the tree, as ONE row of 32-bit words per lane (csrc/anm_group.hpp:
+    LaneView::init reads its row with one vector load): the tables indexed by bus -- lane -> bus -> parent -> lane of the
+    parent -- cost every wavefront a chain of three dependent loads before its first Newton trip.  Lanes are group-relative.
+      word 0: bus (8 bits) | height + 1 (4) | depth + 1 (4) | number of children (4) | lane of the parent or a padding lane (8)
+              | bit 28: the heavy child sits in the next lane (hybrid plan)
+      words 1 ..: lanes of the children, a byte each (no such child: a padding lane)
+      then (hybrid plan): lanes of the light children folded at level 1, 2, ..., a byte each, in level order
+      then: height + 1 of every child, a nibble each (0: no such child)
+      last word: the lane that plays bus l + 1 (lane l does the input / output of bus l + 1 in the tree kernel)
+    Returns (words per lane, first word of the light-child list, flat list) or None (more than 15 children / levels)."""
+    G, maxch = tt["GRP"], tt["MAXCH"]
+    if maxch > 15 or tt["MAXH"] > 14 or tt["MAXD"] > 14:
+        return None
+    pad = lane_bus.index(0)
+    nw_ch = (maxch + 3) // 4
+    slots = []   # (level, j) of the hybrid plan's light-child slots
+    if hy is not None:
+        for h in range(tt["MAXH"] + 1):
+            slots += [(h, j) for j in range(hy["NLH"][h])]
+    nw_lq = (len(slots) + 3) // 4
+    nw_hh = (maxch + 7) // 8     # heights of the children, a nibble each (height + 1; 0: no such child)
+    nw = 1 + nw_ch + nw_lq + nw_hh + 1   # last word: the lane that plays bus l + 1 (where lane l, which does bus l + 1's I/O, finds it)
+    out = []
+    for l in range(G):
+        b = lane_bus[l]
+        words = [0] * nw
+        par = tt["PARENT"][b] if b else 0
+        pl = pos[par] if (b and par > 0) else pad
+        ch = [c for c in tt["CH"][b * maxch:(b + 1) * maxch]] if b else [-1] * maxch
+        words[0] = (b & 0xFF) | (((tt["HEIGHT"][b] + 1) if b else 0) << 8) | (((tt["DEPTH"][b] + 1) if b else 0) << 12) \
+            | ((tt["NCH"][b] if b else 0) << 16) | (pl << 20)
+        if hy is not None and b and hy["HEAVY"][b]:
+            words[0] |= 1 << 28
+        for c in range(maxch):
+            lane = pos[ch[c]] if ch[c] > 0 else pad
+            words[1 + c // 4] |= lane << (8 * (c % 4))
+        for q, (h, j) in enumerate(slots):
+            c = hy["LCH"][(h * n_bus + b) * hy["MAXL"] + j] if b else -1
+            lane = pos[c] if c > 0 else pad
+            words[1 + nw_ch + q // 4] |= lane << (8 * (q % 4))
+        for c in range(maxch):
+            if ch[c] > 0:
+                words[1 + nw_ch + nw_lq + c // 8] |= (tt["HEIGHT"][ch[c]] + 1) << (4 * (c % 8))
+        words[nw - 1] = pos[l + 1] if l + 1 < n_bus else l
+        out += words
+    return nw, 1 + nw_ch, 1 + nw_ch + nw_lq, out
+
+
 def _arr(name, values, typ="int"):
     vals = list(values)
     body = ", ".join(str(int(v)) for v in vals) if vals else "0"
@@ -525,6 +574,30 @@ def emit_header(topo, name=None) -> str:
                 _arr("T_PAR_FULL", [x[2] for x in pad2(pl["PAR"])]),
                 _arr("T_CH_N", chn), _arr("T_CH_CTRL", chc), _arr("T_CH_BANK", chb), _arr("T_CH_FULL", chf),
             ]  # fmt: skip
+    if tt is not None:
+        if dp is not None:
+            lane_bus_, pos_ = dp["LANE_BUS"], dp["POS"]
+        elif hy is not None:
+            lane_bus_, pos_ = hy["LANE_BUS"], hy["POS"]
+        else:
+            lane_bus_, pos_ = [b if b < n_bus else 0 for b in range(1, tt["GRP"] + 1)], [0] + list(range(n_bus - 1))
+        lp = lane_pack(n_bus, tt, lane_bus_, pos_, hy if dp is None else None)
+        if lp is None:
+            lines += ["  static constexpr int T_LP_NW = 0, T_LP_LQ = 0, T_LP_HH = 0;", "  alignas(16) static constexpr unsigned T_LP[1] = {0};"]
+        else:
+            lines += ["  // one row of words per lane: its place in the tree (codegen.lane_pack)",
+                      "  static constexpr int T_LP_NW = %d, T_LP_LQ = %d, T_LP_HH = %d;" % (lp[0], lp[1], lp[2]),
+                      "  alignas(16) static constexpr unsigned T_LP[%d] = {%s};" % (len(lp[3]), ", ".join("0x%xu" % w for w in lp[3]))]
+        # register hand-overs (DPP / ds_bpermute): the child classes a level folds -- class c at level h when some bus has a
+        # c-th child of height h - 1 (a child is folded at the level right after its own, whatever the height of its parent)
+        maxch_ = tt["MAXCH"]
+        cls_h = [0] * ((tt["MAXH"] + 1) * maxch_)
+        for b in range(1, n_bus):
+            for c in range(maxch_):
+                k = tt["CH"][b * maxch_ + c]
+                if k > 0:
+                    cls_h[(tt["HEIGHT"][k] + 1) * maxch_ + c] = 1
+        lines += [_arr("T_CLS_H", cls_h)]
     lines += [
         "};",
         "}  // namespace",

@@ -163,6 +163,8 @@ struct LaneView {
   Lanes<T> X;
   double ybb_r, ybb_i, ybp_r, ybp_i, ypb_r, ypb_i;   // Y_bb, Y_b,parent, Y_parent,b (padding lanes: 0 -> W = 0)
   unsigned long long gmask; // lanes of my group
+  unsigned pk[T::T_LP_NW > 0 ? T::T_LP_NW : 1];   // this lane's row of codegen.lane_pack (group-relative lanes)
+  bool dpp_child;           // hybrid plan: the heavy child of this lane's bus sits in the next lane
 
   __device__ __forceinline__ void init() {
     constexpr int G = T::GRP;
@@ -171,6 +173,24 @@ struct LaneView {
     const int lane = threadIdx.x & 63;
     l = lane & (G - 1);
     gb = lane - l;
+    gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gb;
+    ybb_r = ybb_i = ybp_r = ybp_i = ypb_r = ypb_i = 0.0;
+    dpp_child = false;
+    if constexpr (T::T_LP_NW > 0) {
+      // ONE row of packed words per lane (a single vector load) instead of the chain lane -> bus -> parent -> lane of the
+      // parent through three tables: three dependent loads in front of the first Newton trip of every wavefront
+      static_for<0, T::T_LP_NW>([&](auto K) { pk[K] = T::T_LP[l * T::T_LP_NW + K]; });
+      const unsigned w0 = pk[0];
+      b = int(w0 & 0xFFu);
+      lane_bus = b > 0;
+      height = int((w0 >> 8) & 0xFu) - 1;
+      depth = int((w0 >> 12) & 0xFu) - 1;
+      nch = int((w0 >> 16) & 0xFu);
+      X.psrc4 = 4 * (gb + int((w0 >> 20) & 0xFFu));
+      dpp_child = ((w0 >> 28) & 1u) != 0u;
+      static_for<0, T::T_MAXCH>([&](auto Cc) { X.csrc4[Cc] = 4 * (gb + int((pk[1 + Cc / 4] >> (8 * (Cc % 4))) & 0xFFu)); });
+      return;
+    }
     b = T::T_LANE_BUS[l];
     lane_bus = b > 0;
     const int parent = T::T_PARENT[b];               // 0: slack (b is a root of the elimination forest)
@@ -182,8 +202,6 @@ struct LaneView {
       const int c = lane_bus ? T::T_CH[b * T::T_MAXCH + Cc] : -1;
       X.csrc4[Cc] = 4 * (gb + (c > 0 ? T::T_POS[c] : PAD));
     });
-    gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gb;
-    ybb_r = ybb_i = ybp_r = ybp_i = ypb_r = ypb_i = 0.0;
   }
   __device__ __forceinline__ void load_y(cptr_t C) {   // admittances of the compiled network
     typedef Layout<T> L;
@@ -246,20 +264,13 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
   constexpr int NLQ = HYB ? hyb_slot_base<T>(T::T_MAXH + 1) : 0;
   [[maybe_unused]] unsigned lqp[HYB ? (NLQ + 3) / 4 + 1 : 1] = {0u};
   [[maybe_unused]] unsigned clp[HYB ? (T::T_MAXCH + 3) / 4 : 1] = {0u};
-  [[maybe_unused]] bool dpp_child = false;   // this lane's bus has its heavy child in the next lane
+  [[maybe_unused]] const bool dpp_child = V.dpp_child;   // this lane's bus has its heavy child in the next lane
   if constexpr (HYB) {
-    constexpr int PAD = first_padding_lane<T>();
-    const int gb0 = wl - (wl & (T::GRP - 1));
-    const int bb = T::T_LANE_BUS[wl & (T::GRP - 1)];
-    static_for<1, T::T_MAXH + 1>([&](auto H) {
-      static_for<0, T::T_NLH[H]>([&](auto J) {
-        constexpr int q = hyb_slot_base<T>(H) + J;
-        const int c = bb > 0 ? T::T_LCH[(H * T::NB + bb) * T::T_MAXL + J] : -1;
-        lqp[q / 4] |= unsigned(gb0 + (c > 0 ? T::T_POS[c] : PAD)) << (8 * (q % 4));
-      });
-    });
-    static_for<0, T::T_MAXCH>([&](auto Cc) { clp[Cc / 4] |= unsigned(cl[Cc]) << (8 * (Cc % 4)); });
-    dpp_child = bb > 0 && T::T_HEAVY[bb] > 0;
+    static_assert(T::T_LP_NW > 0, "the hybrid plan comes with the packed lane table (codegen.lane_pack)");
+    // (the table holds group-relative lanes, a byte each: + the first lane of the group in every byte)
+    const unsigned gb1 = unsigned(V.gb) * 0x01010101u;
+    static_for<0, (NLQ + 3) / 4>([&](auto K) { lqp[K] = V.pk[T::T_LP_LQ + K] + gb1; });
+    static_for<0, (T::T_MAXCH + 3) / 4>([&](auto K) { clp[K] = V.pk[1 + K] + gb1; });
   }
   [[maybe_unused]] auto child_lane = [&](auto Cc) -> int {   // lane of the Cc-th child (W sums)
     if constexpr (HYB) return int(__builtin_amdgcn_ubfe(clp[Cc / 4], 8u * (Cc % 4), 8u));
@@ -407,6 +418,37 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
             }
           }
           if constexpr (h < T::T_MAXH) ANM_WAVE_SYNC();
+        });
+      } else if constexpr (!LDSX && T::T_LP_NW > 0 && T::T_MAXCH <= 8) {
+        // Register hand-overs (DPP moves / ds_bpermute), every child folded at the level right after its OWN (whatever the
+        // height of its parent: a parent of a higher level has nothing else to do then) -- a level moves only the child
+        // classes some bus really folds there (T_CLS_H): the 6-bus feeder moves 2 + 1 classes instead of 2 + 2, twelve to
+        // twenty-four DPP moves of a 375-instruction trip.  chh: height + 1 of each child of this lane's bus (a nibble each).
+        const unsigned chh = V.pk[T::T_LP_HH];
+        static_for<0, T::T_MAXH + 1>([&](auto H) {
+          constexpr int h = H;
+          if constexpr (h > 0) {
+            static_for<0, T::T_MAXCH>([&](auto Cc) {
+              if constexpr (T::T_CLS_H[h * T::T_MAXCH + Cc] != 0) {
+                const JT ga = X.template from_child<Cc>(Sc.a), gbb = X.template from_child<Cc>(Sc.b);
+                const JT gc = X.template from_child<Cc>(Sc.c), gd = X.template from_child<Cc>(Sc.d);
+                const JT g0 = X.template from_child<Cc>(Lr0), g1 = X.template from_child<Cc>(Lr1);
+                if (((chh >> (4 * Cc)) & 0xFu) == unsigned(h)) {   // my Cc-th child has height h - 1
+                  Dg.a -= ga; Dg.b -= gbb; Dg.c -= gc; Dg.d -= gd;
+                  r0 -= g0; r1 -= g1;
+                }
+              }
+            });
+          }
+          if (height == h) {
+            Dg = blk_inv_fast(Dg);
+            if constexpr (h < T::T_MAXH) {
+              const Blk<JT> Lk = blk_mul(Jpb, Dg);
+              Sc = blk_mul(Lk, Jbp);
+              Lr0 = fm(Lk.a, r0, Lk.b * r1);
+              Lr1 = fm(Lk.c, r0, Lk.d * r1);
+            }
+          }
         });
       } else
       static_for<0, T::T_MAXH + 1>([&](auto H) {

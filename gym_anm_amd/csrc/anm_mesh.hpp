@@ -683,9 +683,15 @@ inline bool build_plan(const anm_network_desc& n, Plan& P, std::string& err) {
 // are staged in LDS (Launch)
 template <class JT, bool PG = false, bool WG = false, int SW = 2, bool TL = !WG>
 #ifndef ANM_MESH_MINWAVES2
-// The SW = 2 variants carry NO waves-per-SIMD hint (1): the compiler gives them 192 registers = two wavefronts per SIMD
-// either way, but with the hint its schedule of the trip is slower -- meshed 30 buses, 16 384 transitions: 546 -> 534 us, same
-// box, three rounds each (profiles/r06_b_mesh_regression.txt: the regression the driver saw between rounds 4 and 5).
+// The waves-per-SIMD hint of the SW = 2 variants: none (1).  Round 6 traced most of the 522 -> 546 us of the meshed 30-bus batch
+// between rounds 4 and 5 to `__launch_bounds__(256, 2)` (round 4 compiled without a hint): the same 192 registers either way,
+// but hipcc's schedule of the trip is 7-18 us slower with it (profiles/r06_a_mesh_bisect.txt, r06_b_mesh_regression.txt).
+// CAUTION, measured the hard way: this kernel sits on a code-generation fault of hipcc 7.2.  With the outputs section written
+// as in round 5 (dump and list observation called from each branch) and the kernel arguments of this round, the variant with
+// its tables in LDS returned wrong branch_p entries and rewards -- V, I and every other quantity bit-equal to the other
+// variants -- on the star / complete / five-feeder test networks without the hint, and faulted on the complete graph with it;
+// with ONE call site each (below: lo_mode / dump) every variant passes the whole GPU tier under either setting.  Any edit here
+// is followed by tests/test_gpu_headline.py (structured topologies, launch variants bit-identical) before anything else.
 #define ANM_MESH_MINWAVES2 1
 #endif
 __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) void k_mesh(Dims d, const int* __restrict__ ri, const double* __restrict__ rd0,

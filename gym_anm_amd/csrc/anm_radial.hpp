@@ -486,7 +486,10 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     // it at three wavefronts per SIMD)
     group::newton_groups<TT, JT, 10, TT::T_DPP == 0, PG ? 2 : ANM_LDSX_FETCH>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn,
                                                                             so.tol, so.max_iter, &sh[0][0]);
-    const int back4 = 4 * (gb + (isbus ? TT::T_POS[l + 1] : l));
+    int back_lane;   // the lane that plays bus l + 1
+    if constexpr (TT::T_LP_NW > 0) back_lane = int(V.pk[TT::T_LP_NW - 1]);
+    else back_lane = isbus ? TT::T_POS[l + 1] : l;
+    const int back4 = 4 * (gb + back_lane);
     vm = group::bperm(gvm, back4); cs = group::bperm(gcs, back4); sn = group::bperm(gsn, back4);
     // iteration count and verdict are uniform over a group: every lane takes those of the lane playing bus 1
     // (all lanes execute the hand-over: an inactive source lane would read as 0)
@@ -712,10 +715,21 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE) f[d.f_gen_pmax + slot] = p_pot;
   };
 
-  // (one call site for the dump and for the list-form observation: their |z| / arg z code exists once, not once per mode
-  // and branch; lo_mode: 0 none, 1 zeros, 2 gather -- uniform over the lanes of an environment, like `dump`)
+  // (one call site for the dump: its |z| / arg z code exists once, not once per mode)
   bool dump = false;
-  int lo_mode = 0;
+  do {
+  if (mode == 0) {
+    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
+    if (l == 0) {
+      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
+      io.t.converged[e] = converged ? 1 : 0;
+      if (io.t.nr_iters) io.t.nr_iters[e] = it;
+      if (nr_diff) nr_diff[e] = fdiff;
+    }
+    dump = true;
+    break;
+  }
+
   double* state = io.e.state + e * W_ST;
   // the observation: clip(state, Box) next to the state row, or (a list is set: anm_env.py:497-521, 562-592) n_obs entries
   // gathered from this environment's electrical state
@@ -770,21 +784,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       obs[k] = fmin(fmax(v, io.e.obs_lo[k]), io.e.obs_hi[k]);
     }
   };
-  do {
-  if (mode == 0) {
-    if (typ == DEV_STORAGE) io.t.soc[e * W_DES + slot] = soc;
-    if (l == 0) {
-      io.t.reward[e] = reward; io.t.e_loss[e] = e_loss; io.t.penalty[e] = penalty;
-      io.t.converged[e] = converged ? 1 : 0;
-      if (io.t.nr_iters) io.t.nr_iters[e] = it;
-      if (nr_diff) nr_diff[e] = fdiff;
-    }
-    dump = true;
-    break;
-  }
   if (skip) {
     if (mode == 2) {  // absorbing terminal state
-      if (list) lo_mode = 1;
+      if (list) list_obs(true);
       else for (int k = l; k < S; k += G) obs[k] = 0.0;
       if (l == 0) { io.e.reward[e] = 0.0; if (io.e.nr_iters) io.e.nr_iters[e] = 0; }
     }
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         if (io.e.timestep) io.e.timestep[e] = 0;
         io.e.reward[e] = 0.0; io.e.e_loss[e] = 0.0; io.e.penalty[e] = 0.0;
       }
-      lo_mode = converged ? 2 : 1;
+      list_obs(!converged);
     }
     dump = true;
     break;
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   } else {
     for (int k = l; k < S; k += G) { state[k] = 0.0; if (!list) obs[k] = 0.0; }
   }
-  lo_mode = term ? 1 : 2;
+  list_obs(term);
   if (l == 0) {
     const double c1 = rd[SF_C1], c2 = rd[SF_C2];
     io.e.terminated[e] = term ? 1 : 0;
@@ -858,7 +860,6 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   }
   dump = true;
   } while (false);
-  if (list && lo_mode != 0) list_obs(lo_mode == 1);
   if (dump) write_full();
   ANM_PHASE(5);
 }
