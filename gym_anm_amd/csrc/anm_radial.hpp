@@ -402,8 +402,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   double dev_p = 0.0, dev_q = 0.0, p_pot = 0.0;
   {
     cptr_t sd = C + d.off_dev + l * SD_SIZE;
+    const Recip rbase = make_recip(base);   // (one reciprocal for the three divisions of a lane: see div_by)
     if (typ == DEV_LOAD) {
-      const double p = fmin(fmax(in_p / base, sd[0]), sd[1]);
+      const double p = fmin(fmax(div_by(in_p, rbase), sd[0]), sd[1]);
       dev_p = p;
       dev_q = p * sd[2];
     } else if (typ == DEV_CLASSICAL || typ == DEV_RENEWABLE || typ == DEV_STORAGE) {
@@ -418,10 +419,10 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         pl = fmax(pl, (soc - sd[SD_SOC_MAX]) / (dt * eff));
         pu = fmin(pu, eff * (soc - sd[SD_SOC_MIN]) / dt);
       } else {
-        p_pot = fmin(fmax(in_pot / base, sd[SD_PMIN]), sd[SD_PMAX]);
+        p_pot = fmin(fmax(div_by(in_pot, rbase), sd[SD_PMIN]), sd[SD_PMAX]);
         pu = fmin(pu, p_pot);
       }
-      project_pq<4>(sd, in_p / base, in_q / base, pl, pu, dev_p, dev_q);
+      project_pq<4>(sd, div_by(in_p, rbase), div_by(in_q, rbase), pl, pu, dev_p, dev_q);
       if (des) {
         const double ns = (dev_p <= 0.0) ? (soc - dt * eff * dev_p) : (soc - dt * dev_p / eff);
         soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
