@@ -408,15 +408,16 @@ def lane_pack(n_bus, tt, lane_bus, pos, hy):
     """What a lane of a group needs to know about its place in the tree, as ONE row of 32-bit words per lane (csrc/anm_group.hpp:
     LaneView::init reads its row with one vector load): the tables indexed by bus -- lane -> bus -> parent -> lane of the
     parent -- cost every wavefront a chain of three dependent loads before its first Newton trip.  Lanes are group-relative.
-      word 0: bus (8 bits) | height + 1 (4) | depth + 1 (4) | number of children (4) | lane of the parent or a padding lane (8)
-              | bit 28: the heavy child sits in the next lane (hybrid plan)
+      word 0: bus (7 bits) | height + 1 (7) | depth + 1 (7) | number of children (4) | lane of the parent or a padding lane (6)
+              | bit 31: the heavy child sits in the next lane (hybrid plan)
       words 1 ..: lanes of the children, a byte each (no such child: a padding lane)
       then (hybrid plan): lanes of the light children folded at level 1, 2, ..., a byte each, in level order
-      then: height + 1 of every child, a nibble each (0: no such child)
+      then: height + 1 of every child, a byte each (0: no such child)
       last word: the lane that plays bus l + 1 (lane l does the input / output of bus l + 1 in the tree kernel)
-    Returns (words per lane, first word of the light-child list, flat list) or None (more than 15 children / levels)."""
+    Returns (words per lane, first word of the light-child list, first word of the child heights, flat list) or None (a bus
+    with more than 15 children)."""
     G, maxch = tt["GRP"], tt["MAXCH"]
-    if maxch > 15 or tt["MAXH"] > 14 or tt["MAXD"] > 14:
+    if maxch > 15:
         return None
     pad = lane_bus.index(0)
     nw_ch = (maxch + 3) // 4
@@ -425,7 +426,7 @@ def lane_pack(n_bus, tt, lane_bus, pos, hy):
         for h in range(tt["MAXH"] + 1):
             slots += [(h, j) for j in range(hy["NLH"][h])]
     nw_lq = (len(slots) + 3) // 4
-    nw_hh = (maxch + 7) // 8     # heights of the children, a nibble each (height + 1; 0: no such child)
+    nw_hh = (maxch + 3) // 4     # heights of the children, a byte each (height + 1; 0: no such child)
     nw = 1 + nw_ch + nw_lq + nw_hh + 1   # last word: the lane that plays bus l + 1 (where lane l, which does bus l + 1's I/O, finds it)
     out = []
     for l in range(G):
@@ -434,10 +435,10 @@ def lane_pack(n_bus, tt, lane_bus, pos, hy):
         par = tt["PARENT"][b] if b else 0
         pl = pos[par] if (b and par > 0) else pad
         ch = [c for c in tt["CH"][b * maxch:(b + 1) * maxch]] if b else [-1] * maxch
-        words[0] = (b & 0xFF) | (((tt["HEIGHT"][b] + 1) if b else 0) << 8) | (((tt["DEPTH"][b] + 1) if b else 0) << 12) \
-            | ((tt["NCH"][b] if b else 0) << 16) | (pl << 20)
+        words[0] = (b & 0x7F) | (((tt["HEIGHT"][b] + 1) if b else 0) << 7) | (((tt["DEPTH"][b] + 1) if b else 0) << 14) \
+            | ((tt["NCH"][b] if b else 0) << 21) | (pl << 25)
         if hy is not None and b and hy["HEAVY"][b]:
-            words[0] |= 1 << 28
+            words[0] |= 1 << 31
         for c in range(maxch):
             lane = pos[ch[c]] if ch[c] > 0 else pad
             words[1 + c // 4] |= lane << (8 * (c % 4))
@@ -447,7 +448,7 @@ def lane_pack(n_bus, tt, lane_bus, pos, hy):
             words[1 + nw_ch + q // 4] |= lane << (8 * (q % 4))
         for c in range(maxch):
             if ch[c] > 0:
-                words[1 + nw_ch + nw_lq + c // 8] |= (tt["HEIGHT"][ch[c]] + 1) << (4 * (c % 8))
+                words[1 + nw_ch + nw_lq + c // 4] |= (tt["HEIGHT"][ch[c]] + 1) << (8 * (c % 4))
         words[nw - 1] = pos[l + 1] if l + 1 < n_bus else l
         out += words
     return nw, 1 + nw_ch, 1 + nw_ch + nw_lq, out
@@ -535,6 +536,8 @@ def emit_header(topo, name=None) -> str:
             _arr("T_ZBB", tt["ZBB"]), _arr("T_ZBP", tt["ZBP"]), _arr("T_ZPB", tt["ZPB"]),
         ]  # fmt: skip
         hy = None if (dp is not None or os.environ.get("ANM_NO_HYBRID")) else hybrid_plan(n_bus, tt)  # ANM_NO_HYBRID: tuning switch
+        if hy is not None and lane_pack(n_bus, tt, hy["LANE_BUS"], hy["POS"], hy) is None:
+            hy = None   # (a bus with more than 15 children: no packed rows, the plain LDS hand-overs)
         if hy is not None:
             lines += [
                 "  // hybrid hand-overs (codegen.hybrid_plan): buses laid out along their heavy edges (DPP row_shl:1 from the child of",

@@ -181,13 +181,13 @@ struct LaneView {
       // parent through three tables: three dependent loads in front of the first Newton trip of every wavefront
       static_for<0, T::T_LP_NW>([&](auto K) { pk[K] = T::T_LP[l * T::T_LP_NW + K]; });
       const unsigned w0 = pk[0];
-      b = int(w0 & 0xFFu);
+      b = int(w0 & 0x7Fu);
       lane_bus = b > 0;
-      height = int((w0 >> 8) & 0xFu) - 1;
-      depth = int((w0 >> 12) & 0xFu) - 1;
-      nch = int((w0 >> 16) & 0xFu);
-      X.psrc4 = 4 * (gb + int((w0 >> 20) & 0xFFu));
-      dpp_child = ((w0 >> 28) & 1u) != 0u;
+      height = int((w0 >> 7) & 0x7Fu) - 1;
+      depth = int((w0 >> 14) & 0x7Fu) - 1;
+      nch = int((w0 >> 21) & 0xFu);
+      X.psrc4 = 4 * (gb + int((w0 >> 25) & 0x3Fu));
+      dpp_child = (w0 >> 31) != 0u;
       static_for<0, T::T_MAXCH>([&](auto Cc) { X.csrc4[Cc] = 4 * (gb + int((pk[1 + Cc / 4] >> (8 * (Cc % 4))) & 0xFFu)); });
       return;
     }
@@ -419,12 +419,11 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           }
           if constexpr (h < T::T_MAXH) ANM_WAVE_SYNC();
         });
-      } else if constexpr (!LDSX && T::T_LP_NW > 0 && T::T_MAXCH <= 8) {
+      } else if constexpr (!LDSX && T::T_LP_NW > 0) {
         // Register hand-overs (DPP moves / ds_bpermute), every child folded at the level right after its OWN (whatever the
         // height of its parent: a parent of a higher level has nothing else to do then) -- a level moves only the child
         // classes some bus really folds there (T_CLS_H): the 6-bus feeder moves 2 + 1 classes instead of 2 + 2, twelve to
-        // twenty-four DPP moves of a 375-instruction trip.  chh: height + 1 of each child of this lane's bus (a nibble each).
-        const unsigned chh = V.pk[T::T_LP_HH];
+        // twenty-four DPP moves of a 375-instruction trip.  (height + 1 of each child of this lane's bus: a byte each in the packed row)
         static_for<0, T::T_MAXH + 1>([&](auto H) {
           constexpr int h = H;
           if constexpr (h > 0) {
@@ -433,7 +432,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
                 const JT ga = X.template from_child<Cc>(Sc.a), gbb = X.template from_child<Cc>(Sc.b);
                 const JT gc = X.template from_child<Cc>(Sc.c), gd = X.template from_child<Cc>(Sc.d);
                 const JT g0 = X.template from_child<Cc>(Lr0), g1 = X.template from_child<Cc>(Lr1);
-                if (((chh >> (4 * Cc)) & 0xFu) == unsigned(h)) {   // my Cc-th child has height h - 1
+                if (((V.pk[T::T_LP_HH + Cc / 4] >> (8 * (Cc % 4))) & 0xFFu) == unsigned(h)) {   // my Cc-th child has height h - 1
                   Dg.a -= ga; Dg.b -= gbb; Dg.c -= gc; Dg.d -= gd;
                   r0 -= g0; r1 -= g1;
                 }

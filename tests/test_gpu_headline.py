@@ -442,7 +442,36 @@ def test_mesh_structured_topologies_against_oracle(shape):
     _mesh_network_against_oracle(len(net["bus"]), 3, 0, 64, 0.5, 2, net=net)
 
 
-def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeless, net=None):
+def _small_tree():
+    """the 8-bus feeder of parity_common.general_step_with_wide_rows (its library is compiled by that test anyway): a tree with
+    a three-child bus -- no all-DPP plan, so its lane groups use the HYBRID hand-overs (codegen.hybrid_plan) in the tree kernel
+    and the ds_bpermute hand-overs with children folded by height in the thread-per-environment kernels"""
+    from gym_anm_amd import networks
+
+    net = networks.synthetic_radial_network(8, 3)
+    dev = [list(r) for r in net["device"]]
+    while len(dev) < 9:
+        dev.append([len(dev), 2 + len(dev) % 5, -1, 0.2, 0, -4.0 - len(dev)] + [None] * 9)
+    net["device"] = np.array(dev, dtype=object)
+    return net
+
+
+@pytest.mark.parametrize("impl,handoff", [("radial", None), ("thread", 0), ("thread", 2)])
+def test_small_tree_without_a_dpp_plan_against_oracle(impl, handoff):
+    """The hybrid hand-overs of the tree kernel and the register hand-overs by child height (handed over from iteration 0 / 2:
+    the lane groups do all / most of the work) on a tree OTHER than the stock 30-bus feeder, case by case against the oracle,
+    diverging cases included."""
+    from gym_anm_amd import codegen
+    from gym_anm_amd.model import NetworkModel
+
+    net = _small_tree()
+    hdr = codegen.emit_header(NetworkModel(net, 0.25, 100).topology())
+    assert "T_DPP = 0" in hdr and "T_HYB = 1" in hdr
+    sim = _mesh_network_against_oracle(8, 3, 0, 192, 1.0, 6, net=net, impl=impl, handoff_after=handoff)
+    assert sim.impl == impl and not sim.backend.generic
+
+
+def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeless, net=None, impl="mesh", handoff_after=None):
     import anm_oracle as O
     from gym_anm_amd import networks
     from gym_anm_amd.model import NetworkModel
@@ -452,8 +481,9 @@ def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeles
         net = networks.synthetic_meshed_network(n_bus, seed, n_chords) if n_chords else networks.synthetic_radial_network(n_bus, seed)
     model = NetworkModel(net, 0.25, 100)
     tree = len(net["branch"]) == len(net["bus"]) - 1
-    sim = BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl="mesh" if (n_bus <= 12 or tree) else None)
-    assert sim.impl == "mesh"
+    kw = {} if handoff_after is None else {"handoff_after": handoff_after}
+    sim = BatchedSimulator(net, 0.25, 100, num_envs=M, device=DEV, tol=1e-8, impl=impl if (impl != "mesh" or n_bus <= 12 or tree) else None, **kw)
+    assert sim.impl == impl
     npt.assert_allclose(sim.device_ybus(), model.Y_bus, rtol=1e-15, atol=0)
     rng = np.random.default_rng(seed)
     b = model.baseMVA
