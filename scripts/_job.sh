@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash scripts/r06_profile.sh j head thr c30 mix > gpurun_out/r06_j_profile.log 2>&1
-tail -12 gpurun_out/r06_j_profile.log
+python -m pytest tests/test_gpu_headline.py -m gpu -q -k "small_tree or hybrid_tree_kernel" 2>&1 | tail -5

@@ -875,7 +875,7 @@ def general_step_with_wide_rows(kw):
         soc = env.simulator.soc.cpu().numpy().copy()
 
 
-def per_environment_networks(kw, impl, n_variants=24, E_=192, n_check=48):
+def per_environment_networks(kw, impl, n_variants=24, E_=192, n_check=48, base=None):
     """A different network in every environment (the reference: one Simulator per environment, examples/custom_anm6.py:20):
     the class changes from one environment to the next, in no order -- served by the lane-group families (one
     environment per lane group, constants by vector loads).  Transitions against the oracle of each environment's own
@@ -885,7 +885,8 @@ def per_environment_networks(kw, impl, n_variants=24, E_=192, n_check=48):
 
     from gym_anm_amd.envs import ANM6EasyVec
 
-    base = networks.anm6_network()
+    anm6 = base is None     # (base: another network -- the transitions only; the environment layer below is ANM6Easy's)
+    base = networks.anm6_network() if anm6 else base
     variants = [networks.perturbed_network(base, 300 + k) for k in range(1, n_variants)]
     nets = [base] + variants
     rng = np.random.default_rng(8)
@@ -920,6 +921,8 @@ def per_environment_networks(kw, impl, n_variants=24, E_=192, n_check=48):
         npt.assert_allclose(full[e, sl["branch_s"]], out["br_s"], rtol=0, atol=1e-9)
         npt.assert_allclose(float(r[e]), out["reward"], rtol=1e-9, atol=1e-9)
     assert n_conv >= n_check // 2
+    if not anm6:
+        return sim
     # the thread-per-environment family cannot serve such an assignment: asked for, the model moves to a lane group
     sim_t = BatchedSimulator(base, 0.25, 100, num_envs=E_, variants=variants, env_variant=env_variant, impl="thread", **kw(base))
     assert sim_t.impl in ("radial", "mesh")

@@ -465,8 +465,10 @@ def test_small_tree_without_a_dpp_plan_against_oracle(impl, handoff):
     from gym_anm_amd.model import NetworkModel
 
     net = _small_tree()
-    hdr = codegen.emit_header(NetworkModel(net, 0.25, 100).topology())
+    topo = NetworkModel(net, 0.25, 100).topology()
+    hdr = codegen.emit_header(topo)
     assert "T_DPP = 0" in hdr and "T_HYB = 1" in hdr
+    codegen.build_library(topo)   # (the tree's OWN library: without it a radial model runs the table-driven loop of any other)
     sim = _mesh_network_against_oracle(8, 3, 0, 192, 1.0, 6, net=net, impl=impl, handoff_after=handoff)
     assert sim.impl == impl and not sim.backend.generic
 
@@ -711,6 +713,16 @@ def test_general_step_with_rows_wider_than_the_default_lds_limit():
 @pytest.mark.parametrize("impl", ["radial", "mesh"])
 def test_a_different_network_in_every_environment(impl):
     pc.per_environment_networks(KW, impl)
+
+
+def test_a_different_feeder_in_every_environment_on_the_hybrid_tree_kernel():
+    """The per-environment-constants variant of the tree kernel (k_radial<.., Topo, PG>: vector loads of each lane group's own
+    network) on the stock 30-bus feeder, i.e. with the hybrid hand-overs of round 6: 8 perturbed feeders dealt at random,
+    every checked transition against the oracle of its own network."""
+    from gym_anm_amd import networks
+
+    sim = pc.per_environment_networks(KW, "radial", n_variants=8, E_=128, n_check=32, base=networks.synthetic_radial_network(30, 0))
+    assert sim.impl == "radial" and not sim.backend.generic and sim.lanes_per_env == 32
 
 
 def test_reset_and_step_through_views_of_a_mixed_batch():
