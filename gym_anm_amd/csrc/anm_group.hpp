@@ -128,6 +128,91 @@ constexpr int first_padding_lane() {
   return -1;
 }
 
+// Which buses fold their c-th child at elimination level h (the child has height h - 1) -- of the buses of height h:
+// 2 = every one, 1 = some, 0 = none; and: does a bus of a GREATER height fold a c-th child there (an "early" fold: the child
+// is folded at the level right after its own, whatever the height of its parent).  Bus 0 (the slack) folds nothing.
+template <class T>
+constexpr int fold_at_own_level(int h, int c) {
+  int n = 0, k = 0;
+  for (int b = 1; b < T::NB; ++b)
+    if (T::T_HEIGHT[b] == h) {
+      ++n;
+      const int ch = T::T_CH[b * T::T_MAXCH + c];
+      if (ch > 0 && T::T_HEIGHT[ch] == h - 1) ++k;
+    }
+  return k == 0 ? 0 : (k == n ? 2 : 1);
+}
+template <class T>
+constexpr bool fold_early(int h, int c) {
+  for (int b = 1; b < T::NB; ++b)
+    if (T::T_HEIGHT[b] > h) {
+      const int ch = T::T_CH[b * T::T_MAXCH + c];
+      if (ch > 0 && T::T_HEIGHT[ch] == h - 1) return true;
+    }
+  return false;
+}
+// of the buses of height h: 2 = every one hangs off the slack (depth 0), 1 = some, 0 = none
+template <class T>
+constexpr int roots_at_height(int h) {
+  int n = 0, k = 0;
+  for (int b = 1; b < T::NB; ++b)
+    if (T::T_HEIGHT[b] == h) {
+      ++n;
+      if (T::T_DEPTH[b] == 0) ++k;
+    }
+  return k == 0 ? 0 : (k == n ? 2 : 1);
+}
+// Child sums without a predicate: the move of child class c (ONE bank-masked row shift, written into a register that is
+// zero on the lanes the move never writes and keeps them so) delivers to every bus lane it writes either the value of that
+// bus's c-th child or that of a padding lane -- whose W product is zero: its admittances are.  Checked lane by lane over a
+// 16-lane row; a shift that would cross into the row's other group must read a padding lane there too.
+template <class T>
+constexpr bool child_moves_land_on_parents_or_zero() {
+  if (T::T_DPP == 0 || T::GRP > 16) return false;
+  for (int c = 0; c < T::T_MAXCH; ++c) {
+    if (T::T_CH_N[c] != 1 || T::T_CH_FULL[2 * c] != 0) return false;
+    const int ctrl = T::T_CH_CTRL[2 * c], bank = T::T_CH_BANK[2 * c];
+    const int k = ctrl & 0xF, shl = (ctrl & 0x1F0) == 0x100, shr = (ctrl & 0x1F0) == 0x110;
+    if (!shl && !shr) return false;
+    for (int l = 0; l < 16; ++l) {
+      if (((bank >> (l / 4)) & 1) == 0) continue;
+      const int sl = shl ? l + k : l - k;
+      if (sl < 0 || sl > 15) continue;                       // no source: not written
+      const int R = T::T_LANE_BUS[l % T::GRP], S = T::T_LANE_BUS[sl % T::GRP];
+      if (R == 0) continue;                                  // a padding lane receives: nobody reads its sums
+      if (S == 0) {
+        // a padding lane's product arrives: 0 x (the voltage of whatever lane its own "parent" moves read) -- a zero unless
+        // that voltage is Inf / NaN, so that lane must belong to the receiver's environment (whose solve is lost then
+        // anyway), never to the neighbouring group of the row
+        int src = -1;
+        for (int m = 0; m < T::T_PAR_N; ++m) {
+          const int pc = T::T_PAR_CTRL[m], pk = pc & 0xF;
+          const bool pshl = (pc & 0x1F0) == 0x100, pshr = (pc & 0x1F0) == 0x110;
+          if (!pshl && !pshr) return false;
+          if (T::T_PAR_FULL[m] == 0 && ((T::T_PAR_BANK[m] >> (sl / 4)) & 1) == 0) continue;
+          const int q = pshl ? sl + pk : sl - pk;
+          if (q < 0 || q > 15) { if (T::T_PAR_FULL[m] != 0) src = -1; continue; }
+          src = q;
+        }
+        if (src >= 0 && src / T::GRP != l / T::GRP) return false;
+        continue;
+      }
+      if (l / T::GRP != sl / T::GRP) return false;           // another environment's bus
+      if (T::T_CH[R * T::T_MAXCH + c] != S) return false;
+    }
+  }
+  // ... and every bus's c-th child IS delivered by that move
+  for (int b = 1; b < T::NB; ++b)
+    for (int c = 0; c < T::T_MAXCH; ++c) {
+      const int ch = T::T_CH[b * T::T_MAXCH + c];
+      if (ch <= 0) continue;
+      const int ctrl = T::T_CH_CTRL[2 * c], bank = T::T_CH_BANK[2 * c], k = ctrl & 0xF;
+      const int l = T::T_POS[b], sl = ((ctrl & 0x1F0) == 0x100) ? l + k : l - k;
+      if (((bank >> (l / 4)) & 1) == 0 || sl < 0 || sl >= T::GRP || T::T_LANE_BUS[sl] != ch) return false;
+    }
+  return true;
+}
+
 // LDS slot of one handed-over solve: 5 per-bus arrays + the iteration count / flags
 template <class T>
 struct Slot {
@@ -229,6 +314,9 @@ constexpr int hyb_slot_base(int h) {
 // through LDS -- a lane PUBLISHES what its parent (or its children) will need in its own slot, the consumer reads
 // the slot of the lane it needs -- instead of ds_bpermute: a pair of doubles is one 16-byte write / read instead of
 // four bpermutes, and the 5 child slots x 6 values of a bushy level cost 15 reads instead of 60 bpermutes.
+#ifndef ANM_GROUP_MERGED_REGIONS
+#define ANM_GROUP_MERGED_REGIONS 1
+#endif
 // Padding lanes never publish; their slots hold the neutral values (zeroed here, V = 1).
 template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
@@ -296,6 +384,9 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
     // does, so these zeros are the neutral values the hand-overs rely on.
     Blk<JT> Sc = Blk<JT>{JT(0), JT(0), JT(0), JT(0)};
     JT Lr0 = JT(0), Lr1 = JT(0), d0 = JT(0), d1 = JT(0);
+    constexpr bool ROOT_STEP_IN_PIVOT = !LDSX && !(LDSX && T::T_HYB != 0) && T::T_LP_NW > 0 && ANM_GROUP_MERGED_REGIONS != 0;
+    constexpr bool WSUM_FREE = !LDSX && ANM_GROUP_MERGED_REGIONS != 0 && T::T_MAXCH > 0 && child_moves_land_on_parents_or_zero<T>();
+    [[maybe_unused]] double wr[T::T_MAXCH > 0 ? T::T_MAXCH : 1] = {0.0}, wi[T::T_MAXCH > 0 ? T::T_MAXCH : 1] = {0.0};
     [[maybe_unused]] int trip = 0;
     for (;;) {
       const double vr = vm * cs, vi = vm * sn;
@@ -320,6 +411,16 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         xW[wl] = double2{wpb_r, wpb_i};
         ANM_WAVE_SYNC();
       }
+      if constexpr (WSUM_FREE) {
+        // (no predicate: see child_moves_land_on_parents_or_zero; wr / wi are loop-carried so that the lanes no move writes
+        // keep their zeros)
+        static_for<0, T::T_MAXCH>([&](auto Cc) {
+          wr[Cc] = dpp_move<T::T_CH_CTRL[2 * Cc], T::T_CH_BANK[2 * Cc], 0, false>(wr[Cc], wpb_r);
+          wi[Cc] = dpp_move<T::T_CH_CTRL[2 * Cc], T::T_CH_BANK[2 * Cc], 0, false>(wi[Cc], wpb_i);
+          sr += wr[Cc];
+          si += wi[Cc];
+        });
+      } else
       static_for<0, T::T_MAXCH>([&](auto Cc) {
         double cr, ci;
         if constexpr (LDSX) {
@@ -419,6 +520,65 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           }
           if constexpr (h < T::T_MAXH) ANM_WAVE_SYNC();
         });
+      } else if constexpr (!LDSX && T::T_LP_NW > 0 && ANM_GROUP_MERGED_REGIONS != 0) {
+        // Register hand-overs, every child folded at the level right after its OWN (see the next variant), with the
+        // predicated code of a level gathered: all moves of the level first (every lane executes them), then ONE region
+        // for the buses of this height -- their folds (no predicate of its own for a child class every bus of this height
+        // folds now: the 6-bus feeder's only kind) and the pivot -- and one per child class a HIGHER bus folds early.  Each
+        // region the compiler opens is a save / restore pair of the exec mask (+ a skip branch for a long one): issue
+        // slots like any other for a wavefront that iterates alone on its SIMD.  Same operations on every bus, in the
+        // same order: bit-identical to the one-region-per-fold form (ANM_GROUP_MERGED_REGIONS=0).
+        static_for<0, T::T_MAXH + 1>([&](auto H) {
+          constexpr int h = H;
+          [[maybe_unused]] JT g[T::T_MAXCH][6];
+          [[maybe_unused]] auto mine_now = [&](auto Cc) {   // my Cc-th child has height h - 1
+            return ((V.pk[T::T_LP_HH + Cc / 4] >> (8 * (Cc % 4))) & 0xFFu) == unsigned(h);
+          };
+          [[maybe_unused]] auto fold = [&](auto Cc) {
+            Dg.a -= g[Cc][0]; Dg.b -= g[Cc][1]; Dg.c -= g[Cc][2]; Dg.d -= g[Cc][3];
+            r0 -= g[Cc][4]; r1 -= g[Cc][5];
+          };
+          if constexpr (h > 0) {
+            static_for<0, T::T_MAXCH>([&](auto Cc) {
+              if constexpr (T::T_CLS_H[h * T::T_MAXCH + Cc] != 0) {
+                g[Cc][0] = X.template from_child<Cc>(Sc.a); g[Cc][1] = X.template from_child<Cc>(Sc.b);
+                g[Cc][2] = X.template from_child<Cc>(Sc.c); g[Cc][3] = X.template from_child<Cc>(Sc.d);
+                g[Cc][4] = X.template from_child<Cc>(Lr0); g[Cc][5] = X.template from_child<Cc>(Lr1);
+              }
+            });
+          }
+          if (height == h) {
+            if constexpr (h > 0) {
+              static_for<0, T::T_MAXCH>([&](auto Cc) {
+                if constexpr (fold_at_own_level<T>(h, Cc) == 2) fold(Cc);
+                else if constexpr (fold_at_own_level<T>(h, Cc) == 1) { if (mine_now(Cc)) fold(Cc); }
+              });
+            }
+            Dg = blk_inv_fast(Dg);
+            // (the Newton step of a bus that hangs off the slack -- the first level of the back substitution -- right here,
+            // inside the region of its pivot: the same expression, no region or select of its own)
+            if constexpr (roots_at_height<T>(h) == 2) {
+              d0 = fm(Dg.a, r0, Dg.b * r1);
+              d1 = fm(Dg.c, r0, Dg.d * r1);
+            } else if constexpr (roots_at_height<T>(h) == 1) {
+              if (depth == 0) {
+                d0 = fm(Dg.a, r0, Dg.b * r1);
+                d1 = fm(Dg.c, r0, Dg.d * r1);
+              }
+            }
+            if constexpr (h < T::T_MAXH) {
+              const Blk<JT> Lk = blk_mul(Jpb, Dg);
+              Sc = blk_mul(Lk, Jbp);
+              Lr0 = fm(Lk.a, r0, Lk.b * r1);
+              Lr1 = fm(Lk.c, r0, Lk.d * r1);
+            }
+          }
+          if constexpr (h > 0) {
+            static_for<0, T::T_MAXCH>([&](auto Cc) {
+              if constexpr (fold_early<T>(h, Cc)) { if (height > h && mine_now(Cc)) fold(Cc); }
+            });
+          }
+        });
       } else if constexpr (!LDSX && T::T_LP_NW > 0) {
         // Register hand-overs (DPP moves / ds_bpermute), every child folded at the level right after its OWN (whatever the
         // height of its parent: a parent of a higher level has nothing else to do then) -- a level moves only the child
@@ -517,6 +677,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
             p1 = X.from_parent(d1, JT(0));
           }
         }
+        if constexpr (!(ROOT_STEP_IN_PIVOT && dd == 0))
         if (depth == dd) {
           JT a0 = r0, a1 = r1;
           if constexpr (dd > 0) {
@@ -536,6 +697,36 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       const bool upd = __builtin_amdgcn_inverse_ballot_w64(updm);
       const double dth = double(d0);
       const unsigned long long bigm = __builtin_amdgcn_fcmp(fabs(dth), 0.78, FCMP_UGT) & updm;  // NaN counts
+#ifndef ANM_GROUP_POLY_UNMASKED
+#define ANM_GROUP_POLY_UNMASKED 1
+#endif
+      if constexpr (ANM_GROUP_POLY_UNMASKED != 0 && !LDSX) {
+        // (register hand-over variant = the continuation of the thread family's diverging solves, where a trip's instruction
+        // COUNT is its duration: the short path evaluates the polynomials on every lane -- a lane that does not update
+        // computes on whatever its dth holds and drops the result -- so that the wave-uniform branch is the only control
+        // flow in front of them, and the rotation stands once behind both paths)
+        double sd_, cd_;
+        if (bigm == 0ull) {
+          sincos_kernel<true>(dth, 0, sd_, cd_);
+        } else {
+          sincos_medium<true>(dth, sd_, cd_);
+          // (beyond the two-stage reduction: a handful of lanes per million solves -- the library routine then runs on every
+          // lane of the wavefront and the lanes it was called for take its result: no divergent region in this tail)
+          const bool ish = !(fabs(dth) < 4.0e15);
+          if ((__builtin_amdgcn_uicmp(ish ? 1u : 0u, 0u, ICMP_NE) & updm) != 0ull) {
+            const SinCos r = sincos_huge(dth);
+            sd_ = ish ? r.s : sd_;
+            cd_ = ish ? r.c : cd_;
+          }
+        }
+        if (upd) {
+          vm = fma(-double(d1), fabs(vm), vm);
+          // (three-address v_fma_f64 in place of the compiler's v_fmac into a temporary + v_mov_b64 back into the loop's register)
+          const double t1 = sn * sd_, t2 = cs * sd_;
+          cs = fma3<false>(cs, cd_, t1);
+          sn = fma3<true>(sn, cd_, t2);
+        }
+      } else
       if (bigm == 0ull) {
         if (upd) {
           double sd_, cd_;

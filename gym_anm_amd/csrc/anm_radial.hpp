@@ -313,6 +313,18 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   const int mode = io.mode;
   const int K = io.e.K;
   const int S = d.SDIM + K;
+  // The constants of this lane's device (limits, the static part of the projection: SD_SIZE doubles), asked for NOW: their
+  // address depends on the lane alone, and the ~35 loads the device maps would otherwise issue inside their type branches --
+  // after the inputs have arrived -- are a second trip to memory on every wavefront's critical path.  (ANM_RADIAL_PREFETCH=0:
+  // tuning switch, the loads where they are used.)
+#ifndef ANM_RADIAL_PREFETCH
+#define ANM_RADIAL_PREFETCH 1
+#endif
+  double sdr[ANM_RADIAL_PREFETCH ? SD_SIZE : 1];
+  if constexpr (ANM_RADIAL_PREFETCH != 0) {
+    cptr_t row = C + d.off_dev + (l < d.ND ? l : d.ND - 1) * SD_SIZE;
+    static_for<0, SD_SIZE>([&](auto Kk) { sdr[Kk] = row[Kk]; });
+  }
 
   ANM_PHASE(0);
   // ---------------- inputs per device lane -------------------------------------------------
@@ -400,8 +412,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   ANM_PHASE(1);
   // ---------------- device maps (lane = device) ---------------------------------------------
   double dev_p = 0.0, dev_q = 0.0, p_pot = 0.0;
-  {
-    cptr_t sd = C + d.off_dev + l * SD_SIZE;
+  auto device_maps = [&](const auto& sd) {
     const Recip rbase = make_recip(base);   // (one reciprocal for the three divisions of a lane: see div_by)
     if (typ == DEV_LOAD) {
       const double p = fmin(fmax(div_by(in_p, rbase), sd[0]), sd[1]);
@@ -428,7 +439,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
         soc = fmin(fmax(ns, sd[SD_SOC_MIN]), sd[SD_SOC_MAX]);
       }
     }
-  }
+  };
+  if constexpr (ANM_RADIAL_PREFETCH != 0) device_maps(sdr);
+  else device_maps(C + d.off_dev + l * SD_SIZE);
   sh[A_S0][t] = dev_p;
   sh[A_S1][t] = dev_q;
   ANM_GROUP_SYNC();
