@@ -251,6 +251,41 @@ def _dpp_plan_for_group(G, n_bus, parent, ch, maxch, buses, roots, tt):
                     best = (cost, st)
         return None if best is None else best
 
+    def final_sources(steps):
+        out = ["OLD"] * 16
+        for off, banks in steps:
+            for i in range(16):
+                if banks is not None and ((i % G) // 4) not in banks:
+                    continue
+                src = i + off
+                if 0 <= src < 16:
+                    out[i] = src
+                elif banks is None:
+                    out[i] = "ZERO"
+        return out
+
+    def child_moves_safe(lane_bus, plan):
+        par = final_sources(plan["PAR"])
+        for c in range(maxch):
+            st = plan["CH%d" % c]
+            if len(st) != 1 or st[0][1] is None:
+                return False
+            off, banks = st[0]
+            for i in range(16):
+                if ((i % G) // 4) not in banks or not 0 <= i + off < 16:
+                    continue
+                src = i + off
+                R, S = lane_bus[i % G], lane_bus[src % G]
+                if R == 0:
+                    continue
+                if S == 0:  # a padding lane's product: zero x the voltage its own "parent" moves read
+                    if isinstance(par[src], int) and par[src] // G != i // G:
+                        return False
+                    continue
+                if src // G != i // G or ch[R][c] != S:
+                    return False
+        return True
+
     # Layouts worth trying: the c-th child of every bus sits at a fixed offset o_c from its parent, so that
     # "value of my c-th child" is ONE row shift; the layout is then fixed by the offsets and the root positions.
     # Weights: how many dwords per Newton trip go through each class (V and the Newton step from the parent;
@@ -293,11 +328,15 @@ def _dpp_plan_for_group(G, n_bus, parent, ch, maxch, buses, roots, tt):
                 cost += (r[0] if r else 0) * w_ch
             if plan is None:
                 continue
-            if best is None or cost < best[0]:
-                best = (cost, pos, lane_bus, plan)
+            # equal move counts: a layout whose child moves deliver, to every bus lane they write, the value of that
+            # bus's child or the zero of a padding lane of the same environment lets the child sums stand without a
+            # predicate (csrc/anm_group.hpp: child_moves_land_on_parents_or_zero -- the compile-time check of the same)
+            key = (cost, 0 if child_moves_safe(lane_bus, plan) else 1)
+            if best is None or key < best[0]:
+                best = (key, pos, lane_bus, plan)
     if best is None:
         return None
-    cost, pos, lane_bus, plan = best
+    (cost, _), pos, lane_bus, plan = best
 
     def encode(st):
         out = []

