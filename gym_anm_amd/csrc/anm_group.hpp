@@ -32,7 +32,7 @@ namespace group {
 
 // llvm CmpInst predicate codes taken by __builtin_amdgcn_{fcmp,uicmp,sicmp}: they return the compare as a
 // 64-bit lane mask in scalar registers (no bool -> ballot round trip)
-enum : int { FCMP_UNO = 8, FCMP_UGT = 10, ICMP_NE = 33, ICMP_SLT = 40 };
+enum : int { FCMP_UNO = 8, FCMP_UGT = 10, ICMP_EQ = 32, ICMP_NE = 33, ICMP_SLT = 40 };
 
 // ---------------------------------------------------------------------------------------------
 // Hand-overs between the lanes of a group.  Two register-to-register implementations behind one interface,
@@ -335,8 +335,14 @@ constexpr int hyb_slot_base(int h) {
 #ifndef ANM_GROUP_MERGED_REGIONS
 #define ANM_GROUP_MERGED_REGIONS 1
 #endif
+#ifndef ANM_HYB_LIGHT_ALL
+#define ANM_HYB_LIGHT_ALL 1
+#endif
+#ifndef ANM_LDSX_BS_ALL
+#define ANM_LDSX_BS_ALL 1
+#endif
 // Padding lanes never publish; their slots hold the neutral values (zeroed here, V = 1).
-template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH, bool WFREE = true>
+template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH, bool WFREE = true, bool VPOLY = !LDSX>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
                                               double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
                                               double tol, int max_iter, double* xl = nullptr) {
@@ -344,6 +350,11 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
   static_assert(!LDSX || T::T_DPP == 0, "LDS hand-overs are the alternative to ds_bpermute, not to DPP moves");
   [[maybe_unused]] const int wl = threadIdx.x & 63;
   [[maybe_unused]] const int pl = X.psrc4 >> 2;                       // lane of the parent (or a padding lane)
+  // LDS variant, back substitution without regions (ANM_LDSX_BS_ALL): every lane recomputes its step at every level -- from
+  // its own level on its parent's step is final, so it recomputes the same value -- and a bus that hangs off the slack reads
+  // a step of zero: the W slot of a padding lane (its admittances are zero), 64 slots behind the V slots.
+  constexpr bool BS_ALL = LDSX && ANM_LDSX_BS_ALL != 0;
+  [[maybe_unused]] const int plb = (BS_ALL && V.depth == 0) ? 64 + pl : pl;
   [[maybe_unused]] int cl[T::T_MAXCH > 0 ? T::T_MAXCH : 1];           // lanes of the children (or a padding lane)
   static_for<0, T::T_MAXCH>([&](auto Cc) { cl[Cc] = X.csrc4[Cc] >> 2; });
   // LDS hand-overs: what a lane publishes sits TOGETHER in its slot -- (re, im) pairs and the six values a parent folds
@@ -396,6 +407,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
     unsigned long long runm = __builtin_amdgcn_uicmp(gvalid ? 1u : 0u, 0u, ICMP_NE);
     const unsigned glo = unsigned(gmask & busm), ghi = unsigned((gmask & busm) >> 32);   // bus lanes of my group
     tb = 0u; tn = 0u;
+    [[maybe_unused]] const unsigned fbus1 = isbus ? 1u : 0u, fbus3 = isbus ? 3u : 0u;
     it -= gvalid ? 1 : 0;        // the first trip only evaluates: its `it += running` is undone here
     // What a lane publishes for its parent (Schur complement, reduced right-hand side) and its Newton step:
     // a bus lane rewrites them at its own level of every trip before anybody reads them; a padding lane never
@@ -425,13 +437,13 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       const double wbp_r = fma(ybp_r, pr, ybp_i * pim), wbp_i = fma(ybp_r, pim, -(ybp_i * pr));
       // (TRIM: the imaginary part is carried with its sign flipped -- the flip rides on the operands of its consumers instead of
       // being an instruction in front of the moves that hand it to the parent)
-      constexpr bool TRIM = !LDSX && ANM_GROUP_MERGED_REGIONS != 0;
+      constexpr bool TRIM = ANM_GROUP_MERGED_REGIONS != 0;   // (the LDS variant too: what it publishes is the unflipped value)
       const double wpb_r = fma(ypb_r, pr, -(ypb_i * pim)), nwpb_i = fma(ypb_r, pim, ypb_i * pr);
       [[maybe_unused]] const double wpb_i = -nwpb_i;
       // S_b = W_bb + W_bp + sum over the children c of W_pb(c)
       double sr = wbb_r + wbp_r, si = wbb_i + wbp_i;
       if constexpr (LDSX) {
-        xW[wl] = double2{wpb_r, wpb_i};
+        xW[wl] = TRIM ? double2{wpb_r, nwpb_i} : double2{wpb_r, wpb_i};
         ANM_WAVE_SYNC();
       }
       if constexpr (WSUM_FREE) {
@@ -451,17 +463,36 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           const double2 cw = xW[child_lane(Cc)];
           cr = cw.x; ci = cw.y;
         } else {
-          cr = X.template from_child<Cc>(wpb_r); ci = X.template from_child<Cc>(wpb_i);
+          cr = X.template from_child<Cc>(wpb_r); ci = X.template from_child<Cc>(TRIM ? nwpb_i : wpb_i);
         }
         if (Lanes<T>::template child_neutral<Cc>() || Cc < nch) {
           sr += cr;
-          si += ci;
+          if constexpr (TRIM) si -= ci; else si += ci;
         }
       });
       const double fr = sr - bus_p, fi = si - bus_q;
       // group-wide stop test: "||F||inf > tol" and "F has a NaN" are all the reference's loop and flags need.
       // A group that has stopped keeps evaluating the same frozen iterate, so what the last trip computed
       // is also each group's final verdict: nothing but `runm` and `it` is carried over.
+#ifndef ANM_GROUP_FLAG_OR
+#define ANM_GROUP_FLAG_OR 0   // (measured, same box: headline kernel 74.7 us without, 79.2 us with -- the butterfly sits on the exit chain)
+#endif
+      constexpr bool FLAG_OR = ANM_GROUP_FLAG_OR != 0 && !LDSX && ANM_GROUP_MERGED_REGIONS != 0 && T::T_DPP != 0 && (T::GRP == 8 || T::GRP == 16);
+      if constexpr (FLAG_OR) {
+        // the two verdicts as bits of one word per bus lane (1: above the tolerance or NaN, 2: NaN; a padding lane: 0), OR-ed
+        // over the group by a butterfly of DPP-operand v_or_b32 (quad swaps, half-row mirror, row mirror for 16 lanes): every
+        // lane then holds its group's verdict, and "keeps iterating" is the one comparison  verdict == 1
+        const bool bad = !(fmax(fabs(fr), fabs(fi)) <= tol), nan = !(fr == fr) || !(fi == fi);
+        unsigned f = bad ? fbus1 : 0u;
+        f = nan ? fbus3 : f;
+        f |= unsigned(__builtin_amdgcn_update_dpp(0, int(f), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        f |= unsigned(__builtin_amdgcn_update_dpp(0, int(f), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        f |= unsigned(__builtin_amdgcn_update_dpp(0, int(f), 0x141, 0xF, 0xF, true));   // row_half_mirror
+        if constexpr (T::GRP == 16) f |= unsigned(__builtin_amdgcn_update_dpp(0, int(f), 0x140, 0xF, 0xF, true));   // row_mirror
+        tb = f & 1u; tn = f & 2u;
+        it += __builtin_amdgcn_inverse_ballot_w64(runm) ? 1 : 0;   // the update applied in the previous trip
+        runm &= __builtin_amdgcn_uicmp(f, 1u, ICMP_EQ) & __builtin_amdgcn_sicmp(it, max_iter, ICMP_SLT);
+      } else {
       const unsigned long long badm = __builtin_amdgcn_fcmp(fmax(fabs(fr), fabs(fi)), tol, FCMP_UGT);
       const unsigned long long nanm = __builtin_amdgcn_fcmp(fr, fi, FCMP_UNO);
       tb = (unsigned(badm) & glo) | (unsigned(badm >> 32) & ghi);
@@ -469,6 +500,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       it += __builtin_amdgcn_inverse_ballot_w64(runm) ? 1 : 0;   // the update applied in the previous trip
       runm &= __builtin_amdgcn_uicmp(tb, 0u, ICMP_NE) & ~__builtin_amdgcn_uicmp(tn, 0u, ICMP_NE) &
               __builtin_amdgcn_sicmp(it, max_iter, ICMP_SLT);   // NaN > tol is false, like the reference
+      }
       // The loop is left at the END of the trip: the scalar chain compare -> masks -> branch then overlaps the
       // elimination instead of stalling the wavefront in front of it every trip (what counts for the ~94 trips
       // of a diverging solve); the price is one idle elimination when the last group stops (its update is
@@ -477,10 +509,8 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       // spot during the first EARLY_EXIT_TRIPS trips.
       const bool all_done = runm == 0ull;
       if constexpr (EARLY_EXIT_TRIPS > 0) {
-        if (trip < EARLY_EXIT_TRIPS) {
-          if (all_done) break;
-          ++trip;
-        }
+        if (all_done && trip < EARLY_EXIT_TRIPS) break;
+        ++trip;
       }
 
       // ---- Jacobian blocks (anm_device.hpp: newton_update): own diagonal and the two couplings with the parent
@@ -502,7 +532,9 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
             // light children of height h - 1 (published at the end of the previous level), folded by every bus that has some --
             // whatever its own height: all NL slots fetched together, then folded
             if constexpr (NL > 0) {
-              if (height >= h) {
+              // (ANM_HYB_LIGHT_ALL: every lane reads and folds -- a lane without such a child reads a padding lane's slot, zeros,
+              // also after its own pivot: no region around the reads)
+              if (ANM_HYB_LIGHT_ALL != 0 || height >= h) {
 #ifndef ANM_HYB_FETCH
 #define ANM_HYB_FETCH 1   // light-child slots fetched together before they are folded (2: 170 registers, the third wavefront per SIMD lost)
 #endif
@@ -515,6 +547,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
                     const int cq = 3 * int(__builtin_amdgcn_ubfe(lqp[q / 4], 8u * (q % 4), 8u));
                     qv[Q][0] = xS[cq]; qv[Q][1] = xS[cq + 1]; qv[Q][2] = xS[cq + 2];
                   });
+                  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): ONE wait for the round's reads (else one per 16-byte unit)
                   static_for<0, NF>([&](auto Q) {
                     Dg.a -= JT(qv[Q][0].x); Dg.b -= JT(qv[Q][0].y); Dg.c -= JT(qv[Q][1].x); Dg.d -= JT(qv[Q][1].y);
                     r0 -= JT(qv[Q][2].x); r1 -= JT(qv[Q][2].y);
@@ -704,7 +737,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         JT p0 = JT(0), p1 = JT(0);
         if constexpr (dd > 0) {
           if constexpr (LDSX) {
-            const double2 dp = xV[pl];
+            const double2 dp = xV[BS_ALL ? plb : pl];
             p0 = JT(dp.x); p1 = JT(dp.y);
           } else {
             p0 = X.from_parent(d0, JT(0));
@@ -712,7 +745,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           }
         }
         if constexpr (!(ROOT_STEP_IN_PIVOT && dd == 0))
-        if (depth == dd) {
+        if (BS_ALL || depth == dd) {
           JT a0 = r0, a1 = r1;
           if constexpr (dd > 0) {
             a0 = fm(-Jbp.b, p1, fm(-Jbp.a, p0, a0));
@@ -729,16 +762,17 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       // returns the same bits as the short path)
       // (a padding lane's step is zero -- it never writes d0 / d1 -- and a rotation by zero returns its V = 1 bit for bit:
       // where the pads ride along, `& busm` is an instruction saved)
-      const unsigned long long updm = TRIM ? runm : (runm & busm);
+      const unsigned long long updm = (TRIM && !LDSX) ? runm : (runm & busm);
       const bool upd = __builtin_amdgcn_inverse_ballot_w64(updm);
       const double dth = double(d0);
       const unsigned long long bigm = __builtin_amdgcn_fcmp(fabs(dth), 0.78, FCMP_UGT) & updm;  // NaN counts
 #ifndef ANM_GROUP_POLY_UNMASKED
 #define ANM_GROUP_POLY_UNMASKED 1
 #endif
-      if constexpr (ANM_GROUP_POLY_UNMASKED != 0 && !LDSX) {
-        // (register hand-over variant = the continuation of the thread family's diverging solves, where a trip's instruction
-        // COUNT is its duration: the short path evaluates the polynomials on every lane -- a lane that does not update
+      if constexpr (ANM_GROUP_POLY_UNMASKED != 0 && VPOLY) {
+        // (VPOLY: the register hand-over variant = the continuation of the thread family's diverging solves, where a trip's
+        // instruction COUNT is its duration, and the LDS variant where the caller's register budget has room for the
+        // coefficients in vector registers (the radial kernel without per-group classes: 163 of 168): the short path evaluates the polynomials on every lane -- a lane that does not update
         // computes on whatever its dth holds and drops the result -- so that the wave-uniform branch is the only control
         // flow in front of them, and the rotation stands once behind both paths)
         double sd_, cd_;

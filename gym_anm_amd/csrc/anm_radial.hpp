@@ -317,6 +317,9 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
   // address depends on the lane alone, and the ~35 loads the device maps would otherwise issue inside their type branches --
   // after the inputs have arrived -- are a second trip to memory on every wavefront's critical path.  (ANM_RADIAL_PREFETCH=0:
   // tuning switch, the loads where they are used.)
+#ifndef ANM_RADIAL_VPOLY
+#define ANM_RADIAL_VPOLY 1   // the update's polynomials as in the thread family's lane-group loop (group::newton_groups: VPOLY)
+#endif
 #ifndef ANM_RADIAL_PREFETCH
 #define ANM_RADIAL_PREFETCH 1
 #endif
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     static_assert(A_N >= 10, "group::newton_groups<.., LDSX> takes 640 doubles");
     // (per-environment parameters cost this kernel nine registers: two child slots per fetch round instead of three keep
     // it at three wavefronts per SIMD)
-    group::newton_groups<TT, JT, 10, TT::T_DPP == 0, PG ? 2 : ANM_LDSX_FETCH>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn,
+    group::newton_groups<TT, JT, 10, TT::T_DPP == 0, PG ? 2 : ANM_LDSX_FETCH, true, ANM_RADIAL_VPOLY != 0 && !PG>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn,
                                                                             so.tol, so.max_iter, &sh[0][0]);
     int back_lane;   // the lane that plays bus l + 1
     if constexpr (TT::T_LP_NW > 0) back_lane = int(V.pk[TT::T_LP_NW - 1]);
