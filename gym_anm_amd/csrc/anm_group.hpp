@@ -342,7 +342,11 @@ constexpr int hyb_slot_base(int h) {
 #define ANM_LDSX_BS_ALL 1
 #endif
 // Padding lanes never publish; their slots hold the neutral values (zeroed here, V = 1).
-template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH, bool WFREE = true, bool VPOLY = !LDSX>
+// MERGED = false: the loop as it stood before the instruction-count cuts of round 6 (one region per fold, predicated child
+// sums, no copies): 21 registers fewer -- what the radial kernel with per-group classes needs on a tree with a DPP plan to keep
+// three wavefronts per SIMD.
+template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH, bool WFREE = true, bool VPOLY = !LDSX,
+          bool MERGED = (ANM_GROUP_MERGED_REGIONS != 0)>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
                                               double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
                                               double tol, int max_iter, double* xl = nullptr) {
@@ -414,8 +418,8 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
     // does, so these zeros are the neutral values the hand-overs rely on.
     Blk<JT> Sc = Blk<JT>{JT(0), JT(0), JT(0), JT(0)};
     JT Lr0 = JT(0), Lr1 = JT(0), d0 = JT(0), d1 = JT(0);
-    constexpr bool ROOT_STEP_IN_PIVOT = !LDSX && !(LDSX && T::T_HYB != 0) && T::T_LP_NW > 0 && ANM_GROUP_MERGED_REGIONS != 0;
-    constexpr bool WSUM_FREE = WFREE && !LDSX && ANM_GROUP_MERGED_REGIONS != 0 && T::T_MAXCH > 0 && child_moves_land_on_parents_or_zero<T>();
+    constexpr bool ROOT_STEP_IN_PIVOT = !LDSX && !(LDSX && T::T_HYB != 0) && T::T_LP_NW > 0 && MERGED;
+    constexpr bool WSUM_FREE = WFREE && !LDSX && MERGED && T::T_MAXCH > 0 && child_moves_land_on_parents_or_zero<T>();
     constexpr bool WSUM_ONE = WSUM_FREE && child_moves_write_the_same_lanes<T>();
     [[maybe_unused]] double wr[T::T_MAXCH > 0 ? T::T_MAXCH : 1] = {0.0}, wi[T::T_MAXCH > 0 ? T::T_MAXCH : 1] = {0.0};
     [[maybe_unused]] int trip = 0;
@@ -437,7 +441,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
       const double wbp_r = fma(ybp_r, pr, ybp_i * pim), wbp_i = fma(ybp_r, pim, -(ybp_i * pr));
       // (TRIM: the imaginary part is carried with its sign flipped -- the flip rides on the operands of its consumers instead of
       // being an instruction in front of the moves that hand it to the parent)
-      constexpr bool TRIM = ANM_GROUP_MERGED_REGIONS != 0;   // (the LDS variant too: what it publishes is the unflipped value)
+      constexpr bool TRIM = MERGED;   // (the LDS variant too: what it publishes is the unflipped value)
       const double wpb_r = fma(ypb_r, pr, -(ypb_i * pim)), nwpb_i = fma(ypb_r, pim, ypb_i * pr);
       [[maybe_unused]] const double wpb_i = -nwpb_i;
       // S_b = W_bb + W_bp + sum over the children c of W_pb(c)
@@ -477,7 +481,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
 #ifndef ANM_GROUP_FLAG_OR
 #define ANM_GROUP_FLAG_OR 0   // (measured, same box: headline kernel 74.7 us without, 79.2 us with -- the butterfly sits on the exit chain)
 #endif
-      constexpr bool FLAG_OR = ANM_GROUP_FLAG_OR != 0 && !LDSX && ANM_GROUP_MERGED_REGIONS != 0 && T::T_DPP != 0 && (T::GRP == 8 || T::GRP == 16);
+      constexpr bool FLAG_OR = ANM_GROUP_FLAG_OR != 0 && !LDSX && MERGED && T::T_DPP != 0 && (T::GRP == 8 || T::GRP == 16);
       if constexpr (FLAG_OR) {
         // the two verdicts as bits of one word per bus lane (1: above the tolerance or NaN, 2: NaN; a padding lane: 0), OR-ed
         // over the group by a butterfly of DPP-operand v_or_b32 (quad swaps, half-row mirror, row mirror for 16 lanes): every
@@ -580,7 +584,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           }
           if constexpr (h < T::T_MAXH) ANM_WAVE_SYNC();
         });
-      } else if constexpr (!LDSX && T::T_LP_NW > 0 && ANM_GROUP_MERGED_REGIONS != 0) {
+      } else if constexpr (!LDSX && T::T_LP_NW > 0 && MERGED) {
         // Register hand-overs, every child folded at the level right after its OWN (see the next variant), with the
         // predicated code of a level gathered: all moves of the level first (every lane executes them), then ONE region
         // for the buses of this height -- their folds (no predicate of its own for a child class every bus of this height

@@ -501,7 +501,8 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
     static_assert(A_N >= 10, "group::newton_groups<.., LDSX> takes 640 doubles");
     // (per-environment parameters cost this kernel nine registers: two child slots per fetch round instead of three keep
     // it at three wavefronts per SIMD)
-    group::newton_groups<TT, JT, 10, TT::T_DPP == 0, PG ? 2 : ANM_LDSX_FETCH, true, ANM_RADIAL_VPOLY != 0 && !PG>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn,
+    group::newton_groups<TT, JT, 10, TT::T_DPP == 0, PG ? 2 : ANM_LDSX_FETCH, true, ANM_RADIAL_VPOLY != 0 && !PG,
+                         (ANM_GROUP_MERGED_REGIONS != 0) && !(PG && TT::T_DPP != 0)>(V, env_ok && !skip, gvm, gcs, gsn, gp, gq, git, tb, tn,
                                                                             so.tol, so.max_iter, &sh[0][0]);
     int back_lane;   // the lane that plays bus l + 1
     if constexpr (TT::T_LP_NW > 0) back_lane = int(V.pk[TT::T_LP_NW - 1]);

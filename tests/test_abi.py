@@ -165,7 +165,10 @@ def test_register_budgets_of_the_occupancy_critical_kernels():
     budgets = {   # kernel substring -> (max VGPRs, max scratch bytes): wavefronts per SIMD = floor(512 / VGPRs)
         "anm6": {"k_step_rows<double, false>": (256, 0), "k_step_stragglers<double, true>": (256, 0), "k_step_general<double>": (256, 0),
                  "k_transition<double, false, false>": (256, 0),   # (the anm_model_bind_nr_start path is an instantiation of its own)
-                 "k_reset<double, false>": (256, 0)},
+                 "k_reset<double, false>": (256, 0),
+                 # the 6-bus feeder through the radial family (list observations / per-environment classes of a mixed batch):
+                 # three wavefronts per SIMD, with per-group classes too (that instantiation keeps the lean group loop)
+                 "k_radial<double, (anonymous namespace)::Topo, false>": (168, 0), "k_radial<double, (anonymous namespace)::Topo, true>": (168, 0)},
         "case30": {"k_radial<double, (anonymous namespace)::Topo, false>": (168, 0), "k_radial<double, void, false>": (168, 0),
                    "k_mesh<double, false, false, 2, true>": (256, 32),   # (32 B: four doubles of the epilogue, outside the Newton loop)
                    "k_mesh<double, false, false, 3, true>": (168, 160),   # small networks, three wavefronts per SIMD (mesh::Launch)
