@@ -786,7 +786,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
           sincos_medium<true>(dth, sd_, cd_);
           // (beyond the two-stage reduction: a handful of lanes per million solves -- the library routine then runs on every
           // lane of the wavefront and the lanes it was called for take its result: no divergent region in this tail)
-          const bool ish = !(fabs(dth) < 4.0e15);
+          const bool ish = !(fabs(dth) < SINCOS_MEDIUM_MAX);
           if ((__builtin_amdgcn_uicmp(ish ? 1u : 0u, 0u, ICMP_NE) & updm) != 0ull) {
             const SinCos r = sincos_huge(dth);
             sd_ = ish ? r.s : sd_;
@@ -815,7 +815,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         }
       } else if (upd) {
         double sd_, cd_;
-        if (fabs(dth) < 4.0e15) {
+        if (fabs(dth) < SINCOS_MEDIUM_MAX) {
           sincos_medium<!LDSX>(dth, sd_, cd_);
         } else {
           const SinCos r = sincos_huge(dth);

@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(WG ? 512 : 256, SW == 2 ? ANM_MESH_MINWAVES2 : SW) 
       double sd_, cd_;
       if (fabs(dth) <= 0.78) {
         sincos_kernel(dth, 0, sd_, cd_);
-      } else if (fabs(dth) < 4.0e15) {
+      } else if (fabs(dth) < SINCOS_MEDIUM_MAX) {
         sincos_medium(dth, sd_, cd_);
       } else {
         const SinCos r = sincos_huge(dth);

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(64, ANM_RADIAL_WAVES) void k_radial(Dims d, const i
       double sd_, cd_;
       if (fabs(dth) <= 0.78) {
         sincos_kernel(dth, 0, sd_, cd_);
-      } else if (fabs(dth) < 4.0e15) {
+      } else if (fabs(dth) < SINCOS_MEDIUM_MAX) {
         sincos_medium(dth, sd_, cd_);
       } else {
         const SinCos r = sincos_huge(dth);
