@@ -842,3 +842,43 @@ def test_reset_and_step_through_views_of_a_mixed_batch():
             for name, mine, theirs in (("reward", reward[ix], o.reward), ("e_loss", e_loss[ix], o.e_loss),
                                        ("penalty", penalty[ix], o.penalty)):
                 assert torch.equal(mine, theirs), (t, k, name)
+
+
+@pytest.mark.parametrize("impl,E", [("thread", 65536), ("radial", 16384)])
+def test_a_solve_that_blows_up_does_not_reach_its_neighbours(impl, E):
+    """The lane groups of a wavefront hold different environments, and some hand-overs of the lane-group Newton loop
+    are predicate-free (round 6: child sums through a register that is zero wherever no move writes; padding lanes
+    whose products are 0 x whatever their own moves read).  None of that may carry a diverging neighbour's Inf / NaN
+    into a healthy solve: the batch with every non-converging environment replaced by a benign one must leave all OTHER
+    environments bit for bit as they were -- including the slow converging solves that shared lane groups with them."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.simulator import BatchedSimulator
+
+    g = torch.Generator(device=DEV).manual_seed(7)
+
+    def U(lo, hi, n):
+        return lo + (hi - lo) * torch.rand((E, n), generator=g, dtype=torch.float64, device=DEV)
+
+    pl = -U(0, 1, 3) * torch.tensor([10.0, 30.0, 30.0], device=DEV)
+    pp = U(0, 1, 2) * torch.tensor([30.0, 50.0], device=DEV)
+    ps = torch.cat([U(0, 30, 1), U(0, 50, 1), U(-50, 50, 1)], 1)
+    qs = U(-50, 50, 3)
+    soc = U(0, 100, 1) / 100
+
+    def run(pl, pp, ps, qs, soc):
+        sim = BatchedSimulator(networks.anm6_network(), 0.25, 100, num_envs=E, device=DEV, tol=1e-6, max_iter=100, impl=impl)
+        sim.soc.copy_(soc)
+        sim.transition(pl, pp, ps, qs)
+        torch.cuda.synchronize()
+        return sim.full.clone(), sim.pfe_converged.clone(), sim.nr_iters.clone()
+
+    full1, conv1, it1 = run(pl, pp, ps, qs, soc)
+    bad = ~conv1
+    assert int(bad.sum()) >= E // 1000 and bool(conv1[0])              # a few hundred solves that run to the cap or fail
+    assert int((conv1 & (it1 > 6)).sum()) >= 8                          # ... and slow converging ones that met them on lane groups
+    rep = lambda x: torch.where(bad[:, None], x[0:1].expand_as(x), x)  # noqa: E731  (environment 0 converges)
+    full2, conv2, it2 = run(rep(pl), rep(pp), rep(ps), rep(qs), rep(soc))
+    keep = ~bad
+    assert bool(conv2.all())
+    assert torch.equal(it1[keep], it2[keep]) and torch.equal(conv1[keep], conv2[keep])
+    assert torch.equal(full1[keep].view(torch.int64), full2[keep].view(torch.int64))
