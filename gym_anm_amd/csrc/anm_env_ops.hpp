@@ -9,6 +9,14 @@
 #include "anm_device.hpp"
 #include "anm_group.hpp"
 
+// In-wave continuation of the diverging solves: the lane-group loop WITHOUT its short sincos path (group::newton_groups:
+// REDUCE_ALWAYS), on the idea that a launch lasts as long as its slowest wavefront, whose trips reduce anyway -- measured and
+// left off: headline kernel 72.6 -> 76.3 us, same box (profiles/r06_r_s_worst_wavefront.txt): the slowest wavefront, too, takes
+// the short path on most of its trips.
+#ifndef ANM_INWAVE_REDUCE_ALWAYS
+#define ANM_INWAVE_REDUCE_ALWAYS 0
+#endif
+
 namespace anm {
 
 // Parameter classes (anm_model_set_classes): networks with the topology of the model and other numbers.  The
@@ -147,7 +155,7 @@ ANM_HD void op_transition(cptr_t C, const TransitionIO& io, SolverOpts so, int64
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (T::TREE != 0)
       if (cap < so.max_iter && ANM_WAVE_ANY(st.active && valid))
-        group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
+        group::continue_in_groups<T, JT, true, ANM_INWAVE_REDUCE_ALWAYS != 0>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
 #endif
     transition_end<T>(C, w, st, so.tol);
   }
@@ -324,7 +332,7 @@ ANM_HD void reset_from(cptr_t C, const EnvIO& io, SolverOpts so, int64_t e, cons
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (T::TREE != 0)
       if (cap < so.max_iter && ANM_WAVE_ANY(st.active && act))
-        group::continue_in_groups<T, JT>(C, w, st, st.active && act, so.tol, so.max_iter, lds);
+        group::continue_in_groups<T, JT, true, ANM_INWAVE_REDUCE_ALWAYS != 0>(C, w, st, st.active && act, so.tol, so.max_iter, lds);
 #endif
     transition_end<T>(C, w, st, so.tol);
   }
@@ -746,7 +754,7 @@ __device__ void op_step_view(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, handoff >= 0 ? handoff : so.max_iter);
   if constexpr (CAN_GROUP) {
     if (handoff >= 0 && ANM_WAVE_ANY(st.active && valid))
-      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
+      group::continue_in_groups<T, JT, true, ANM_INWAVE_REDUCE_ALWAYS != 0>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
   }
   step_end<T, 1>(C, io, so, e, ctx, w, st, out);
   if (!valid) return;
@@ -891,7 +899,7 @@ __device__ void op_step_rows(cptr_t C, const EnvIO& io, SolverOpts so, int64_t n
   }
   if constexpr (CAN_GROUP) {
     if ((handoff >= 0 || overflow_to_groups) && ANM_WAVE_ANY(st.active && valid))
-      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
+      group::continue_in_groups<T, JT, true, ANM_INWAVE_REDUCE_ALWAYS != 0>(C, w, st, st.active && valid, so.tol, so.max_iter, lds);
   }
   step_end<T, 1>(C, io, so, ec, ctx, w, st, out);
   const bool store = valid && !pending;
@@ -977,7 +985,7 @@ __device__ void op_step_general(cptr_t C, const EnvIO& io, SolverOpts so, int64_
   pf_iterate<T, JT>(C, w, st, so.tol, so.max_iter, handoff >= 0 ? handoff : so.max_iter);
   if constexpr (CAN_GROUP) {
     if (handoff >= 0 && ANM_WAVE_ANY(st.active && valid))
-      group::continue_in_groups<T, JT>(C, w, st, st.active && valid, so.tol, so.max_iter, ldsB);
+      group::continue_in_groups<T, JT, true, ANM_INWAVE_REDUCE_ALWAYS != 0>(C, w, st, st.active && valid, so.tol, so.max_iter, ldsB);
   }
   if (!ctx.absorbing) transition_end<T>(C, w, st, so.tol);
 

@@ -346,7 +346,7 @@ constexpr int hyb_slot_base(int h) {
 // sums, no copies): 21 registers fewer -- what the radial kernel with per-group classes needs on a tree with a DPP plan to keep
 // three wavefronts per SIMD.
 template <class T, class JT, int EARLY_EXIT_TRIPS = 0, bool LDSX = false, int FETCH = ANM_LDSX_FETCH, bool WFREE = true, bool VPOLY = !LDSX,
-          bool MERGED = (ANM_GROUP_MERGED_REGIONS != 0)>
+          bool MERGED = (ANM_GROUP_MERGED_REGIONS != 0), bool REDUCE_ALWAYS = false>
 __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid, double& vm, double& cs, double& sn,
                                               double bus_p, double bus_q, int& it, unsigned& tb, unsigned& tn,
                                               double tol, int max_iter, double* xl = nullptr) {
@@ -780,7 +780,10 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
         // computes on whatever its dth holds and drops the result -- so that the wave-uniform branch is the only control
         // flow in front of them, and the rotation stands once behind both paths)
         double sd_, cd_;
-        if (bigm == 0ull) {
+        // (REDUCE_ALWAYS: no short path -- the range reduction of a small step returns the step itself and quadrant 0, the
+        // same bits; for a launch that lasts as long as its slowest wavefront, whose trips reduce anyway, the test and the
+        // branch in front of the short path are four instructions of every trip)
+        if (!REDUCE_ALWAYS && bigm == 0ull) {
           sincos_kernel<true>(dth, 0, sd_, cd_);
         } else {
           sincos_medium<true>(dth, sd_, cd_);
@@ -840,7 +843,7 @@ __device__ __forceinline__ void newton_groups(const LaneView<T>& V, bool gvalid,
 // `lds`: >= NG * Slot<T>::SIZE doubles, private to this wavefront; every lane of the wave must call.
 // WFREE = false: the predicate-free child sums (four to eight loop-carried registers) left out -- the straggler launch, whose
 // budget is two wavefronts per SIMD.
-template <class T, class JT, bool WFREE = true>
+template <class T, class JT, bool WFREE = true, bool REDUCE_ALWAYS = false>
 __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFState<T>& st, bool mine, double tol, int max_iter,
                                    double* lds) {
   typedef Slot<T> S;
@@ -879,7 +882,7 @@ __device__ __forceinline__ void continue_in_groups(cptr_t C, EnvWork<T>& w, PFSt
     }
     ANM_WAVE_SYNC();
     unsigned tb, tn;
-    newton_groups<T, JT, 0, false, ANM_LDSX_FETCH, WFREE>(V, gvalid, vm, cs, sn, bus_p, bus_q, it, tb, tn, tol, max_iter);
+    newton_groups<T, JT, 0, false, ANM_LDSX_FETCH, WFREE, true, (ANM_GROUP_MERGED_REGIONS != 0), REDUCE_ALWAYS>(V, gvalid, vm, cs, sn, bus_p, bus_q, it, tb, tn, tol, max_iter);
 
     // ---- results back to the owner lanes
     if (isbus) {
