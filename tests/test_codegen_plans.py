@@ -126,3 +126,91 @@ def test_stock_headers_carry_the_plans():
     assert "T_DPP = 1" in h6 and "T_HYB = 0" in h6 and get(h6, "T_CLS_H") == [0, 0, 1, 1, 1, 0]
     assert "T_DPP = 0" in h30 and "T_HYB = 1" in h30 and "T_ALL_HEAVY = 1" in h30
     assert get(h30, "T_NLH") == [0, 2, 1, 1, 2] and get(h30, "T_NCH_H") == [0, 3, 4, 3, 5]
+
+
+def _ints(hdr, name):
+    return [int(x) for x in re.search(r"%s\[\d+\] = \{([^}]*)\}" % name, hdr).group(1).split(",")]
+
+
+def child_moves_land_on_parents_or_zero(hdr):
+    """csrc/anm_group.hpp's compile-time check of the same name, restated on a descriptor's text: the (single, bank-masked)
+    DPP move of every child class delivers to each bus lane it writes that bus's child of the class, or the product of a
+    padding lane whose own parent moves read a lane of the SAME group (or nothing); and every child is delivered."""
+    grp, maxch = int(re.search(r"GRP = (\d+)", hdr).group(1)), int(re.search(r"T_MAXCH = (\d+)", hdr).group(1))
+    if "T_DPP = 1" not in hdr or grp > 16:
+        return False
+    lane_bus, pos, ch = _ints(hdr, "T_LANE_BUS"), _ints(hdr, "T_POS"), _ints(hdr, "T_CH")
+    ch_n, ch_ctrl, ch_bank, ch_full = (_ints(hdr, "T_CH_" + k) for k in ("N", "CTRL", "BANK", "FULL"))
+    par_n = int(re.search(r"T_PAR_N = (\d+)", hdr).group(1))
+    par_ctrl, par_bank, par_full = (_ints(hdr, "T_PAR_" + k) for k in ("CTRL", "BANK", "FULL"))
+    n_bus = len(pos)
+
+    def src_of(ctrl, lane):
+        k, kind = ctrl & 0xF, ctrl & 0x1F0
+        assert kind in (0x100, 0x110)
+        s = lane + k if kind == 0x100 else lane - k
+        return s if 0 <= s <= 15 else None
+
+    for c in range(maxch):
+        if ch_n[c] != 1 or ch_full[2 * c] != 0:
+            return False
+        for lane in range(16):
+            if not (ch_bank[2 * c] >> (lane // 4)) & 1:
+                continue
+            sl = src_of(ch_ctrl[2 * c], lane)
+            if sl is None:
+                continue
+            R, S = lane_bus[lane % grp], lane_bus[sl % grp]
+            if R == 0:
+                continue
+            if S == 0:
+                src = None
+                for m in range(par_n):
+                    if not par_full[m] and not (par_bank[m] >> (sl // 4)) & 1:
+                        continue
+                    q = src_of(par_ctrl[m], sl)
+                    if q is None:
+                        if par_full[m]:
+                            src = None
+                        continue
+                    src = q
+                if src is not None and src // grp != lane // grp:
+                    return False
+                continue
+            if lane // grp != sl // grp or ch[R * maxch + c] != S:
+                return False
+    for b in range(1, n_bus):
+        for c in range(maxch):
+            k = ch[b * maxch + c]
+            if k <= 0:
+                continue
+            sl = src_of(ch_ctrl[2 * c], pos[b])
+            if not (ch_bank[2 * c] >> (pos[b] // 4)) & 1 or sl is None or sl >= grp or lane_bus[sl] != k:
+                return False
+    return True
+
+
+def test_the_stock_feeder_gets_a_layout_with_predicate_free_child_sums():
+    """codegen.dpp_plan's tie-break (round 6): among the equal-cost DPP layouts of the 6-bus feeder one whose child moves land on
+    parents or on same-environment zeros -- the lane-group loop then sums the children's W products without a predicate
+    (what the headline's trip count rests on)."""
+    from gym_anm_amd import networks
+    from gym_anm_amd.model import NetworkModel
+
+    assert child_moves_land_on_parents_or_zero(codegen.emit_header(codegen.stock_topologies()["anm6"]))
+    for seed in (0, 2):   # (the 5-bus test trees of the GPU tier have whole-row first moves: zeros arrive by bound_ctrl, another path)
+        topo = NetworkModel(networks.synthetic_radial_network(5, seed), 0.25, 100).topology()
+        hdr = codegen.emit_header(topo)
+        assert "T_DPP = 1" in hdr and not child_moves_land_on_parents_or_zero(hdr) and 1 in _ints(hdr, "T_CH_FULL")
+    # and the check does say no: the feeder's layout of the first half of the round (a padding lane there read the first bus of
+    # the NEXT group as its parent, so its zero product could have been 0 x that environment's Inf)
+    hdr = codegen.emit_header(codegen.stock_topologies()["anm6"])
+    old = hdr.replace(_line(hdr, "T_LANE_BUS"), "  static constexpr int T_LANE_BUS[8] = {5, 3, 0, 0, 4, 2, 1, 0};")
+    old = old.replace(_line(old, "T_POS"), "  static constexpr int T_POS[6] = {0, 6, 5, 1, 4, 0};")
+    old = old.replace(_line(old, "T_PAR_CTRL"), "  static constexpr int T_PAR_CTRL[2] = {257, 261};")
+    old = old.replace(_line(old, "T_CH_CTRL"), "  static constexpr int T_CH_CTRL[4] = {273, 0, 277, 0};")
+    assert not child_moves_land_on_parents_or_zero(old)
+
+
+def _line(hdr, name):
+    return next(l for l in hdr.split("\n") if (" " + name + "[") in l)

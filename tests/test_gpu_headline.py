@@ -473,6 +473,23 @@ def test_small_tree_without_a_dpp_plan_against_oracle(impl, handoff):
     assert sim.impl == impl and not sim.backend.generic
 
 
+@pytest.mark.parametrize("n_bus,seed,handoff", [(5, 0, 0), (5, 2, 2)])
+def test_small_trees_with_a_dpp_plan_other_than_the_stock_feeder_against_oracle(n_bus, seed, handoff):
+    """The register hand-over variant of the lane-group loop on DPP lane layouts other than ANM6's (two 5-bus trees:
+    codegen.dpp_plan picks among the equal-cost layouts one whose child moves land on parents or same-environment zeros, the
+    kernel then sums children without a predicate): every solve handed over from iteration 0 / 2, case by case against the
+    oracle -- diverging cases sharing wavefronts with converging ones included."""
+    from gym_anm_amd import codegen, networks
+    from gym_anm_amd.model import NetworkModel
+
+    net = networks.synthetic_radial_network(n_bus, seed)
+    topo = NetworkModel(net, 0.25, 100).topology()
+    assert "T_DPP = 1" in codegen.emit_header(topo)
+    codegen.build_library(topo)
+    sim = _mesh_network_against_oracle(n_bus, seed, 0, 192, 1.0, 6, net=net, impl="thread", handoff_after=handoff)
+    assert sim.impl == "thread" and not sim.backend.generic
+
+
 def _mesh_network_against_oracle(n_bus, seed, n_chords, M, load_scale, n_hopeless, net=None, impl="mesh", handoff_after=None):
     import anm_oracle as O
     from gym_anm_amd import networks
