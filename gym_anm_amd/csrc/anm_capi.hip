@@ -42,6 +42,10 @@ int fail_hip(hipError_t e, const char* where) {
   return -2;
 }
 
+// (in-wave hand-over point; end of round 6, with the lane-group trip at half a thread-mode trip: 5 / 6 / 7 -> 73.7 / 74.3 / 74.8 us
+// per step at 65 536 environments, four rounds, profiles/r06_z_handoff.txt.  6 stays: it is also where the two-launch step of the
+// larger batches hands over, and the two step modes are bit-identical under the automatic policy only at the same point --
+// a batch's results must not depend on its size.)
 #ifndef ANM_HANDOFF_DEFAULT
 #define ANM_HANDOFF_DEFAULT 6
 #endif

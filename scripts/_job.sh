@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python scripts/straggler_levels_r06.py 2>&1 | grep "^E " | tee gpurun_out/r06_y_levels.txt
+python scripts/handoff_r06.py 2>&1 | grep "@" | tee gpurun_out/r06_z_handoff.txt
